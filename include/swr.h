@@ -1,0 +1,315 @@
+/*
+ * swr.h -- C ABI of the MI355X-native multi-domain CTR hot path ("libswr").
+ *
+ * The reference (Xiaopengli1/Scenario-Wise-Rec) has no FFI / plugin layer: the
+ * boundary its hot path sits behind is the Python module API
+ * (scenario_wise_rec.basic.layers / .models.multi_domain / .trainers), and the
+ * arithmetic is dispatched to ATen.  This header is the operator boundary a
+ * replacement for that ATen work binds to; every entry point cites the
+ * reference call site whose work it replaces (paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes stub a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *  - plain C symbols, plain pointers and sizes, no C++ / torch types;
+ *  - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *  - the caller owns every buffer; the library allocates nothing persistent
+ *    (scratch comes in through explicit `workspace` arguments whose size the
+ *    matching `*_workspace_bytes` call returns);
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *    performs no hidden synchronisation and is capturable into a hipGraph;
+ *  - return value: SWR_OK (0) or a negative swr_status; nothing throws;
+ *  - re-entrant and thread-safe for distinct streams / workspaces;
+ *  - matrices are row-major fp32 with an explicit leading dimension (`ld*`,
+ *    in elements).
+ */
+#ifndef SWR_H_
+#define SWR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWR_ABI_VERSION 1
+
+typedef enum {
+    SWR_OK = 0,
+    SWR_ERR_ARG = -1,         /* NULL pointer, negative size, bad enum */
+    SWR_ERR_DTYPE = -2,       /* unsupported element type */
+    SWR_ERR_ALIGN = -3,       /* pointer / leading dimension not aligned as required */
+    SWR_ERR_LAUNCH = -4,      /* hip launch / runtime error */
+    SWR_ERR_UNSUPPORTED = -5, /* shape outside the implemented envelope */
+    SWR_ERR_WORKSPACE = -6    /* workspace too small */
+} swr_status;
+
+/* element types of caller-provided index / value columns: the reference casts
+ * with `.long()` / `.float()` (basic/layers.py:70,89) after
+ * `reduce_mem_usage` may have narrowed them (utils/data.py:109-124) */
+typedef enum {
+    SWR_I8 = 1, SWR_I16 = 2, SWR_I32 = 3, SWR_I64 = 4, SWR_U8 = 5,
+    SWR_F16 = 6, SWR_BF16 = 7, SWR_F32 = 8, SWR_F64 = 9, SWR_BOOL = 10
+} swr_dtype;
+
+/* bits of the device-side error word (`err_flag` arguments, may be NULL) */
+#define SWR_FLAG_INDEX_OOR 1u      /* embedding index outside [0, vocab): torch raises IndexError */
+#define SWR_FLAG_GRAD_RANGE 2u     /* |embedding grad| >= 2^20: outside the fixed-point accumulator */
+
+int swr_abi_version(void);
+const char* swr_status_str(int status);
+/* 1 when a HIP device is visible to the calling process (no compute is done) */
+int swr_device_available(void);
+
+/* ------------------------------------------------------------------ K1 ----
+ * EmbeddingLayer.forward(x, features, squeeze_dim=True)
+ * (basic/layers.py:64-105): F_s row gathers + F_d casts + two cats, fused
+ * into ONE launch that writes straight into the [B, K0] concat layout
+ * (sparse block first, dense columns last -- the caller assigns `out_col`).
+ * Optional hash stage (build-side addition, the reference has none): when
+ * `hash_seed != 0` the raw id is mapped to row = mix64(id ^ seed) % vocab.
+ * `keys_out` (nullable) receives the looked-up row of every (slot, sample) as
+ * uint32 [n_sparse * B]; the backward consumes it. */
+typedef struct {
+    const float* weight;   /* [vocab, dim] table */
+    const void* idx;       /* [B] ids, type idx_dtype */
+    int64_t vocab;
+    int32_t dim;
+    int32_t idx_dtype;     /* swr_dtype, integer kinds */
+    int32_t out_col;       /* first output column */
+    uint32_t hash_seed;    /* 0 = ids are rows (the reference behaviour) */
+} swr_sparse_slot;
+
+typedef struct {
+    const void* values;    /* [B] */
+    int32_t dtype;         /* swr_dtype */
+    int32_t out_col;
+} swr_dense_slot;
+
+int swr_embed_gather_fwd(const swr_sparse_slot* sparse_host, int n_sparse,
+                         const swr_dense_slot* dense_host, int n_dense,
+                         int64_t B, float* out, int64_t ld_out,
+                         uint32_t* keys_out, uint32_t* err_flag, void* stream);
+
+/* ------------------------------------------------------------------ K3 ----
+ * Backward of the lookup: replaces aten::embedding_dense_backward (32 calls
+ * per step at the KuaiRand config, each zero-filling [V, E]).
+ * All slots are reduced together: sort (table, row) keys, then a segmented
+ * reduction in dual-limb 64-bit fixed point, so the result does not depend on
+ * the order in which partial sums meet (bitwise deterministic, and identical
+ * on every data-parallel rank).  Slots that share a table (`shared_with`,
+ * basic/layers.py:71-72) carry the same `table_id` and sum into one gradient.
+ *   mode 0 (dense) : grad_dense[vocab, dim] is fully written (zeros included);
+ *   mode 1 (sparse): for large tables; `urow` / `ugrad` have one entry per
+ *                    looked-up sample of the table, in sorted-row order:
+ *                    urow[i] = row (first entry of each distinct row) or -1,
+ *                    ugrad[i, :] = summed gradient of that row (or 0).
+ * Sparse-mode tables must have the largest table ids. */
+typedef struct {
+    int64_t vocab;
+    int32_t dim;
+    int32_t in_col;        /* first column of this slot in dE */
+    int32_t table_id;      /* 0..n_tables-1 */
+    int32_t mode;          /* 0 dense, 1 sparse */
+    float* grad_dense;     /* mode 0: [vocab, dim] of the TABLE (same pointer for sharing slots) */
+    int32_t* urow;         /* mode 1: [count of samples of this table] */
+    float* ugrad;          /* mode 1: [count, dim] */
+} swr_embed_grad_slot;
+
+size_t swr_embed_bwd_workspace_bytes(const swr_embed_grad_slot* slots_host, int n_slots, int64_t B);
+int swr_embed_bwd(const swr_embed_grad_slot* slots_host, int n_slots,
+                  const uint32_t* keys /* [n_slots * B] from the forward */,
+                  const float* dE, int64_t ld, int64_t B,
+                  void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream);
+
+/* ------------------------------------------------------------------ K2 ----
+ * fp32 matrix products on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact
+ * fp32 fused multiply-add chains in k order).  They replace aten::addmm / mm
+ * of nn.Linear forward and backward (basic/layers.py:253-260) and of STAR's
+ * `x @ (W_s * W_d)` (models/multi_domain/star.py:103-107).
+ * `groups` > 1 runs independent problems (per-domain towers / experts) in one
+ * launch; `gs*` are the element strides between consecutive groups.
+ *
+ *   nt:  C[m, n] = sum_k A[m, k] * B[n, k] (+ bias[n])      Linear forward, dX of [in,out] weights
+ *   nn:  C[m, n] = sum_k A[m, k] * B[k, n] (+ bias[n])      dX of Linear, forward of [in,out] weights
+ *   tn:  C[k1, k2] = sum_m A[m, k1] * B[m, k2]              weight gradients (reduction over the batch)
+ *
+ * nt / nn options:
+ *   a_scale / a_shift (nullable, [K] per group): the A operand is read as
+ *     relu?(a_scale[k] * A[m,k] + a_shift[k]) -- the previous layer's
+ *     BatchNorm + ReLU applied on the fly;
+ *   stat_partials (nullable): per 32-row tile and output column the pair
+ *     (mean, M2 = sum (c - mean)^2) of the tile's rows, laid out
+ *     [ceil(M/32)][groups][N][2] (= [tiles][groups*N][2], so the
+ *     groups of one launch finalise as ONE BatchNorm over groups*N columns);
+ *     swr_bn_finalize merges them (Chan) in fp64;
+ *   accumulate != 0: C += result (gradient fan-in).
+ * tn: the batch is split over workgroups; partial products go to `workspace`
+ *   and are summed in a fixed order (deterministic).  `colsum` (nullable,
+ *   [groups][K1]) additionally receives sum_m A[m, k1] (bias gradient). */
+typedef struct {
+    int64_t M;
+    int32_t N, K;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    const float* bias;
+    float* C; int64_t ldc;
+    const float* a_scale; const float* a_shift; int32_t a_relu;
+    int32_t accumulate;
+    float* stat_partials;
+    int32_t groups;
+    int64_t gsA, gsB, gsC, gsBias, gsScale;
+} swr_gemm_args;
+
+int swr_gemm_nt(const swr_gemm_args* args_host, void* stream);
+int swr_gemm_nn(const swr_gemm_args* args_host, void* stream);
+
+typedef struct {
+    int64_t M;
+    int32_t K1, K2;
+    const float* A; int64_t lda;   /* [M, K1] */
+    const float* B; int64_t ldb;   /* [M, K2] */
+    float* C; int64_t ldc;         /* [K1, K2] */
+    float* colsum;                 /* nullable [K1] */
+    int32_t accumulate;
+    int32_t groups;
+    int64_t gsA, gsB, gsC, gsColsum;
+} swr_gemm_tn_args;
+
+size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args_host);
+int swr_gemm_tn(const swr_gemm_tn_args* args_host, void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------- BatchNorm1d ----
+ * nn.BatchNorm1d(eps, momentum=0.1) of every MLP block
+ * (basic/layers.py:253-258).  Training: batch mean and BIASED batch variance
+ * normalise; running_var takes the UNBIASED variance.  The statistics come
+ * from the producing GEMM's `stat_partials`. */
+int swr_bn_finalize(const float* stat_partials, int n_tiles, int64_t M, int N,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, int n_tracked /* counters to bump (fused BN modules) */,
+                    float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale */
+int swr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int N, float* scale, float* shift, void* stream);
+
+/* activation applied after the affine, per column range (basic/activation.py:27-54) */
+typedef enum { SWR_ACT_NONE = 0, SWR_ACT_RELU = 1, SWR_ACT_SIGMOID = 2, SWR_ACT_SOFTMAX = 3 } swr_act;
+typedef struct {
+    int32_t col_lo, col_hi;   /* [col_lo, col_hi) */
+    int32_t act;              /* swr_act */
+    int32_t group;            /* softmax: width of each softmax group (Softmax(dim=1) of one gate) */
+} swr_act_range;
+#define SWR_MAX_ACT_RANGES 4
+
+/* Y[m, n] = act(scale[n] * Z[m, n] + shift[n]); scale/shift NULL = identity affine */
+int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scale, const float* shift,
+                       const swr_act_range* acts_host, int n_acts,
+                       float* Y, int64_t ldy, int64_t M, int N, void* stream);
+
+/* Backward of Y = act(BN_train(Z)):
+ *   pass 1  dA = act'(Y) * dY;  partials of S1[n] = sum dA, S2[n] = sum dA * xhat   ([n_tiles][N][2], 64-row tiles)
+ *   finalize dgamma = S2, dbeta = S1, coefficients of dZ = ca*dA + cb*Z + cc
+ *   pass 2  dZ
+ * (torch native_batch_norm_backward; SURVEY.md fact 1: dZ is dense in every
+ * row, other domains' rows included). */
+int swr_bn_act_bwd_stats(const float* dY, int64_t lddy, const float* Y, int64_t ldy,
+                         const float* Z, int64_t ldz, const float* mean, const float* rstd,
+                         const swr_act_range* acts_host, int n_acts,
+                         float* partials, int64_t M, int N, void* stream);
+int swr_bn_bwd_finalize(const float* partials, int n_tiles, int64_t M, int N,
+                        const float* gamma, const float* rstd,
+                        float* dgamma, float* dbeta, int accumulate,
+                        float* ca, float* cb, float* cc, void* stream);
+/* dZ = ca[n] * act'(Y) * dY + cb[n] * (Z - mean[n]) + cc[n].  With ca = scale (eval-mode BN or plain
+ * affine; NULL = 1) and cb = cc = mean = NULL this is the backward of swr_affine_act_fwd w.r.t. Z. */
+int swr_act_bwd_apply(const float* dY, int64_t lddy, const float* Y, int64_t ldy,
+                      const float* Z, int64_t ldz, const float* ca, const float* cb, const float* cc,
+                      const float* mean, const swr_act_range* acts_host, int n_acts,
+                      float* dZ, int64_t lddz, int64_t M, int N, void* stream);
+
+/* ------------------------------------------------------- gate mixing ------
+ * expert_pooling = sum_j gate[:, j] * expert_j  (models/multi_domain/mmoe.py:48-49,
+ * ple.py:121-126,131-133).  Y holds the activated experts and gates side by side;
+ * output d mixes the `n_sel` experts listed in sel[d] with the n_sel weights at
+ * Y[:, g_col + d * g_stride + j].
+ *   P[m, d*H + h] = sum_j Y[m, g_col + d*g_stride + j] * Y[m, x_col + sel[d][j]*H + h] */
+#define SWR_MIX_MAX_OUT 16
+#define SWR_MIX_MAX_SEL 16
+typedef struct {
+    int32_t n_out, n_sel, H;
+    int32_t x_col, g_col, g_stride;
+    uint8_t sel[SWR_MIX_MAX_OUT][SWR_MIX_MAX_SEL];
+} swr_mix_desc;
+
+int swr_moe_mix_fwd(const swr_mix_desc* desc_host, const float* Y, int64_t ldy,
+                    float* P, int64_t ldp, int64_t M, void* stream);
+/* writes (accumulate = 0) or adds to (accumulate != 0) dY[:, expert and gate columns]; experts that no
+ * output selects get a zero gradient */
+int swr_moe_mix_bwd(const swr_mix_desc* desc_host, const float* dP, int64_t lddp,
+                    const float* Y, int64_t ldy, float* dY, int64_t lddy, int accumulate,
+                    int64_t M, void* stream);
+
+/* ---------------------------------------------- domain select + loss ------
+ * final = 0; for d: final = where(domain_id == d, y_d, final)
+ * (mmoe.py:53-55, base_example.py:72-74): integer equality on the raw id, ids
+ * outside [0, D) give exactly 0.0.  `apply_sigmoid`: y_d = sigmoid(V[:, d])
+ * (towers, mmoe.py:51) or V[:, d] as is.  `extra` (nullable, [M]):
+ * out = sigmoid(select(V) + extra), STAR's `sig(final + aux_out)` (star.py:117). */
+int swr_select_fwd(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype,
+                   int apply_sigmoid, const float* extra, float* out, int64_t M, void* stream);
+int swr_select_bwd(const float* dout, const float* out, int D, const void* domain, int dom_dtype,
+                   int apply_sigmoid, int has_extra, float* dV, int64_t lddv, float* dextra,
+                   int64_t M, void* stream);
+
+/* torch.nn.BCELoss(reduction='mean') on probabilities (trainers/ctr_trainer.py:56,70):
+ * logs clamped at -100; backward (p - y) / max(p (1 - p), 1e-12) / M * dloss. */
+size_t swr_bce_workspace_bytes(int64_t M);
+int swr_bce_fwd(const float* p, const void* y, int y_dtype, int64_t M, float* loss,
+                void* workspace, size_t workspace_bytes, void* stream);
+int swr_bce_bwd(const float* p, const void* y, int y_dtype, int64_t M, const float* dloss,
+                float* dp, void* stream);
+
+/* -------------------------------------------------------- elementwise -----
+ * small helpers of STAR / PPNet / HAMUR middles */
+/* C = A * B (elementwise, same shape) */
+int swr_mul_fwd(const float* A, const float* B, float* C, int64_t n, void* stream);
+/* column sums: out[n] (+)= sum_m X[m, n]  (bias gradients of layers without BatchNorm) */
+size_t swr_colsum_workspace_bytes(int64_t M, int N);
+int swr_colsum(const float* X, int64_t ldx, int64_t M, int N, float* out, int accumulate,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------- Adam -------
+ * torch.optim.Adam(lr, betas, eps, weight_decay) of the reference trainer
+ * (trainers/ctr_trainer.py:50-52,73): L2 decay added to the gradient, bias
+ * corrections from the step count.  The step count, learning rate and the
+ * derived scalars live in device memory (`swr_adam_hyper`) so that a captured
+ * hipGraph replays correctly: swr_adam_advance bumps the step and recomputes
+ * them in fp64 on the device. */
+typedef struct {
+    double lr, beta1, beta2, eps, weight_decay;
+    int64_t step;
+    float step_size;        /* lr / (1 - beta1^step) */
+    float inv_bc2_sqrt;     /* 1 / sqrt(1 - beta2^step) */
+    float one_minus_b1, b2, one_minus_b2, eps_f, wd_f, pad;
+} swr_adam_hyper;
+
+int swr_adam_advance(swr_adam_hyper* hyper_dev, void* stream);
+/* dense update of a flat fp32 arena */
+int swr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n,
+                   const swr_adam_hyper* hyper_dev, void* stream);
+/* large tables with row-sparse gradients (mode 1 of swr_embed_bwd): touched rows take the summed
+ * gradient, every other row takes g = weight_decay * p -- together exactly the dense update the
+ * reference performs.  `bitmap` ([ceil(vocab/32)] words, zero on entry, zero on
+ * exit) marks touched rows between the two launches. */
+int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int dim,
+                  const int32_t* urow, const float* ugrad, int64_t n_entries,
+                  uint32_t* bitmap, const swr_adam_hyper* hyper_dev, void* stream);
+int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vocab, int dim,
+                             uint32_t* bitmap, const swr_adam_hyper* hyper_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWR_H_ */

@@ -1,0 +1,78 @@
+// Shared helpers for the libswr HIP sources (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "swr.h"
+
+#define SWR_WAVE 64
+
+#define SWR_REQUIRE(cond, code) \
+    do {                        \
+        if (!(cond)) return (code); \
+    } while (0)
+
+static inline int swr_launch_status() {
+    return hipGetLastError() == hipSuccess ? SWR_OK : SWR_ERR_LAUNCH;
+}
+
+static inline bool swr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static inline int64_t swr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- typed loads of caller columns: `.long()` / `.float()` of the reference (layers.py:70,89)
+__device__ __forceinline__ int64_t swr_load_index(const void* p, int dtype, int64_t i) {
+    switch (dtype) {
+        case SWR_I8: return static_cast<const int8_t*>(p)[i];
+        case SWR_U8: return static_cast<const uint8_t*>(p)[i];
+        case SWR_BOOL: return static_cast<const uint8_t*>(p)[i] != 0;
+        case SWR_I16: return static_cast<const int16_t*>(p)[i];
+        case SWR_I32: return static_cast<const int32_t*>(p)[i];
+        default: return static_cast<const int64_t*>(p)[i];
+    }
+}
+
+__device__ __forceinline__ float swr_bf16_to_float(uint16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
+
+__device__ __forceinline__ float swr_load_value(const void* p, int dtype, int64_t i) {
+    switch (dtype) {
+        case SWR_F32: return static_cast<const float*>(p)[i];
+        case SWR_F16: return __half2float(static_cast<const __half*>(p)[i]);
+        case SWR_BF16: return swr_bf16_to_float(static_cast<const uint16_t*>(p)[i]);
+        case SWR_F64: return static_cast<float>(static_cast<const double*>(p)[i]);
+        case SWR_I8: return static_cast<float>(static_cast<const int8_t*>(p)[i]);
+        case SWR_U8: return static_cast<float>(static_cast<const uint8_t*>(p)[i]);
+        case SWR_BOOL: return static_cast<const uint8_t*>(p)[i] != 0 ? 1.f : 0.f;
+        case SWR_I16: return static_cast<float>(static_cast<const int16_t*>(p)[i]);
+        case SWR_I32: return static_cast<float>(static_cast<const int32_t*>(p)[i]);
+        default: return static_cast<float>(static_cast<const int64_t*>(p)[i]);
+    }
+}
+
+static inline bool swr_is_index_dtype(int d) {
+    return d == SWR_I8 || d == SWR_I16 || d == SWR_I32 || d == SWR_I64 || d == SWR_U8 || d == SWR_BOOL;
+}
+static inline bool swr_is_value_dtype(int d) { return d >= SWR_I8 && d <= SWR_BOOL; }
+
+// Chan's parallel merge of (count, mean, M2) in fp64
+struct SwrMoments {
+    double n, mean, m2;
+};
+__device__ __forceinline__ SwrMoments swr_merge(SwrMoments a, SwrMoments b) {
+    if (b.n == 0) return a;
+    if (a.n == 0) return b;
+    SwrMoments r;
+    r.n = a.n + b.n;
+    const double d = b.mean - a.mean;
+    r.mean = a.mean + d * (b.n / r.n);
+    r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+    return r;
+}
+
+__device__ __forceinline__ float swr_sigmoid(float x) {
+    // two-sided form: no overflow, monotone, matches torch.sigmoid to 1 ulp
+    const float e = __expf(-fabsf(x));
+    const float r = 1.f / (1.f + e);
+    return x >= 0.f ? r : e * r;
+}

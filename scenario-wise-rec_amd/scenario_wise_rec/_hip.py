@@ -1,0 +1,204 @@
+"""ctypes binding of libswr.so (include/swr.h) -- the only door to the device code.
+
+There is NO CPU fallback: importing this module without the built library, or
+launching with tensors that are not on a HIP device, raises.  PyTorch is used
+for device memory and streams only (`tensor.data_ptr()`,
+`torch.cuda.current_stream().cuda_stream`).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libswr.so")
+
+
+class SwrError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"libswr.so not found at {_LIB_PATH}: build it with "
+            "`python scenario-wise-rec_amd/build_native.py` (hipcc, gfx950). "
+            "scenario_wise_rec has no CPU fallback.")
+    return C.CDLL(_LIB_PATH)
+
+
+lib = _load()
+
+# ----------------------------------------------------------------------------- enums
+I8, I16, I32, I64, U8, F16, BF16, F32, F64, BOOL = range(1, 11)
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX = 0, 1, 2, 3
+FLAG_INDEX_OOR, FLAG_GRAD_RANGE = 1, 2
+
+_DTYPES = {
+    torch.int8: I8, torch.int16: I16, torch.int32: I32, torch.int64: I64, torch.uint8: U8,
+    torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32, torch.float64: F64, torch.bool: BOOL,
+}
+_ACTS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "softmax": ACT_SOFTMAX}
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise SwrError(f"unsupported column dtype {t.dtype}")
+
+
+# --------------------------------------------------------------------------- structs
+class SparseSlot(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("idx", C.c_void_p), ("vocab", C.c_int64), ("dim", C.c_int32),
+                ("idx_dtype", C.c_int32), ("out_col", C.c_int32), ("hash_seed", C.c_uint32)]
+
+
+class DenseSlot(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("dtype", C.c_int32), ("out_col", C.c_int32)]
+
+
+class EmbedGradSlot(C.Structure):
+    _fields_ = [("vocab", C.c_int64), ("dim", C.c_int32), ("in_col", C.c_int32), ("table_id", C.c_int32),
+                ("mode", C.c_int32), ("grad_dense", C.c_void_p), ("urow", C.c_void_p), ("ugrad", C.c_void_p)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
+                ("bias", C.c_void_p), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int32),
+                ("accumulate", C.c_int32), ("stat_partials", C.c_void_p), ("groups", C.c_int32),
+                ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsBias", C.c_int64),
+                ("gsScale", C.c_int64)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [("M", C.c_int64), ("K1", C.c_int32), ("K2", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("colsum", C.c_void_p),
+                ("accumulate", C.c_int32), ("groups", C.c_int32),
+                ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsColsum", C.c_int64)]
+
+
+class ActRange(C.Structure):
+    _fields_ = [("col_lo", C.c_int32), ("col_hi", C.c_int32), ("act", C.c_int32), ("group", C.c_int32)]
+
+
+MIX_MAX_OUT, MIX_MAX_SEL = 16, 16
+
+
+class MixDesc(C.Structure):
+    _fields_ = [("n_out", C.c_int32), ("n_sel", C.c_int32), ("H", C.c_int32), ("x_col", C.c_int32),
+                ("g_col", C.c_int32), ("g_stride", C.c_int32), ("sel", (C.c_uint8 * MIX_MAX_SEL) * MIX_MAX_OUT)]
+
+
+class AdamHyper(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("step", C.c_int64), ("step_size", C.c_float),
+                ("inv_bc2_sqrt", C.c_float), ("one_minus_b1", C.c_float), ("b2", C.c_float),
+                ("one_minus_b2", C.c_float), ("eps_f", C.c_float), ("wd_f", C.c_float), ("pad", C.c_float)]
+
+
+# ------------------------------------------------------------------------ signatures
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_SIGS = {
+    "swr_abi_version": (C.c_int, []),
+    "swr_status_str": (C.c_char_p, [_I]),
+    "swr_device_available": (C.c_int, []),
+    "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
+    "swr_embed_bwd_workspace_bytes": (_Z, [_P, _I, _L]),
+    "swr_embed_bwd": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
+    "swr_gemm_nt": (C.c_int, [_P, _P]),
+    "swr_gemm_nn": (C.c_int, [_P, _P]),
+    "swr_gemm_tn_workspace_bytes": (_Z, [_P]),
+    "swr_gemm_tn": (C.c_int, [_P, _P, _Z, _P]),
+    "swr_bn_finalize": (C.c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "swr_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "swr_affine_act_fwd": (C.c_int, [_P, _L, _P, _P, _P, _I, _P, _L, _L, _I, _P]),
+    "swr_bn_act_bwd_stats": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _P]),
+    "swr_bn_bwd_finalize": (C.c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "swr_act_bwd_apply": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P]),
+    "swr_moe_mix_fwd": (C.c_int, [_P, _P, _L, _P, _L, _L, _P]),
+    "swr_moe_mix_bwd": (C.c_int, [_P, _P, _L, _P, _L, _P, _L, _I, _L, _P]),
+    "swr_select_fwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P, _L, _P]),
+    "swr_select_bwd": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _L, _P, _L, _P]),
+    "swr_bce_workspace_bytes": (_Z, [_L]),
+    "swr_bce_fwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _Z, _P]),
+    "swr_bce_bwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _P]),
+    "swr_mul_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
+    "swr_colsum_workspace_bytes": (_Z, [_L, _I]),
+    "swr_colsum": (C.c_int, [_P, _L, _L, _I, _P, _I, _P, _Z, _P]),
+    "swr_adam_advance": (C.c_int, [_P, _P]),
+    "swr_adam_dense": (C.c_int, [_P, _P, _P, _P, _L, _P, _P]),
+    "swr_adam_rows": (C.c_int, [_P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P]),
+    "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _P, _P]),
+}
+EXPORTS = tuple(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here = the library does not match include/swr.h
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SwrError(f"{what}: {lib.swr_status_str(rc).decode()} ({rc})")
+
+
+# --------------------------------------------------------------------------- helpers
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SwrError("scenario_wise_rec (MI355X build) runs on HIP device tensors only; got a "
+                           f"{t.device} tensor. There is no CPU fallback.")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def f32c(t):
+    """fp32, unit stride in the last dim (rows may be strided)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        t = t.contiguous()
+    if t.dim() == 2 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+_err_flags = {}
+
+
+def err_flag(device):
+    """Per-device sticky error word written by the kernels (index out of range, gradient range)."""
+    key = torch.device(device).index or 0
+    if key not in _err_flags:
+        _err_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _err_flags[key]
+
+
+def check_errors(device=None):
+    """Synchronising check of the device error word; raises like the reference would."""
+    for key, flag in list(_err_flags.items()):
+        v = int(flag.item())
+        if v:
+            flag.zero_()
+            if v & FLAG_INDEX_OOR:
+                raise IndexError("index out of range in self")     # torch's nn.Embedding message
+            if v & FLAG_GRAD_RANGE:
+                raise SwrError("embedding gradient outside the fixed-point accumulator range (|g| >= 2^20)")
+
+
+def act_ranges(acts, n_cols):
+    """acts: None | str | list of (lo, hi, act, group)."""
+    if acts is None or isinstance(acts, str):
+        acts = [(0, n_cols, acts, 1)]
+    arr = (ActRange * len(acts))()
+    for i, (lo, hi, a, g) in enumerate(acts):
+        arr[i] = ActRange(lo, hi, _ACTS[a.lower() if isinstance(a, str) else a], g)
+    return arr, len(acts)

@@ -1,0 +1,535 @@
+"""Device ops of the hot path: thin launchers over the C ABI (include/swr.h) and the
+`torch.autograd.Function`s the model mirror composes.
+
+Every function here launches hand-written HIP kernels on the current HIP stream; torch supplies
+device memory and the autograd tape only.  All matrices are fp32 row-major 2-D tensors whose rows may
+be strided (`ld = stride(0)`), so column slices of a wider buffer are passed without copies.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip as H
+from ._hip import lib
+
+
+# =========================================================================== raw launchers
+def _ld(t):
+    return t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else (t.shape[-1] if t.dim() == 2 else 0)
+
+
+def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_relu=False, accumulate=False,
+         stat_partials=None, groups=1, gsA=0, gsB=0, gsC=0, gsBias=0, gsScale=0, lda=None, ldb=None, ldc=None):
+    """kind 'nt': C[m,n] = sum_k A[m,k] B[n,k];  'nn': C[m,n] = sum_k A[m,k] B[k,n]."""
+    a = H.GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda = A.data_ptr(), lda if lda is not None else _ld(A)
+    a.B, a.ldb = B.data_ptr(), ldb if ldb is not None else _ld(B)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C, a.ldc = C_out.data_ptr(), ldc if ldc is not None else _ld(C_out)
+    a.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    a.a_shift = a_shift.data_ptr() if a_shift is not None else None
+    a.a_relu = int(a_relu)
+    a.accumulate = int(accumulate)
+    a.stat_partials = stat_partials.data_ptr() if stat_partials is not None else None
+    a.groups, a.gsA, a.gsB, a.gsC, a.gsBias, a.gsScale = groups, gsA, gsB, gsC, gsBias, gsScale
+    fn = lib.swr_gemm_nt if kind == "nt" else lib.swr_gemm_nn
+    H.check(fn(C.byref(a), H.stream()), f"swr_gemm_{kind}")
+
+
+def gemm_tn(A, B, C_out, M, K1, K2, colsum=None, accumulate=False, groups=1, gsA=0, gsB=0, gsC=0, gsColsum=0,
+            lda=None, ldb=None, ldc=None):
+    """C[k1,k2] = sum_m A[m,k1] B[m,k2] (+ colsum[k1] = sum_m A[m,k1]); deterministic split over m."""
+    a = H.GemmTnArgs()
+    a.M, a.K1, a.K2 = M, K1, K2
+    a.A, a.lda = A.data_ptr(), lda if lda is not None else _ld(A)
+    a.B, a.ldb = B.data_ptr(), ldb if ldb is not None else _ld(B)
+    a.C, a.ldc = C_out.data_ptr(), ldc if ldc is not None else _ld(C_out)
+    a.colsum = colsum.data_ptr() if colsum is not None else None
+    a.accumulate, a.groups = int(accumulate), groups
+    a.gsA, a.gsB, a.gsC, a.gsColsum = gsA, gsB, gsC, gsColsum
+    nbytes = lib.swr_gemm_tn_workspace_bytes(C.byref(a))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=A.device)
+    H.check(lib.swr_gemm_tn(C.byref(a), H.ptr(ws), nbytes, H.stream()), "swr_gemm_tn")
+
+
+def colsum(X, M, N, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    nbytes = lib.swr_colsum_workspace_bytes(M, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    H.check(lib.swr_colsum(H.ptr(X), _ld(X), M, N, H.ptr(out), int(accumulate), H.ptr(ws), nbytes, H.stream()), "swr_colsum")
+    return out
+
+
+def _cat_params(tensors):
+    """One tensor aliasing `tensors` back to back.  Models lay the parameters of fused layers out
+    adjacently in the parameter arena (basic/module.py), in which case this is a zero-copy view of the
+    arena; otherwise it is a concatenation copy."""
+    t0 = tensors[0].detach()
+    if len(tensors) == 1:
+        return t0
+    tail = tuple(t0.shape[1:])
+    adjacent = True
+    p, store = t0.data_ptr(), t0.untyped_storage().data_ptr()
+    for t in tensors:
+        if (not t.is_contiguous() or t.data_ptr() != p or t.dtype != t0.dtype or tuple(t.shape[1:]) != tail
+                or t.untyped_storage().data_ptr() != store):
+            adjacent = False
+            break
+        p += t.numel() * t.element_size()
+    rows = sum(t.shape[0] if t.dim() > 0 else 1 for t in tensors)
+    shape = (rows,) + tail
+    if adjacent:
+        strides, acc = [], 1
+        for n in reversed(shape):
+            strides.append(acc)
+            acc *= n
+        return t0.as_strided(shape, tuple(reversed(strides)))
+    return torch.cat([t.detach().reshape((-1,) + tail) for t in tensors])
+
+
+def _split_like(flat, tensors):
+    """Slices of `flat` (first-dim concatenation) shaped like each of `tensors`."""
+    out, off = [], 0
+    for t in tensors:
+        n = t.shape[0] if t.dim() > 0 else 1
+        out.append(flat[off:off + n].reshape(t.shape))
+        off += n
+    return out
+
+
+# =========================================================================== embedding gather
+class _GatherPlan:
+    """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes")
+
+
+class EmbedGather(Function):
+    """K1 forward / K3 backward (basic/layers.py:64-105)."""
+
+    @staticmethod
+    def forward(ctx, plan, *weights):
+        # plan.sparse: list of (weight_pos, idx tensor, vocab, dim, out_col, hash_seed); plan.dense: (values, out_col)
+        dev = weights[0].device if weights else plan.dense[0][0].device
+        B = (plan.sparse[0][1] if plan.sparse else plan.dense[0][0]).shape[0]
+        # slots whose table takes a gradient first: the backward reduces exactly that prefix
+        plan.sparse = sorted(plan.sparse, key=lambda s: not weights[s[0]].requires_grad)
+        ctx.n_grad_slots = sum(1 for s in plan.sparse if weights[s[0]].requires_grad)
+        out = torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
+        ns, nd = len(plan.sparse), len(plan.dense)
+        sp = (H.SparseSlot * max(ns, 1))()
+        for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse):
+            H.require_device(idx, weights[wpos])
+            sp[i] = H.SparseSlot(weights[wpos].data_ptr(), idx.data_ptr(), vocab, dim, H.dtype_code(idx), col, seed)
+        dn = (H.DenseSlot * max(nd, 1))()
+        for i, (vals, col) in enumerate(plan.dense):
+            H.require_device(vals)
+            dn[i] = H.DenseSlot(vals.data_ptr(), H.dtype_code(vals), col)
+        need_keys = ctx.n_grad_slots > 0
+        keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
+        flag = H.err_flag(dev)
+        H.check(lib.swr_embed_gather_fwd(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), H.ptr(flag), H.stream()),
+                "swr_embed_gather_fwd")
+        ctx.plan, ctx.keys, ctx.B = plan, keys, B
+        ctx.weights = weights            # identity / shapes only
+        return out[:, :plan.width] if plan.width != plan.ld else out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dE):
+        plan, B, weights = ctx.plan, ctx.B, ctx.weights
+        if ctx.keys is None or B == 0 or ctx.n_grad_slots == 0:
+            return (None,) + tuple(None if not w.requires_grad else torch.zeros_like(w) for w in weights)
+        dE = H.f32c(dE)
+        dev = dE.device
+        # tables: dense gradient when small, row-sparse entries when large; sparse tables take the largest ids
+        live = plan.sparse[:ctx.n_grad_slots]
+        uses = {}
+        for s, (wpos, *_rest) in enumerate(live):
+            uses.setdefault(wpos, []).append(s)
+        order = sorted(uses, key=lambda w: (weights[w].numel() * 4 > plan.dense_limit_bytes, w))
+        table_id = {w: i for i, w in enumerate(order)}
+        grads = [None] * len(weights)
+        sparse_out = {}
+        slots = (H.EmbedGradSlot * len(live))()
+        for s, (wpos, idx, vocab, dim, col, seed) in enumerate(live):
+            w = weights[wpos]
+            sparse_mode = w.numel() * 4 > plan.dense_limit_bytes
+            if sparse_mode:
+                if wpos not in sparse_out:
+                    cnt = len(uses[wpos]) * B
+                    sparse_out[wpos] = (torch.empty(cnt, dtype=torch.int32, device=dev),
+                                        torch.empty((cnt, dim), dtype=torch.float32, device=dev))
+                urow, ugrad = sparse_out[wpos]
+                slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 1, None, urow.data_ptr(), ugrad.data_ptr())
+            else:
+                if grads[wpos] is None:
+                    grads[wpos] = torch.empty_like(w, memory_format=torch.contiguous_format)
+                slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 0, grads[wpos].data_ptr(), None, None)
+        ns = len(live)
+        nbytes = lib.swr_embed_bwd_workspace_bytes(slots, ns, B)
+        if nbytes == 0:
+            raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 48 slots or key width above 32 bits)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        H.check(lib.swr_embed_bwd(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
+                                  H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd")
+        for wpos, (urow, ugrad) in sparse_out.items():
+            # row-sparse gradient of a large table: consumed by FusedAdam (optim.py); `.grad` stays None
+            weights[wpos]._swr_sparse_grad = (urow, ugrad)
+        return (None,) + tuple(grads)
+
+
+# =========================================================================== Linear (+BN) (+act)
+class LinearBNAct(Function):
+    """[Linear -> BatchNorm1d -> activation] of an MLP block (basic/layers.py:253-258) for one or more
+    independent layers at once:
+
+      groups == 1 : the weights of several layers that read the SAME input are stacked along N
+                    (experts + gates of MMoE: one [K0, 148] product instead of nine);
+      groups  > 1 : layer g reads columns [g*K, (g+1)*K) of x and writes [g*N, (g+1)*N) (per-domain towers).
+
+    Training: batch statistics (biased variance) from the GEMM epilogue, running stats updated in place;
+    eval: running statistics.  `bn = None` gives a plain Linear (+activation).
+    """
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        # params = n_w weights [N_i, K] + n_w biases (or none) + (gammas + betas if bn)
+        nw = cfg["n_w"]
+        Ws, rest = params[:nw], params[nw:]
+        bs = rest[:nw] if cfg["has_bias"] else ()
+        rest = rest[nw:] if cfg["has_bias"] else rest
+        gammas, betas = (rest[:cfg["n_bn"]], rest[cfg["n_bn"]:]) if cfg["bn"] is not None else ((), ())
+        H.require_device(x, Ws[0])
+        x = H.f32c(x)
+        W = _cat_params(Ws)
+        b = _cat_params(bs) if bs else None
+        G = cfg["groups"]
+        M, K = x.shape[0], W.shape[1]
+        Ntot = W.shape[0]
+        N = Ntot // G
+        dev = x.device
+        Z = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+        training = cfg["training"] and cfg["bn"] is not None
+        n_tiles = (M + 31) // 32
+        partials = torch.empty((n_tiles, Ntot, 2), dtype=torch.float32, device=dev) if training else None
+        gemm("nt", x, W, Z, M, N, K, bias=b, stat_partials=partials, groups=G,
+             gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N)
+        acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
+        mean = rstd = scale = shift = None
+        if cfg["bn"] is not None:
+            bn = cfg["bn"]
+            gamma, beta = _cat_params(gammas), _cat_params(betas)
+            scale = torch.empty(Ntot, dtype=torch.float32, device=dev)
+            shift = torch.empty(Ntot, dtype=torch.float32, device=dev)
+            if training:
+                if M < 2:
+                    raise ValueError("Expected more than 1 value per channel when training")   # torch's message
+                mean = torch.empty(Ntot, dtype=torch.float32, device=dev)
+                rstd = torch.empty(Ntot, dtype=torch.float32, device=dev)
+                rm, rv, nbt = _cat_params(bn["running_mean"]), _cat_params(bn["running_var"]), _cat_params(bn["nbt"])
+                copy_back = rm.data_ptr() != bn["running_mean"][0].data_ptr()
+                H.check(lib.swr_bn_finalize(H.ptr(partials), n_tiles, M, Ntot, H.ptr(gamma), H.ptr(beta), bn["eps"],
+                                            bn["momentum"], H.ptr(rm), H.ptr(rv), H.ptr(nbt), nbt.numel(), H.ptr(mean),
+                                            H.ptr(rstd), H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_finalize")
+                if copy_back:      # buffers were not adjacent: scatter the updated copies back
+                    for dst, src in zip(bn["running_mean"], _split_like(rm, bn["running_mean"])):
+                        dst.copy_(src)
+                    for dst, src in zip(bn["running_var"], _split_like(rv, bn["running_var"])):
+                        dst.copy_(src)
+                    for dst, src in zip(bn["nbt"], _split_like(nbt, bn["nbt"])):
+                        dst.copy_(src)
+            else:
+                rm, rv = _cat_params(bn["running_mean"]), _cat_params(bn["running_var"])
+                H.check(lib.swr_bn_eval_coeffs(H.ptr(gamma), H.ptr(beta), H.ptr(rm), H.ptr(rv), bn["eps"], Ntot,
+                                               H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_eval_coeffs")
+        identity = cfg["bn"] is None and all(a[2] in (None, "none") for a in _norm_acts(cfg["acts"], Ntot))
+        if identity:
+            Y = Z
+        else:
+            Y = torch.empty_like(Z)
+            H.check(lib.swr_affine_act_fwd(H.ptr(Z), Ntot, H.ptr(scale), H.ptr(shift), acts, n_acts, H.ptr(Y), Ntot, M,
+                                           Ntot, H.stream()), "swr_affine_act_fwd")
+        ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
+        ctx.params = params
+        ctx.training_bn = training
+        ctx.save_for_backward(x, W, Z, Y, mean, rstd, scale, _cat_params(gammas) if gammas else None)
+        return Y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dY):
+        cfg = ctx.cfg
+        M, N, K, G, Ntot = ctx.dims
+        x, W, Z, Y, mean, rstd, scale, gamma = ctx.saved_tensors
+        dev = x.device
+        dY = H.f32c(dY)
+        acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
+        dgamma = dbeta = None
+        dZ = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+        if ctx.training_bn:
+            nt = (M + 63) // 64
+            partials = torch.empty((nt, Ntot, 2), dtype=torch.float32, device=dev)
+            H.check(lib.swr_bn_act_bwd_stats(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(mean),
+                                             H.ptr(rstd), acts, n_acts, H.ptr(partials), M, Ntot, H.stream()),
+                    "swr_bn_act_bwd_stats")
+            dgamma = torch.empty(Ntot, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(Ntot, dtype=torch.float32, device=dev)
+            ca, cb, cc = (torch.empty(Ntot, dtype=torch.float32, device=dev) for _ in range(3))
+            H.check(lib.swr_bn_bwd_finalize(H.ptr(partials), nt, M, Ntot, H.ptr(gamma), H.ptr(rstd), H.ptr(dgamma),
+                                            H.ptr(dbeta), 0, H.ptr(ca), H.ptr(cb), H.ptr(cc), H.stream()),
+                    "swr_bn_bwd_finalize")
+            H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(ca), H.ptr(cb),
+                                          H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
+                    "swr_act_bwd_apply")
+        else:
+            # eval-mode BN (a fixed affine) or no BN: dZ = scale * act'(Y) dY
+            identity = scale is None and all(a[2] in (None, "none") for a in _norm_acts(cfg["acts"], Ntot))
+            if identity:
+                dZ = dY if (M <= 1 or dY.stride(0) == Ntot) else dY.contiguous()
+            else:
+                H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(scale), None,
+                                              None, None, acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
+                        "swr_act_bwd_apply")
+        # parameter gradients: dW[g] = dZ_g^T x_g (+ db = column sums), dX = dZ W
+        dW = torch.empty((Ntot, K), dtype=torch.float32, device=dev)
+        db = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
+        gemm_tn(dZ, x, dW, M, N, K, colsum=db, groups=G, gsA=N, gsB=(K if G > 1 else 0), gsC=N * K, gsColsum=N)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            if G > 1:
+                dx = torch.empty((M, G * K), dtype=torch.float32, device=dev)
+                gemm("nn", dZ, W, dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
+            else:
+                dx = torch.empty((M, _pad4(K)), dtype=torch.float32, device=dev)
+                gemm("nn", dZ, W, dx, M, K, Ntot)
+                if dx.shape[1] != K:
+                    dx = dx[:, :K]
+        nw = cfg["n_w"]
+        grads = list(_split_like(dW, ctx.params[:nw]))
+        if cfg["has_bias"]:
+            grads += _split_like(db, ctx.params[nw:2 * nw])
+        if cfg["bn"] is not None:
+            off = nw * (2 if cfg["has_bias"] else 1)
+            gam = ctx.params[off:off + cfg["n_bn"]]
+            if dgamma is not None:
+                grads += _split_like(dgamma, gam) + _split_like(dbeta, gam)
+            else:
+                grads += [None] * (2 * cfg["n_bn"])
+        return (None, dx) + tuple(grads)
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _norm_acts(acts, n):
+    if acts is None or isinstance(acts, str):
+        return [(0, n, acts, 1)]
+    return acts
+
+
+def linear_bn_act(x, weights, biases, bn=None, acts=None, groups=1, training=True):
+    """Functional front-end of LinearBNAct.
+
+    weights / biases: lists of Parameters stacked along the output dim (biases may be None);
+    bn: None or dict(gamma=[...], beta=[...], running_mean=[...], running_var=[...], nbt=[...], eps, momentum)."""
+    cfg = {"n_w": len(weights), "has_bias": biases is not None, "groups": groups, "acts": acts,
+           "training": training, "bn": None, "n_bn": 0}
+    params = list(weights) + (list(biases) if biases is not None else [])
+    if bn is not None:
+        cfg["bn"] = {k: bn[k] for k in ("running_mean", "running_var", "nbt", "eps", "momentum")}
+        cfg["n_bn"] = len(bn["gamma"])
+        params += list(bn["gamma"]) + list(bn["beta"])
+    return LinearBNAct.apply(cfg, x, *params)
+
+
+class MatmulIO(Function):
+    """y = x @ W + b with W stored [in, out] -- STAR's factorised FCN layer (star.py:103-107)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        H.require_device(x, W)
+        x, W = H.f32c(x), H.f32c(W)
+        M, K, N = x.shape[0], W.shape[0], W.shape[1]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm("nn", x, W, y, M, N, K, bias=b)
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = H.f32c(dy)
+        M, K, N = x.shape[0], W.shape[0], W.shape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+            gemm("nt", dy, W, dx, M, K, N)                    # dx[m,k] = sum_n dy[m,n] W[k,n]
+        dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        gemm_tn(x, dy, dW, M, K, N)                           # dW[k,n] = sum_m x[m,k] dy[m,n]
+        if db is not None:
+            colsum(dy, M, N, out=db)
+        return dx, dW, db
+
+
+# =========================================================================== gate mixing
+def make_mix_desc(n_out, n_sel, H_, x_col, g_col, g_stride, sel):
+    d = H.MixDesc()
+    d.n_out, d.n_sel, d.H, d.x_col, d.g_col, d.g_stride = n_out, n_sel, H_, x_col, g_col, g_stride
+    for o in range(n_out):
+        for j in range(n_sel):
+            d.sel[o][j] = sel[o][j]
+    return d
+
+
+class MoeMix(Function):
+    """pooled[:, o*H:(o+1)*H] = sum_j gate_o[:, j] * expert_{sel[o][j]}  (mmoe.py:48-49, ple.py:121-133).
+    `Y` holds the activated experts (from x_col) and gate probabilities (from g_col) side by side."""
+
+    @staticmethod
+    def forward(ctx, Y, desc, width_in):
+        H.require_device(Y)
+        Y = H.f32c(Y)
+        M = Y.shape[0]
+        P = torch.empty((M, desc.n_out * desc.H), dtype=torch.float32, device=Y.device)
+        H.check(lib.swr_moe_mix_fwd(C.byref(desc), H.ptr(Y), Y.stride(0) if M > 1 else Y.shape[1], H.ptr(P),
+                                    P.shape[1], M, H.stream()), "swr_moe_mix_fwd")
+        ctx.desc, ctx.width_in = desc, width_in
+        ctx.save_for_backward(Y)
+        return P
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dP):
+        (Y,) = ctx.saved_tensors
+        dP = H.f32c(dP)
+        M = Y.shape[0]
+        dY = torch.zeros((M, ctx.width_in), dtype=torch.float32, device=Y.device)
+        H.check(lib.swr_moe_mix_bwd(C.byref(ctx.desc), H.ptr(dP), dP.stride(0) if M > 1 else dP.shape[1], H.ptr(Y),
+                                    Y.stride(0) if M > 1 else Y.shape[1], H.ptr(dY), ctx.width_in, 0, M, H.stream()),
+                "swr_moe_mix_bwd")
+        return dY, None, None
+
+
+# =========================================================================== select / loss
+class DomainSelect(Function):
+    """final = 0; for d: final = where(domain == d, y_d, final) (mmoe.py:53-55); y_d = sigmoid(V[:, d]) when
+    `apply_sigmoid`, and out = sigmoid(select + extra) when `extra` is given (star.py:117)."""
+
+    @staticmethod
+    def forward(ctx, V, domain, apply_sigmoid, extra):
+        H.require_device(V, domain)
+        V = H.f32c(V)
+        M, D = V.shape
+        out = torch.empty(M, dtype=torch.float32, device=V.device)
+        ex = H.f32c(extra).reshape(-1) if extra is not None else None
+        domain = domain.contiguous()
+        H.check(lib.swr_select_fwd(H.ptr(V), V.stride(0) if M > 1 else D, D, H.ptr(domain), H.dtype_code(domain),
+                                   int(apply_sigmoid), H.ptr(ex), H.ptr(out), M, H.stream()), "swr_select_fwd")
+        ctx.save_for_backward(out, domain)
+        ctx.meta = (M, D, apply_sigmoid, extra is not None, tuple(extra.shape) if extra is not None else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        out, domain = ctx.saved_tensors
+        M, D, apply_sigmoid, has_extra, eshape = ctx.meta
+        dout = H.f32c(dout).contiguous()
+        dV = torch.empty((M, D), dtype=torch.float32, device=out.device)
+        dextra = torch.empty(M, dtype=torch.float32, device=out.device) if has_extra else None
+        H.check(lib.swr_select_bwd(H.ptr(dout), H.ptr(out), D, H.ptr(domain), H.dtype_code(domain), int(apply_sigmoid),
+                                   int(has_extra), H.ptr(dV), D, H.ptr(dextra), M, H.stream()), "swr_select_bwd")
+        return dV, None, None, (dextra.reshape(eshape) if has_extra else None)
+
+
+class BCEMean(Function):
+    """torch.nn.BCELoss(reduction='mean') on probabilities (ctr_trainer.py:56,70)."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        H.require_device(p, y)
+        p = H.f32c(p).contiguous()
+        y = y.contiguous()
+        M = p.numel()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        nbytes = lib.swr_bce_workspace_bytes(M)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+        H.check(lib.swr_bce_fwd(H.ptr(p), H.ptr(y), H.dtype_code(y), M, H.ptr(loss), H.ptr(ws), nbytes, H.stream()),
+                "swr_bce_fwd")
+        ctx.save_for_backward(p, y)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        p, y = ctx.saved_tensors
+        dloss = dloss.float().contiguous()
+        dp = torch.empty_like(p)
+        H.check(lib.swr_bce_bwd(H.ptr(p), H.ptr(y), H.dtype_code(y), p.numel(), H.ptr(dloss), H.ptr(dp), H.stream()),
+                "swr_bce_bwd")
+        return dp, None
+
+
+def bce_mean(p, y):
+    return BCEMean.apply(p, y)
+
+
+def domain_select(V, domain, apply_sigmoid=True, extra=None):
+    return DomainSelect.apply(V, domain, apply_sigmoid, extra)
+
+
+# =========================================================================== small helpers
+class Mul(Function):
+    """c = a * b (PPNet's `hidden * gate_out`, ppnet.py:27; EPNet's `agn_x * gate_output`, epnet.py:30)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        H.require_device(a, b)
+        a, b = H.f32c(a).contiguous(), H.f32c(b).contiguous()
+        c = torch.empty_like(a)
+        H.check(lib.swr_mul_fwd(H.ptr(a), H.ptr(b), H.ptr(c), a.numel(), H.stream()), "swr_mul_fwd")
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = H.f32c(dc).contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            H.check(lib.swr_mul_fwd(H.ptr(dc), H.ptr(b), H.ptr(da), a.numel(), H.stream()), "swr_mul_fwd")
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            H.check(lib.swr_mul_fwd(H.ptr(dc), H.ptr(a), H.ptr(db), a.numel(), H.stream()), "swr_mul_fwd")
+        return da, db
+
+
+def mul(a, b):
+    return Mul.apply(a, b)
+
+
+class StopGradCols(Function):
+    """Identity whose gradient is zero on columns [lo, hi): `torch.cat((a, b.detach()), dim=1)` of the
+    reference (ppnet.py:54, epnet.py:27) without materialising the concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.span = (lo, hi)
+        return x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = g.clone()
+        g[:, ctx.span[0]:ctx.span[1]] = 0
+        return g, None, None

@@ -1,0 +1,112 @@
+"""FusedAdam: torch.optim.Adam(lr, betas, eps, weight_decay) semantics (the reference trainer's
+optimizer, `trainers/ctr_trainer.py:50-52,73`) as HBM-streaming HIP kernels.
+
+  * parameters that live back to back in a parameter arena (basic/module.py) with their gradients at
+    matching offsets are updated by ONE launch per contiguous run;
+  * large embedding tables with row-sparse gradients (ops.EmbedGather) take a row kernel for the looked-up
+    rows and a sweep for all other rows (g = weight_decay * p) -- together exactly the dense update the
+    reference performs on every row of every table every step;
+  * parameters that took no gradient in the last backward are skipped entirely, like torch
+    (`grad is None`: no decay, no state), e.g. PPNet's agnostic tables;
+  * step count and bias corrections live in device memory (a captured hipGraph replays correctly).
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip as H
+from ._hip import lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._hyper = {}        # group index -> (device uint8 tensor holding swr_adam_hyper, uploaded host copy)
+        self._mv = {}           # storage ptr -> (m_flat, v_flat) shadowing a parameter storage
+        self._big = {}          # id(param) -> (m, v, bitmap)
+
+    # ---- device-side hyper-parameters ---------------------------------------------------------------
+    def _hyper_dev(self, gi, group, device):
+        want = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                float(group["weight_decay"]))
+        ent = self._hyper.get(gi)
+        if ent is None:
+            h = H.AdamHyper(*want, 0)
+            buf = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).to(device)
+            self._hyper[gi] = [buf, want]
+        elif ent[1] != want:
+            # lr (scheduler) or another hyper-parameter changed on the host: refresh the five doubles, keep the step
+            host = torch.tensor(want, dtype=torch.float64).view(torch.uint8)
+            ent[0][:40].copy_(host.to(device))
+            ent[1] = want
+        return self._hyper[gi][0]
+
+    def _state_for(self, p):
+        """(m, v) views shadowing p inside per-storage flat state buffers (so adjacency carries over)."""
+        st = p.untyped_storage()
+        key = st.data_ptr()
+        if key not in self._mv:
+            n = st.nbytes() // 4
+            self._mv[key] = (torch.zeros(n, dtype=torch.float32, device=p.device),
+                             torch.zeros(n, dtype=torch.float32, device=p.device))
+        off = (p.data_ptr() - key) // 4
+        m, v = self._mv[key]
+        return m[off:off + p.numel()], v[off:off + p.numel()], key
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        stream = H.stream()
+        for gi, group in enumerate(self.param_groups):
+            dense, sparse = [], []
+            for p in group["params"]:
+                sg = getattr(p, "_swr_sparse_grad", None)
+                if sg is not None:
+                    sparse.append((p, sg))
+                elif p.grad is not None and getattr(p, "_swr_touched", True):
+                    dense.append(p)
+            if not dense and not sparse:
+                continue
+            dev = (dense[0] if dense else sparse[0][0]).device
+            H.require_device(*(dense[:1] + [s[0] for s in sparse[:1]]))
+            hyper = self._hyper_dev(gi, group, dev)
+            H.check(lib.swr_adam_advance(H.ptr(hyper), stream), "swr_adam_advance")
+            # contiguous runs: parameter, gradient and state addresses all advance together
+            items = []
+            for p in dense:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise H.SwrError("FusedAdam needs contiguous fp32 parameters")
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                m, v, key = self._state_for(p)
+                items.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), key, g))
+            items.sort(key=lambda t: t[0])
+            runs = []
+            for it in items:
+                if runs:
+                    r = runs[-1]
+                    gap = it[0] - (r[0] + 4 * r[4])
+                    # merge across alignment padding (zeros with zero gradient: the update is a no-op there)
+                    if (0 <= gap <= 64 and it[5] == r[5] and it[1] - r[1] == it[0] - r[0] and it[2] - r[2] == it[0] - r[0]):
+                        r[4] = (it[0] - r[0]) // 4 + it[4]
+                        r[6].append(it[6])
+                        continue
+                runs.append([it[0], it[1], it[2], it[3], it[4], it[5], [it[6]]])
+            for p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep in runs:
+                H.check(lib.swr_adam_dense(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
+                                           n, H.ptr(hyper), stream), "swr_adam_dense")
+            for p, (urow, ugrad) in sparse:
+                if id(p) not in self._big:
+                    self._big[id(p)] = (torch.zeros_like(p), torch.zeros_like(p),
+                                        torch.zeros((p.shape[0] + 31) // 32, dtype=torch.int32, device=p.device))
+                m, v, bitmap = self._big[id(p)]
+                H.check(lib.swr_adam_rows(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(urow), H.ptr(ugrad),
+                                          urow.numel(), H.ptr(bitmap), H.ptr(hyper), stream), "swr_adam_rows")
+                H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap),
+                                                     H.ptr(hyper), stream), "swr_adam_sweep_untouched")
+        return loss

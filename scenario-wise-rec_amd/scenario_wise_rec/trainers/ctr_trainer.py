@@ -1,0 +1,139 @@
+"""CTRTrainer (reference: `trainers/ctr_trainer.py:10-165`): same constructor, `fit`,
+`train_one_epoch`, `evaluate`, `evaluate_multi_domain_loss`, `predict`.
+
+The training step is the reference's (to(device) -> forward -> BCE -> zero_grad -> backward ->
+optimizer step, `ctr_trainer.py:62-77`) on the HIP path: fused model forward/backward (ops.py), fused BCE,
+FusedAdam.  `torch.optim.Adam` (the reference default) is mapped to FusedAdam, which implements the same
+update; any other `optimizer_fn` is used as given.  The per-step `loss.item()` host sync of the reference
+(`:74`) is kept only at `log_interval` boundaries.
+"""
+import os
+import time
+
+import torch
+import tqdm
+from sklearn.metrics import log_loss, roc_auc_score
+
+from .. import _hip as H
+from .. import ops
+from ..basic.callback import EarlyStopper
+from ..optim import FusedAdam
+
+
+class BCELoss(torch.nn.Module):
+    """torch.nn.BCELoss(reduction='mean') on the fused HIP kernels."""
+
+    def forward(self, y_pred, y):
+        return ops.bce_mean(y_pred, y)
+
+
+class CTRTrainer(object):
+    def __init__(self, model, data_set_type, optimizer_fn=torch.optim.Adam, optimizer_params=None, scheduler_fn=None,
+                 scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None, model_path="./"):
+        self.model = model
+        self.data_set_type = data_set_type
+        if gpus is None:
+            gpus = []
+        self.gpus = gpus
+        if len(gpus) > 1:
+            # the reference wraps the model in single-process nn.DataParallel here (`ctr_trainer.py:45-47`);
+            # the MI355X build is one process per GPU over RCCL instead: see scenario_wise_rec.parallel
+            raise NotImplementedError("multi-GPU runs use one process per GPU: scenario_wise_rec.parallel.DataParallelStep")
+        self.device = torch.device(device)
+        self.model.to(self.device)
+        if optimizer_params is None:
+            optimizer_params = {"lr": 1e-3, "weight_decay": 1e-5}
+        if optimizer_fn is torch.optim.Adam and not optimizer_params.get("amsgrad", False):
+            optimizer_fn = FusedAdam
+        self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
+        self.scheduler = None
+        if scheduler_fn is not None:
+            self.scheduler = scheduler_fn(self.optimizer, **scheduler_params)
+        self.criterion = BCELoss()
+        self.evaluate_fn = roc_auc_score
+        self.n_epoch = n_epoch
+        self.early_stopper = EarlyStopper(patience=earlystop_patience)
+        self.model_path = model_path
+
+    # ---- one optimisation step (`ctr_trainer.py:67-73`) ---------------------------------------------
+    def train_step(self, x_dict, y):
+        y_pred = self.model(x_dict)
+        loss = self.criterion(y_pred, y)
+        self.model.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def train_one_epoch(self, data_loader, log_interval=10):
+        self.model.train()
+        total_loss = None
+        tk0 = tqdm.tqdm(data_loader, desc="train", smoothing=0, mininterval=1.0)
+        for i, (x_dict, y) in enumerate(tk0):
+            x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
+            y = y.to(self.device, non_blocking=True)
+            loss = self.train_step(x_dict, y).detach()
+            total_loss = loss if total_loss is None else total_loss + loss
+            if (i + 1) % log_interval == 0:
+                tk0.set_postfix(loss=total_loss.item() / log_interval)      # the only host sync of the loop
+                H.check_errors()
+                total_loss = None
+        H.check_errors()
+
+    def fit(self, train_dataloader, val_dataloader=None):
+        for epoch_i in range(self.n_epoch):
+            print('epoch:', epoch_i)
+            self.train_one_epoch(train_dataloader)
+            if self.scheduler is not None:
+                if epoch_i % self.scheduler.step_size == 0:
+                    print("Current lr : {}".format(self.optimizer.state_dict()['param_groups'][0]['lr']))
+                self.scheduler.step()
+            if val_dataloader:
+                auc, logloss = self.evaluate(self.model, val_dataloader)
+                print(f'epoch:{epoch_i} | val auc: {auc} | val logloss: {logloss}')
+                if self.early_stopper.stop_training(auc, self.model.state_dict()):
+                    print(f'validation: best auc: {self.early_stopper.best_auc}')
+                    self.model.load_state_dict(self.early_stopper.best_weights)
+                    break
+        time_now = time.strftime('%m_%d_%H_%M', time.localtime(int(round(time.time() * 1000)) / 1000))
+        name = self.model.__class__.__name__ + "_" + self.data_set_type + "_" + time_now + ".pth"
+        torch.save(self.model.state_dict(), os.path.join(self.model_path, name))
+
+    def _forward_all(self, model, data_loader, desc, with_domain=False):
+        model.eval()
+        ys, ps, ds = [], [], []
+        with torch.no_grad():
+            for x_dict, y in tqdm.tqdm(data_loader, desc=desc, smoothing=0, mininterval=1.0):
+                x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
+                ps.append(model(x_dict).reshape(-1))
+                ys.append(y.reshape(-1))
+                if with_domain:
+                    ds.append(x_dict["domain_indicator"].reshape(-1))
+        H.check_errors()
+        if not ps:
+            return [], [], []
+        p = torch.cat(ps).cpu().tolist()
+        t = torch.cat([y.cpu() for y in ys]).tolist()
+        d = torch.cat(ds).cpu().tolist() if with_domain else []
+        return t, p, d
+
+    def evaluate(self, model, data_loader, mode="val"):
+        targets, predicts, _ = self._forward_all(model, data_loader, "validation")
+        return self.evaluate_fn(targets, predicts), log_loss(targets, predicts)
+
+    def evaluate_multi_domain_loss(self, model, data_loader, domain_num):
+        """-> (logloss per domain, auc per domain, total logloss, total auc); None for empty domains
+        (`ctr_trainer.py:113-152`)."""
+        targets, predicts, domains = self._forward_all(model, data_loader, "validation", with_domain=True)
+        domain_logloss, domain_auc = [], []
+        for d in range(domain_num):
+            t = [a for a, dd in zip(targets, domains) if dd == d]
+            p = [a for a, dd in zip(predicts, domains) if dd == d]
+            domain_logloss.append(log_loss(t, p) if t else None)
+            domain_auc.append(self.evaluate_fn(t, p) if t else None)
+        total_logloss = log_loss(targets, predicts) if predicts else None
+        total_auc = self.evaluate_fn(targets, predicts) if predicts else None
+        return domain_logloss, domain_auc, total_logloss, total_auc
+
+    def predict(self, model, data_loader):
+        _, predicts, _ = self._forward_all(model, data_loader, "predict")
+        return predicts

@@ -98,3 +98,37 @@ def assert_probs_close(got, want, tol=1e-4):
     err = np.abs(logit(np.asarray(got)[~zero]) - logit(w))
     bad = err > tol + quant
     assert not bad.any(), f"max logit error {err.max():.3e} (tol {tol}); {bad.sum()} rows out of tolerance"
+
+
+# ------------------------------------------------------------------ product model from a golden case
+def product_features(schema):
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    return [SparseFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"]) if f["kind"] == "sparse"
+            else DenseFeature(f["name"]) for f in schema]
+
+
+def build_product_model(case, device="cuda"):
+    """The product (HIP) model of the case's family, loaded with the golden `state0`."""
+    import copy
+
+    import torch
+    from scenario_wise_rec.models import multi_domain as md
+    h = copy.deepcopy(case.hyper)
+    sch = [product_features(s) for s in case.schemas]
+    fam = case.family
+    if fam == "PPNet":
+        model = md.PPNet(sch[0], sch[1], **h)
+    elif fam == "EPNet":
+        model = md.EPNet(sch[0], sch[1], **h)
+    elif fam in ("HamurSmall", "HamurLarge"):
+        model = getattr(md, fam)(sch[0], h["domain_num"], h["fcn_dims"], h["hyper_dims"], h["k"])
+    else:
+        model = getattr(md, fam)(sch[0], **h)
+    state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in case.group("state0").items()}
+    model.load_state_dict(state, strict=True)
+    return model.to(device)
+
+
+def to_device(x, device="cuda"):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in x.items()}

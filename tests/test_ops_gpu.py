@@ -1,0 +1,228 @@
+"""Op-level parity of the HIP kernels (through the C ABI via scenario_wise_rec.ops) against numpy /
+the oracle, on seeded inputs.  Integer / copy work is bit-exact; fp32 products are compared with an
+fp64 reference at fp32-roundoff tolerances written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda") if dtype is None else \
+        torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+@pytest.mark.parametrize("B,dims,n_dense,idx_dtype", [
+    (250, [16, 16, 16], 2, np.int64), (1000, [8, 8], 1, np.int16), (64, [32], 0, np.int32),
+    (333, [6, 10, 3], 3, np.int64),          # dims not multiples of 4: scalar path
+    (1, [16], 1, np.int64), (4097, [64, 64], 4, np.int8)])
+def test_gather_bit_exact(B, dims, n_dense, idx_dtype):
+    """K1 is a pure copy: bit-exact against numpy fancy indexing, sparse block first, dense last."""
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(B)
+    vocabs = [int(min(rng.integers(2, 300), np.iinfo(idx_dtype).max)) for _ in dims]
+    feats = [DenseFeature("d0")] if n_dense else []      # dense first in the list: output still puts it last
+    feats += [SparseFeature(f"s{i}", v, d) for i, (v, d) in enumerate(zip(vocabs, dims))]
+    feats += [DenseFeature(f"d{i}") for i in range(1, n_dense)]
+    layer = EmbeddingLayer(feats)
+    tables = {f"s{i}": rng.standard_normal((v, d)).astype(np.float32) for i, (v, d) in enumerate(zip(vocabs, dims))}
+    with torch.no_grad():
+        for k, t in tables.items():
+            layer.embed_dict[k].weight.copy_(torch.from_numpy(t))
+    layer.to("cuda")
+    x = {f"s{i}": rng.integers(0, v, size=B).astype(idx_dtype) for i, v in enumerate(vocabs)}
+    x.update({f"d{i}": rng.random(B).astype(np.float16 if i % 2 else np.float32) for i in range(n_dense)})
+    out = layer({k: _dev(v) for k, v in x.items()}, feats, squeeze_dim=True).cpu().numpy()
+    want = np.concatenate([tables[f"s{i}"][x[f"s{i}"].astype(np.int64)] for i in range(len(dims))] +
+                          [x[f"d{i}"].astype(np.float32)[:, None] for i in range(n_dense)], axis=1)
+    assert out.shape == want.shape
+    assert np.array_equal(out, want)
+
+
+def test_gather_out_of_range_index_raises():
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    f = [SparseFeature("s0", 10, 8)]
+    layer = EmbeddingLayer(f).to("cuda")
+    layer({"s0": torch.tensor([1, 2, 10], device="cuda")}, f, squeeze_dim=True)
+    with pytest.raises(IndexError):
+        H.check_errors()
+
+
+@pytest.mark.parametrize("B,dim,vocabs,limit", [(250, 16, [2, 7, 200], 1 << 30), (1000, 8, [3, 500], 1 << 30),
+                                                (777, 16, [5, 4000, 9000], 64 * 1024),     # two sparse-mode tables
+                                                (512, 12, [40], 1 << 30), (300, 64, [11, 13], 1 << 30)])
+def test_embedding_backward(B, dim, vocabs, limit):
+    """K3 against np.add.at in fp64.  The fixed-point accumulation is exact to 2^-60, so the only error
+    is the final fp32 rounding: rtol 2e-7 of the largest entry."""
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(B + dim)
+    feats = [SparseFeature(f"s{i}", v, dim) for i, v in enumerate(vocabs)]
+    feats.append(SparseFeature("shared", vocabs[0], dim, shared_with="s0"))       # two slots, one table
+    layer = EmbeddingLayer(feats)
+    layer.dense_table_limit_bytes = limit
+    layer.to("cuda")
+    x = {f.name: rng.integers(0, f.vocab_size, size=B) for f in feats}
+    x["s0"][: B // 2] = 1                                                          # a long run of one row
+    out = layer({k: _dev(v) for k, v in x.items()}, feats, squeeze_dim=True)
+    g = rng.standard_normal(out.shape).astype(np.float32) * 1e-3
+    out.backward(_dev(g))
+    torch.cuda.synchronize()
+    for i, f in enumerate(feats[:-1]):
+        want = np.zeros((f.vocab_size, dim), np.float64)
+        np.add.at(want, x[f.name], g[:, i * dim:(i + 1) * dim].astype(np.float64))
+        if i == 0:
+            np.add.at(want, x["shared"], g[:, len(vocabs) * dim:(len(vocabs) + 1) * dim].astype(np.float64))
+        w = layer.embed_dict[f.name].weight
+        if f.vocab_size * dim * 4 > limit:
+            urow, ugrad = w._swr_sparse_grad
+            urow, ugrad = urow.cpu().numpy(), ugrad.cpu().numpy()
+            got = np.zeros_like(want)
+            rows = urow[urow >= 0]
+            assert len(np.unique(rows)) == len(rows)                               # each row listed once
+            got[rows] = ugrad[urow >= 0]
+            assert np.all(ugrad[urow < 0] == 0)
+            assert w.grad is None or not torch.count_nonzero(w.grad)
+        else:
+            got = w.grad.cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * np.abs(want).max())
+
+
+def test_embedding_backward_is_deterministic():
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(5)
+    feats = [SparseFeature("a", 3, 16), SparseFeature("b", 1000, 16)]
+    layer = EmbeddingLayer(feats).to("cuda")
+    x = {k: _dev(rng.integers(0, v, size=20000)) for k, v in (("a", 3), ("b", 1000))}
+    g = _dev(rng.standard_normal((20000, 32)).astype(np.float32))
+    res = []
+    for _ in range(3):
+        layer.zero_grad()
+        layer(x, feats, squeeze_dim=True).backward(g)
+        res.append([p.grad.clone() for p in layer.parameters()])
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(250, 148, 516), (64, 1, 16), (1000, 33, 7), (31, 300, 52), (4096, 256, 376)])
+def test_gemm_forms(M, N, K):
+    """nt / nn / tn on the f32 MFMA pipe against fp64 matmul: exact-fp32 fma chains, so the error is
+    fp32 summation roundoff, bounded here by 2e-6 * sum|a||b| per output."""
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)          # asymmetric operands (transpose-detecting)
+    b = rng.standard_normal(N).astype(np.float32)
+    dA, dW = _dev(A), _dev(W)
+    C = torch.empty((M, N), device="cuda")
+    ops.gemm("nt", dA, dW, C, M, N, K, bias=_dev(b))
+    bound = 2e-6 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1)
+    assert np.all(np.abs(C.cpu().numpy() - (A.astype(np.float64) @ W.astype(np.float64).T + b)) <= bound)
+    Wio = np.ascontiguousarray(W.T)
+    C2 = torch.empty((M, N), device="cuda")
+    ops.gemm("nn", dA, _dev(Wio), C2, M, N, K)
+    assert np.all(np.abs(C2.cpu().numpy() - A.astype(np.float64) @ Wio.astype(np.float64)) <= bound)
+    G = rng.standard_normal((M, N)).astype(np.float32)
+    dWg = torch.empty((N, K), device="cuda")
+    cs = torch.empty(N, device="cuda")
+    ops.gemm_tn(_dev(G), dA, dWg, M, N, K, colsum=cs)
+    want = G.astype(np.float64).T @ A.astype(np.float64)
+    bound_t = 2e-6 * (np.abs(G).astype(np.float64).T @ np.abs(A).astype(np.float64) + 1)
+    assert np.all(np.abs(dWg.cpu().numpy() - want) <= bound_t)
+    np.testing.assert_allclose(cs.cpu().numpy(), G.astype(np.float64).sum(0), rtol=0, atol=2e-6 * np.abs(G).sum(0).max())
+
+
+def test_gemm_identity_detects_transposes():
+    """A = I with an asymmetric B: a swapped row/column in the fragment or C mapping cannot pass."""
+    from scenario_wise_rec import ops
+    n = 96
+    B = np.arange(n * n, dtype=np.float32).reshape(n, n) / 7.0
+    I = np.eye(n, dtype=np.float32)
+    C = torch.empty((n, n), device="cuda")
+    ops.gemm("nt", _dev(I), _dev(B), C, n, n, n)
+    assert np.array_equal(C.cpu().numpy(), B.T)
+    ops.gemm("nn", _dev(I), _dev(B), C, n, n, n)
+    assert np.array_equal(C.cpu().numpy(), B)
+    ops.gemm_tn(_dev(I), _dev(B), C, n, n, n)
+    assert np.array_equal(C.cpu().numpy(), B)
+
+
+def test_grouped_gemm_and_prologue():
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(3)
+    M, G, N, K = 300, 5, 16, 32
+    X = rng.standard_normal((M, G * K)).astype(np.float32)
+    W = rng.standard_normal((G * N, K)).astype(np.float32)
+    sc = rng.standard_normal(G * K).astype(np.float32)
+    sh = rng.standard_normal(G * K).astype(np.float32)
+    C = torch.empty((M, G * N), device="cuda")
+    ops.gemm("nt", _dev(X), _dev(W), C, M, N, K, a_scale=_dev(sc), a_shift=_dev(sh), a_relu=True, groups=G,
+             gsA=K, gsB=N * K, gsC=N, gsScale=K)
+    Xp = np.maximum(X.astype(np.float64) * sc + sh, 0)
+    want = np.concatenate([Xp[:, g * K:(g + 1) * K] @ W[g * N:(g + 1) * N].astype(np.float64).T for g in range(G)], 1)
+    np.testing.assert_allclose(C.cpu().numpy(), want, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N", [(250, 148), (33, 5), (4099, 64)])
+def test_linear_bn_act_block_vs_oracle(M, N):
+    """One [Linear -> BatchNorm1d(train) -> ReLU | softmax] block, forward, running stats and every
+    gradient, against the oracle tape in fp64.  Tolerance 2e-5 absolute on O(1) values."""
+    from oracle import tape as T
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(M * N)
+    K = 52
+    n_sm = 4 if N >= 8 else 0                        # trailing softmax group of 4
+    X = rng.standard_normal((M, K)); W = rng.standard_normal((N, K)) * 0.3; b = rng.standard_normal(N) * 0.1
+    g = rng.random(N) + 0.5; be = rng.standard_normal(N) * 0.2
+    dY = rng.standard_normal((M, N))
+    # oracle
+    x_, W_, b_, g_, be_ = (T.param(a.copy()) for a in (X, W, b, g, be))
+    z = T.linear(x_, W_, b_)
+    y, mu, var = T.batchnorm_train(z, g_, be_, 1e-5)
+    if n_sm:
+        y = T.cat1([T.relu(T.slice1(y, 0, N - n_sm)), T.softmax_rows(T.slice1(y, N - n_sm, N))])
+    else:
+        y = T.relu(y)
+    T.backward(y, seed=dY)
+    # product
+    t = {k: _dev(v, torch.float32).requires_grad_(True) for k, v in dict(X=X, W=W, b=b, g=g, be=be).items()}
+    rm, rv, nbt = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    acts = [(0, N - n_sm, "relu", 1), (N - n_sm, N, "softmax", 4)] if n_sm else "relu"
+    bn = {"gamma": [t["g"]], "beta": [t["be"]], "running_mean": [rm], "running_var": [rv], "nbt": [nbt],
+          "eps": 1e-5, "momentum": 0.1}
+    Y = ops.linear_bn_act(t["X"], [t["W"]], [t["b"]], bn=bn, acts=acts, training=True)
+    Y.backward(_dev(dY, torch.float32))
+    np.testing.assert_allclose(Y.detach().cpu().numpy(), y.v, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * mu, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * var * M / (M - 1), rtol=1e-5)
+    assert int(nbt) == 1
+    for name, ref in (("X", x_), ("W", W_), ("g", g_), ("be", be_)):
+        scale = np.abs(ref.g).max()
+        np.testing.assert_allclose(t[name].grad.cpu().numpy(), ref.g, rtol=0, atol=3e-5 * scale, err_msg=name)
+    assert np.abs(t["b"].grad.cpu().numpy()).max() < 1e-3 * np.abs(W_.g).max()      # mathematically zero
+
+
+def test_fused_adam_matches_oracle():
+    from oracle.optim import Adam
+    from scenario_wise_rec.optim import FusedAdam
+    rng = np.random.default_rng(0)
+    shapes = [(37, 5), (11,), (128, 16)]
+    ps = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    params = [torch.nn.Parameter(_dev(p)) for p in ps]
+    opt = FusedAdam(params, lr=1e-3, weight_decay=1e-5)
+    ref = Adam(lr=1e-3, weight_decay=1e-5)
+    state = {i: p.astype(np.float64) for i, p in enumerate(ps)}
+    for step in range(5):
+        gs = [rng.standard_normal(s).astype(np.float32) * 10 ** rng.uniform(-6, 0) for s in shapes]
+        for p, g in zip(params, gs):
+            p.grad = _dev(g)
+        opt.step()
+        ref.step(state, {i: g.astype(np.float64) for i, g in enumerate(gs)})
+    for i, p in enumerate(params):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), state[i], rtol=0, atol=2e-6)
