@@ -34,7 +34,7 @@ def test_gather_bit_exact(B, dims, n_dense, idx_dtype):
     layer.to("cuda")
     x = {f"s{i}": rng.integers(0, v, size=B).astype(idx_dtype) for i, v in enumerate(vocabs)}
     x.update({f"d{i}": rng.random(B).astype(np.float16 if i % 2 else np.float32) for i in range(n_dense)})
-    out = layer({k: _dev(v) for k, v in x.items()}, feats, squeeze_dim=True).cpu().numpy()
+    out = layer({k: _dev(v) for k, v in x.items()}, feats, squeeze_dim=True).detach().cpu().numpy()
     want = np.concatenate([tables[f"s{i}"][x[f"s{i}"].astype(np.int64)] for i in range(len(dims))] +
                           [x[f"d{i}"].astype(np.float32)[:, None] for i in range(n_dense)], axis=1)
     assert out.shape == want.shape
