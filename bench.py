@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- train samples/s of the multi-domain CTR hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2] [--no-graph] [--no-cpu-baseline]
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): KuaiRand-shaped 5-domain
+MMoE with 4 experts, embed_dim 16, batch 65 536 per GPU, synthetic device-resident inputs, random-init
+weights.  One step = the reference's training step (`trainers/ctr_trainer.py:67-73`): fused lookup ->
+experts/gates -> towers -> domain select -> BCE -> backward (all parameter gradients, embedding tables
+included) -> Adam(lr 1e-3, weight_decay 1e-5) on every parameter.  fp32 end to end (f32 MFMA).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with
+HIP events on the launch stream) and `cpu_baseline` (the numpy oracle timed on this box's host cores on a
+bounded sample).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), data parallel,
+weak scaling (65 536 rows per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "scenario-wise-rec_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+# KuaiRand-1K schema (scripts/run_kuairand_ctr_multi_domain.py:15-57, scripts/data/kuairand/load_data_1k.py:23-49,
+# README.md:137): user_id, video_id, 8 user categoricals, 18 one-hot groups, 4 video categoricals; 4 dense
+KUAIRAND_VOCABS = [1000, 4371900, 8, 2, 3, 2, 8, 8, 7, 7,
+                   3, 8, 51, 1472, 16, 35, 4, 119, 455, 8, 6, 6, 3, 3, 3, 3, 3, 3,
+                   3, 8, 200, 300]
+KUAIRAND_DOMAIN_SHARES = [0.207, 0.666, 0.077, 0.035, 0.016]      # README.md:42-46
+
+CONFIGS = {
+    2: dict(name="kuairand_mmoe4_e16_b65536", family="MMOE", vocabs=KUAIRAND_VOCABS, embed_dim=16, n_dense=4,
+            batch=65536, domain_shares=KUAIRAND_DOMAIN_SHARES,
+            hyper=dict(domain_num=5, n_expert=4, expert_params={"dims": [32]}, tower_params={"dims": [16]})),
+}
+
+
+def synth_batch(cfg, B, seed, zipf=True):
+    """Synthetic batch (numpy, host): Zipf(1.05) ids clipped to V for tables with V >= 1e4, uniform otherwise,
+    dense U[0,1), domain ~ the dataset's interaction shares, labels Bernoulli(0.2)."""
+    rng = np.random.default_rng(seed)
+    x = {}
+    for i, v in enumerate(cfg["vocabs"]):
+        if zipf and v >= 10000:
+            ids = np.minimum(rng.zipf(1.05, size=B) - 1, v - 1)
+            ids = (ids * 2654435761) % v            # scatter the popular rows over the table
+        else:
+            ids = rng.integers(0, v, size=B)
+        x[f"s{i}"] = ids.astype(np.int64)
+    for i in range(cfg["n_dense"]):
+        x[f"d{i}"] = rng.random(B).astype(np.float32)
+    p = np.asarray(cfg["domain_shares"], dtype=np.float64)
+    x["domain_indicator"] = rng.choice(len(p), size=B, p=p / p.sum()).astype(np.int64)
+    y = (rng.random(B) < 0.2).astype(np.float32)
+    return x, y
+
+
+def build_model(cfg, seed=2024):
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.models import multi_domain as md
+    torch.manual_seed(seed)
+    feats = [DenseFeature(f"d{i}") for i in range(cfg["n_dense"])] + \
+            [SparseFeature(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
+    return getattr(md, cfg["family"])(feats, **cfg["hyper"]), feats
+
+
+def gather_bytes_per_sample(cfg, idx_bytes=8):
+    fs, e, fd = len(cfg["vocabs"]), cfg["embed_dim"], cfg["n_dense"]
+    k0 = fs * e + fd
+    return fs * (idx_bytes + 4 * e) + 4 * fd + 4 * k0          # 4 384 B at config 2
+
+
+def time_kernel_events(fn, iters, stream):
+    """Average duration (ms) of `fn` launched `iters` times back to back on `stream`, HIP events on that stream."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        fn()
+        start.record(stream)
+        for _ in range(iters):
+            fn()
+        stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """The numpy oracle (a port of the reference's step, pinned on the reference's outputs) timed on this host:
+    same model shape and tables, a bounded batch, fwd + BCE + bwd + Adam."""
+    from threadpoolctl import threadpool_info
+    from oracle.models import OracleModel
+    from oracle.nn import Dense, Sparse
+    from oracle.optim import Adam
+    Bc = 8192
+    rng = np.random.default_rng(0)
+    feats = [Dense(f"d{i}") for i in range(cfg["n_dense"])] + [Sparse(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
+    model, _ = build_model(cfg)
+    state = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    del model
+    om = OracleModel(cfg["family"], dict(features=feats, **cfg["hyper"]), state, dtype=np.float32)
+    opt = Adam(lr=1e-3, weight_decay=1e-5)
+    x, y = synth_batch(cfg, Bc, seed=1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        _, _, grads = om.loss_and_grads(x, y)
+        opt.step(om.state, grads)
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    return {"value": n * Bc / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{n} full steps (fwd+BCE+bwd+dense Adam) of the numpy oracle at batch {Bc}, same tables and model; "
+                      f"BLAS on {threads} threads, elementwise numpy single-threaded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--uniform-ids", action="store_true", help="uniform ids for the large tables (worst case for the gather)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.trainers import CTRTrainer
+    model, feats = build_model(cfg)
+    trainer = CTRTrainer(model, cfg["name"], optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device=str(dev))
+    model.train()
+    B = cfg["batch"]
+    xh, yh = synth_batch(cfg, B, seed=2022 + args.config + 1000 * rank, zipf=not args.uniform_ids)
+    x = {k: torch.from_numpy(v).to(dev) for k, v in xh.items()}
+    y = torch.from_numpy(yh).to(dev)
+
+    if world > 1:
+        from scenario_wise_rec.parallel import DataParallelStep
+        stepper = DataParallelStep(trainer, world)
+        step_fn = lambda: stepper.train_step(x, y)
+    else:
+        step_fn = lambda: trainer.train_step(x, y)
+
+    # ---- warm-up (eager), then capture the whole step into a hipGraph -------------------------------------
+    graph = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(1, args.warmup)):
+            loss = step_fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    H.check_errors()
+    if not args.no_graph and world == 1:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = step_fn()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:                     # noqa: BLE001
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step_fn
+    for _ in range(2):
+        run()
+
+    # ---- timed region: exactly K steps between barrier + synchronize ------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    H.check_errors()
+    final_loss = float(loss)
+
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel (see DESIGN.md "Measurement") ------------------------------------
+    roof = measure_roofline(cfg, model, trainer, x, dev, args.steps)
+    out = {
+        "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["name"], "global_batch": world * B, "per_gpu_batch": B,
+                   "step": "fwd+BCE+bwd+Adam(all params, dense tables incl.)", "parallelism": f"dp{world}",
+                   "ids": "uniform" if args.uniform_ids else "zipf1.05(video_id)+uniform", "hipgraph": graph is not None,
+                   "final_loss": final_loss},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    print(json.dumps(out))
+
+
+def measure_roofline(cfg, model, trainer, x, dev, iters):
+    """Dominant kernel of the step at this config: the untouched-row Adam sweep over the 4.37 M x 16 video_id
+    table (dense-Adam semantics of the reference: every row moves every step).  HBM-bound:
+    algorithmic bytes = rows * dim * (3 reads + 3 writes) * 4 B + the touched-row bitmap."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec._hip import lib
+    opt = trainer.optimizer
+    big = [p for p in model.parameters() if id(p) in opt._big]
+    if not big:
+        return None
+    p = max(big, key=lambda t: t.numel())
+    m, v, bitmap = opt._big[id(p)]
+    hyper = opt._hyper[0][0]
+    stream = torch.cuda.Stream()
+
+    def launch():
+        H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap),
+                                             H.ptr(hyper), H.stream()), "swr_adam_sweep_untouched")
+    backup = (p.detach().clone(), m.clone(), v.clone())
+    ms = time_kernel_events(launch, max(10, iters), stream)
+    with torch.no_grad():
+        p.copy_(backup[0]); m.copy_(backup[1]); v.copy_(backup[2])
+    nbytes = p.numel() * 4 * 6 + bitmap.numel() * 4
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "adam_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_ms": ms}
+
+
+if __name__ == "__main__":
+    main()
