@@ -1,0 +1,101 @@
+"""Worker of the data-parallel tests (one process per rank; launched by tests/test_parallel*.py).
+
+    python tests/dp_worker.py <mode> <case> <out_dir>
+
+mode "exchange-cpu": gloo on CPU.  Each rank takes its row shard of the golden case, gets its LOCAL gradients
+    from the oracle (test infrastructure), packs them the way the product does (flat dense arena + row-sparse
+    entries for the largest table) and runs the product's exchange step (scenario_wise_rec.parallel) with a
+    numpy row merge injected.  Rank 0 dumps the exchanged gradients.
+mode "full-gpu": gloo over device tensors, every rank on cuda:0.  The whole HIP path (DataParallelStep) for one
+    step; rank 0 dumps gradients and the state after the step.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "scenario-wise-rec_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from _golden import Case, build_product_model, make_oracle, to_device
+
+
+def shard(case, rank, world):
+    x, y = case.batch(0)
+    B = len(y)
+    sh = B // world
+    return {k: v[rank * sh:(rank + 1) * sh] for k, v in x.items()}, y[rank * sh:(rank + 1) * sh]
+
+
+def numpy_merge_rows(urow, ugrad, vocab):
+    """Oracle-side stand-in for the HIP row merge: same output convention (sorted rows first-listed, -1 padding)."""
+    r, g = urow.numpy(), ugrad.numpy().astype(np.float64)
+    full = np.zeros((vocab, g.shape[1]))
+    np.add.at(full, r[r >= 0], g[r >= 0])
+    rows = np.unique(r[r >= 0])
+    out_r = np.full(len(r), -1, np.int32)
+    out_g = np.zeros_like(g, dtype=np.float32)
+    out_r[:len(rows)] = rows
+    out_g[:len(rows)] = full[rows]
+    return torch.from_numpy(out_r), torch.from_numpy(out_g)
+
+
+def main():
+    mode, name, out_dir = sys.argv[1:4]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = Case(name)
+    x, y = shard(case, rank, world)
+    if mode == "exchange-cpu":
+        from scenario_wise_rec.parallel import exchange_gradients
+        om = make_oracle(case)
+        _, _, grads = om.loss_and_grads(x, y)
+        keys = sorted(grads)
+        big = max((k for k in keys if "embed_dict" in k), key=lambda k: grads[k].size)
+        dense_keys = [k for k in keys if k != big]
+        flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in dense_keys]).astype(np.float32))
+        gb = grads[big]
+        rows = np.flatnonzero(np.abs(gb).sum(1) > 0).astype(np.int32)
+        n = len(y)                                   # one entry per looked-up sample, -1 padded (product convention)
+        urow = np.full(n, -1, np.int32); urow[:len(rows)] = rows
+        ugrad = np.zeros((n, gb.shape[1]), np.float32); ugrad[:len(rows)] = gb[rows]
+        merged = exchange_gradients(flat, [(torch.from_numpy(urow), torch.from_numpy(ugrad), gb.shape[0])], world,
+                                    merge_rows=numpy_merge_rows)
+        if rank == 0:
+            out, off = {}, 0
+            for k in dense_keys:
+                out[k] = flat[off:off + grads[k].size].numpy().reshape(grads[k].shape); off += grads[k].size
+            r, g = merged[0]
+            full = np.zeros(gb.shape, np.float32)
+            full[r.numpy()[r.numpy() >= 0]] = g.numpy()[r.numpy() >= 0]
+            out[big] = full
+            np.savez(os.path.join(out_dir, "exchanged.npz"), **out)
+    else:
+        from scenario_wise_rec import _hip as H
+        from scenario_wise_rec.parallel import DataParallelStep
+        from scenario_wise_rec.trainers import CTRTrainer
+        from scenario_wise_rec.basic.module import SwrModule
+        if len(sys.argv) > 4:
+            SwrModule.dense_table_limit_bytes = int(sys.argv[4])     # force the row-sparse path for the larger tables
+        torch.cuda.set_device(0)
+        model = build_product_model(case, device="cuda:0")
+        tr = CTRTrainer(model, "dp", optimizer_params={"lr": case.meta["lr"], "weight_decay": case.meta["weight_decay"]},
+                        device="cuda:0")
+        step = DataParallelStep(tr, world)
+        model.train()
+        step.train_step(to_device(x, "cuda:0"), torch.from_numpy(y).cuda())
+        torch.cuda.synchronize()
+        H.check_errors()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "state1.npz"), **{k: v.cpu().numpy() for k, v in model.state_dict().items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
