@@ -123,6 +123,12 @@ def cpu_baseline(cfg, seconds_budget=20.0):
                       f"BLAS on {threads} threads, elementwise numpy single-threaded"}
 
 
+def _stage(msg):
+    if os.environ.get("SWR_BENCH_VERBOSE"):
+        torch.cuda.synchronize()
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +157,10 @@ def main():
     from scenario_wise_rec import _hip as H
     from scenario_wise_rec.trainers import CTRTrainer
     model, feats = build_model(cfg)
+    if os.environ.get("SWR_BENCH_FREEZE_TABLES"):          # debugging aid: no embedding backward / table update
+        for n_, p_ in model.named_parameters():
+            if "embed_dict" in n_:
+                p_.requires_grad_(False)
     trainer = CTRTrainer(model, cfg["name"], optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device=str(dev))
     model.train()
     B = cfg["batch"]
@@ -167,28 +177,27 @@ def main():
 
     # ---- warm-up (eager), then capture the whole step into a hipGraph -------------------------------------
     graph = None
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(1, args.warmup)):
-            loss = step_fn()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    H.check_errors()
     if not args.no_graph and world == 1:
+        from scenario_wise_rec.trainers.graph import GraphedStep
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = step_fn()
+            graph = GraphedStep(trainer, x, y, warmup=args.warmup)
+            _stage("captured")
             graph.replay()
             torch.cuda.synchronize()
+            _stage("first replay")
         except Exception as e:                     # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+    if graph is None:
+        for _ in range(max(1, args.warmup)):
+            step_fn()
+        torch.cuda.synchronize()
+    H.check_errors()
     run = graph.replay if graph is not None else step_fn
     for _ in range(2):
         run()
+    _stage("pre-timed replays")
 
     # ---- timed region: exactly K steps between barrier + synchronize ------------------------------------
     if dist is not None:
@@ -196,7 +205,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run()
+        loss = run()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -206,7 +215,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     H.check_errors()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank != 0:
         return
@@ -214,6 +223,7 @@ def main():
     value = world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel (see DESIGN.md "Measurement") ------------------------------------
+    print(f"[bench] timed region done: {ms:.3f} ms/step", file=sys.stderr, flush=True)
     roof = measure_roofline(cfg, model, trainer, x, dev, args.steps)
     out = {
         "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X",

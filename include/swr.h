@@ -101,6 +101,7 @@ int swr_embed_gather_fwd(const swr_sparse_slot* sparse_host, int n_sparse,
  * on every data-parallel rank).  Slots that share a table (`shared_with`,
  * basic/layers.py:71-72) carry the same `table_id` and sum into one gradient.
  *   mode 0 (dense) : grad_dense[vocab, dim] is fully written (zeros included);
+ *   mode 2 (dense+): the table's gradient is ADDED to grad_dense (gradient arena fan-in);
  *   mode 1 (sparse): for large tables; `urow` / `ugrad` have one entry per
  *                    looked-up sample of the table, in sorted-row order:
  *                    urow[i] = row (first entry of each distinct row) or -1,
@@ -111,7 +112,7 @@ typedef struct {
     int32_t dim;
     int32_t in_col;        /* first column of this slot in dE */
     int32_t table_id;      /* 0..n_tables-1 */
-    int32_t mode;          /* 0 dense, 1 sparse */
+    int32_t mode;          /* 0 dense, 1 sparse, 2 dense accumulate */
     float* grad_dense;     /* mode 0: [vocab, dim] of the TABLE (same pointer for sharing slots) */
     int32_t* urow;         /* mode 1: [count of samples of this table] */
     float* ugrad;          /* mode 1: [count, dim] */

@@ -110,6 +110,5 @@ extern "C" int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vo
     const int64_t n = vocab * dim;
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(n, AD_THREADS) < 8192 ? swr_ceil_div(n, AD_THREADS) : 8192);
     hipLaunchKernelGGL(adam_sweep_kernel, dim3(grid), dim3(AD_THREADS), 0, st, p, m, v, vocab, dim, bitmap, hyper);
-    if (hipMemsetAsync(bitmap, 0, static_cast<size_t>(swr_ceil_div(vocab, 32)) * 4, st) != hipSuccess) return SWR_ERR_LAUNCH;
-    return swr_launch_status();
+    return swr_zero_async(bitmap, static_cast<size_t>(swr_ceil_div(vocab, 32)) * 4, st);
 }

@@ -76,3 +76,9 @@ __device__ __forceinline__ float swr_sigmoid(float x) {
     const float r = 1.f / (1.f + e);
     return x >= 0.f ? r : e * r;
 }
+
+// Zero-fill as an ordinary kernel node.  hipMemsetAsync becomes a memset node under hipGraph capture;
+// on ROCm 7.2 those were observed to misbehave in back-to-back replays of a captured training step, so the
+// library never issues memsets on the hot path.
+__global__ void swr_zero_kernel(uint4* p, size_t n16, unsigned char* tail, size_t ntail);
+int swr_zero_async(void* p, size_t bytes, hipStream_t st);

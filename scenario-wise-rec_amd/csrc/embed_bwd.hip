@@ -1,11 +1,14 @@
 // K3: backward of the embedding lookup for ALL features of a batch at once
 // (replaces F_s x aten::embedding_dense_backward).
 //
-//   1. build_keys : composite key (table_id << row_bits | row) and payload (slot << 24 | sample)
-//   2. sort       : device-wide LSD radix sort of the (key, payload) pairs on the used key bits only
-//                   (rocPRIM's radix_sort_pairs -- the one library primitive on this path)
-//   3. reduce     : each group of LPE lanes walks a fixed chunk of CHUNK sorted entries, sums runs of
-//                   equal keys in registers and flushes each run with two 64-bit integer atomics
+//   1. build_keys : entries (row, slot << 24 | sample) written grouped by table (one segment per table)
+//   2. sort       : segmented LSD radix sort of every table segment by row, 8 bits per pass, stable; pass p
+//                   only does work for tables whose row ids need more than 8p bits (others copy through).
+//                   Hand-written (histogram -> per-table scan -> ranked scatter), no atomics on global
+//                   memory, no memset nodes, no inter-workgroup spinning: safe to capture and replay.
+//   3. reduce     : each group of LPE lanes walks a fixed chunk of CHUNK sorted entries of one table, sums
+//                   runs of equal rows in registers and flushes each run (plain stores for runs that lie
+//                   inside the chunk, two 64-bit integer atomics for runs cut by a chunk boundary)
 //   4. finalise   : integer accumulators -> fp32 gradients (dense tables) or per-row entries (sparse)
 //
 // Accumulation is dual-limb fixed point: x * 2^20 = hi + frac, hi in 2^-20 units, frac kept in 2^-60
@@ -13,23 +16,24 @@
 // runs, chunks and workgroups meet: bitwise deterministic, identical on every data-parallel rank.
 // Representable range |x| < 2^20 (flagged otherwise); sums of up to 2^22 entries per row cannot overflow.
 //
-// HBM traffic per sample at dim E: keys 4 B + sorted (key, payload) 8 B + dE row 4E, plus 16E bytes of
-// accumulator read-modify-write per DISTINCT (table, row) touched.
+// HBM traffic per sample at dim E: keys 4 B + (8 B read + 8 B write) per sort pass + dE row 4E, plus 16E
+// bytes of accumulator traffic per DISTINCT (table, row) touched.
 #include <algorithm>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include "common.h"
 
-#define MAX_SLOTS 48   // BwdMeta travels by value in the kernarg segment (4 KiB)
+#define MAX_SLOTS 40   // BwdMeta travels by value in the kernarg segment (4 KiB)
 #define CHUNK 32
 #define RB_THREADS 256
+#define SORT_THREADS 256
+#define SORT_ITEMS 8
+#define SORT_TILE (SORT_THREADS * SORT_ITEMS)
 
 struct TableMeta {
     int64_t vocab;
     int64_t acc_off;     // dense: offset (in elements) into the dense accumulator region
-    int64_t sorted_off;  // first sorted position of this table's entries
+    int64_t sorted_off;  // first sorted position of this table's segment
     float* grad_dense;
     int32_t* urow;
     float* ugrad;
@@ -41,30 +45,41 @@ struct BwdMeta {
     TableMeta tab[MAX_SLOTS];
     int32_t slot_col[MAX_SLOTS];
     int32_t slot_dim[MAX_SLOTS];
-    int32_t slot_table[MAX_SLOTS];
+    int64_t slot_dst[MAX_SLOTS];     // where this slot's B entries start inside its table segment
+    int32_t chunk_off[MAX_SLOTS + 1];   // first reduce chunk of each table
     int32_t n_slots, n_tables;
-    int32_t row_bits;
     int32_t dim_max;
+    int32_t pad;
     int64_t B, n;
     int64_t sparse_start;   // first sorted position belonging to a sparse-mode table
 };
 
+struct SortMeta {
+    int64_t seg_off[MAX_SLOTS + 1];
+    int32_t tile_off[MAX_SLOTS + 1];
+    int32_t passes[MAX_SLOTS];
+    int32_t n_tables;
+    int32_t n_tiles;
+};
+
 struct HostPlan {
     BwdMeta m;
+    SortMeta sm;
     int64_t dense_acc_elems;
     int64_t sparse_acc_elems;
-    size_t off_ck0, off_ck1, off_v0, off_v1, off_acc_hi, off_acc_lo, off_temp, temp_bytes, total;
-    int key_bits;
+    size_t off_k0, off_k1, off_v0, off_v1, off_hist, off_acc_hi, off_acc_lo, total;
+    int n_passes;
+    int n_chunks;
 };
 
 static int bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
-    int b = 1;
+    int b = 0;
     while ((max_value >> b) != 0) ++b;
     return b;
 }
 static size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, bool query_temp, HostPlan& p) {
+static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, HostPlan& p) {
     SWR_REQUIRE(slots && n_slots > 0 && n_slots <= MAX_SLOTS && B > 0, SWR_ERR_ARG);
     SWR_REQUIRE(B <= (1 << 24), SWR_ERR_UNSUPPORTED);
     BwdMeta& m = p.m;
@@ -72,11 +87,11 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, b
     m.B = B;
     m.n = static_cast<int64_t>(n_slots) * B;
     int n_tables = 0;
-    int64_t max_vocab = 1;
     int dim_max = 1;
     for (int s = 0; s < n_slots; ++s) {
         SWR_REQUIRE(slots[s].table_id >= 0 && slots[s].table_id < MAX_SLOTS && slots[s].dim > 0 && slots[s].vocab > 0,
                     SWR_ERR_ARG);
+        SWR_REQUIRE(slots[s].vocab <= 0xFFFFFFFFll + 1, SWR_ERR_UNSUPPORTED);
         if (slots[s].table_id + 1 > n_tables) n_tables = slots[s].table_id + 1;
     }
     bool seen[MAX_SLOTS] = {false};
@@ -92,24 +107,25 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, b
             t.grad_dense = sl.grad_dense;
             t.urow = sl.urow;
             t.ugrad = sl.ugrad;
-            SWR_REQUIRE(sl.mode == 0 ? sl.grad_dense != nullptr : (sl.urow != nullptr && sl.ugrad != nullptr), SWR_ERR_ARG);
+            SWR_REQUIRE(sl.mode >= 0 && sl.mode <= 2, SWR_ERR_ARG);
+            SWR_REQUIRE(sl.mode != 1 ? sl.grad_dense != nullptr : (sl.urow != nullptr && sl.ugrad != nullptr), SWR_ERR_ARG);
         } else {
             SWR_REQUIRE(t.vocab == sl.vocab && t.dim == sl.dim && t.mode == sl.mode, SWR_ERR_ARG);
         }
+        m.slot_dst[s] = count[sl.table_id];          // offset inside the table segment (segment base added below)
         count[sl.table_id] += B;
         m.slot_col[s] = sl.in_col;
         m.slot_dim[s] = sl.dim;
-        m.slot_table[s] = sl.table_id;
-        if (sl.vocab > max_vocab) max_vocab = sl.vocab;
         if (sl.dim > dim_max) dim_max = sl.dim;
     }
     int64_t acc = 0, pos = 0;
+    int tiles = 0, chunks = 0, passes = 0;
     m.sparse_start = -1;
     for (int t = 0; t < n_tables; ++t) {
         SWR_REQUIRE(seen[t], SWR_ERR_ARG);                       // table ids must be dense 0..n_tables-1
         TableMeta& tm = m.tab[t];
         tm.sorted_off = pos;
-        if (tm.mode == 0) {
+        if (tm.mode != 1) {
             SWR_REQUIRE(m.sparse_start < 0, SWR_ERR_ARG);        // sparse tables carry the largest ids
             tm.acc_off = acc;
             acc += tm.vocab * tm.dim;
@@ -117,34 +133,39 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, b
             if (m.sparse_start < 0) m.sparse_start = pos;
             tm.acc_off = 0;
         }
+        p.sm.seg_off[t] = pos;
+        p.sm.tile_off[t] = tiles;
+        p.sm.passes[t] = (bits_for(static_cast<uint64_t>(tm.vocab - 1)) + 7) / 8;
+        if (p.sm.passes[t] > passes) passes = p.sm.passes[t];
+        m.chunk_off[t] = chunks;
+        tiles += static_cast<int>(swr_ceil_div(count[t], SORT_TILE));
+        chunks += static_cast<int>(swr_ceil_div(count[t], CHUNK));
         pos += count[t];
     }
+    for (int s = 0; s < n_slots; ++s) m.slot_dst[s] += m.tab[slots[s].table_id].sorted_off;
+    p.sm.seg_off[n_tables] = pos;
+    p.sm.tile_off[n_tables] = tiles;
+    p.sm.n_tables = n_tables;
+    p.sm.n_tiles = tiles;
+    m.chunk_off[n_tables] = chunks;
     if (m.sparse_start < 0) m.sparse_start = m.n;
     m.n_tables = n_tables;
     m.dim_max = dim_max;
-    m.row_bits = bits_for(static_cast<uint64_t>(max_vocab - 1));
-    p.key_bits = m.row_bits + (n_tables > 1 ? bits_for(static_cast<uint64_t>(n_tables - 1)) : 0);
-    SWR_REQUIRE(p.key_bits <= 32, SWR_ERR_UNSUPPORTED);
+    p.n_passes = passes;
+    p.n_chunks = chunks;
     p.dense_acc_elems = acc;
     p.sparse_acc_elems = (m.n - m.sparse_start) * dim_max;
 
-    p.temp_bytes = 0;
-    if (query_temp) {
-        uint32_t* nul = nullptr;
-        if (rocprim::radix_sort_pairs(nullptr, p.temp_bytes, nul, nul, nul, nul, static_cast<size_t>(m.n), 0u,
-                                      static_cast<unsigned>(p.key_bits), hipStream_t(0)) != hipSuccess)
-            return SWR_ERR_LAUNCH;
-    }
     size_t off = 0;
     const size_t kb = align_up(static_cast<size_t>(m.n) * 4);
-    p.off_ck0 = off; off += kb;
-    p.off_ck1 = off; off += kb;
+    p.off_k0 = off; off += kb;
+    p.off_k1 = off; off += kb;
     p.off_v0 = off; off += kb;
     p.off_v1 = off; off += kb;
+    p.off_hist = off; off += align_up(static_cast<size_t>(tiles) * 256 * 4);
     const size_t ab = align_up(static_cast<size_t>(p.dense_acc_elems + p.sparse_acc_elems) * 8);
     p.off_acc_hi = off; off += ab;
     p.off_acc_lo = off; off += ab;
-    p.off_temp = off; off += align_up(p.temp_bytes);
     p.total = off;
     return SWR_OK;
 }
@@ -154,11 +175,124 @@ __global__ __launch_bounds__(RB_THREADS) void build_keys_kernel(const BwdMeta m,
     const int64_t i = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x;
     if (i >= m.n) return;
     const int slot = static_cast<int>(i / m.B);
-    const uint32_t b = static_cast<uint32_t>(i - static_cast<int64_t>(slot) * m.B);
-    ck[i] = (m.row_bits >= 32 ? 0u : (static_cast<uint32_t>(m.slot_table[slot]) << m.row_bits)) | keys[i];
-    val[i] = (static_cast<uint32_t>(slot) << 24) | b;
+    const int64_t b = i - static_cast<int64_t>(slot) * m.B;
+    const int64_t dst = m.slot_dst[slot] + b;
+    ck[dst] = keys[i];
+    val[dst] = (static_cast<uint32_t>(slot) << 24) | static_cast<uint32_t>(b);
 }
 
+// ------------------------------------------------------------------------------- segmented radix sort
+__device__ __forceinline__ int sort_table_of_tile(const SortMeta& sm, int tile) {
+    int t = 0;
+    while (t + 1 < sm.n_tables && sm.tile_off[t + 1] <= tile) ++t;
+    return t;
+}
+
+// per-tile histogram of the pass's digit
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const SortMeta sm, int pass, const uint32_t* __restrict__ kin,
+                                                                 uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    const int tile = blockIdx.x;
+    const int t = sort_table_of_tile(sm, tile);
+    if (pass >= sm.passes[t]) return;
+    const int64_t start = sm.seg_off[t] + static_cast<int64_t>(tile - sm.tile_off[t]) * SORT_TILE;
+    const int len = static_cast<int>(min<int64_t>(SORT_TILE, sm.seg_off[t + 1] - start));
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < len; e += SORT_THREADS) atomicAdd(&lh[(kin[start + e] >> (8 * pass)) & 255u], 1u);
+    __syncthreads();
+    hist[static_cast<int64_t>(tile) * 256 + threadIdx.x] = lh[threadIdx.x];
+}
+
+// one workgroup per table, thread = digit: hist[tile][digit] -> global output offset of (tile, digit)
+__global__ __launch_bounds__(256) void sort_scan_kernel(const SortMeta sm, int pass, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t tot[256];
+    const int t = blockIdx.x;
+    if (pass >= sm.passes[t]) return;
+    const int t0 = sm.tile_off[t], t1 = sm.tile_off[t + 1];
+    uint32_t run = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        const uint32_t c = hist[static_cast<int64_t>(tile) * 256 + threadIdx.x];
+        hist[static_cast<int64_t>(tile) * 256 + threadIdx.x] = run;
+        run += c;
+    }
+    tot[threadIdx.x] = run;
+    __syncthreads();
+    // exclusive scan of the 256 digit totals (Hillis-Steele in LDS)
+    uint32_t v = run;
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? tot[threadIdx.x - off] : 0u;
+        __syncthreads();
+        v += add;
+        tot[threadIdx.x] = v;
+        __syncthreads();
+    }
+    const uint32_t base = static_cast<uint32_t>(sm.seg_off[t]) + (v - run);
+    for (int tile = t0; tile < t1; ++tile) hist[static_cast<int64_t>(tile) * 256 + threadIdx.x] += base;
+}
+
+// stable scatter: element order inside a tile is round-major, then wave, then lane (= memory order)
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const SortMeta sm, int pass, const uint32_t* __restrict__ kin,
+                                                                    const uint32_t* __restrict__ vin,
+                                                                    uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                                    const uint32_t* __restrict__ hist) {
+    __shared__ uint32_t off[256];
+    __shared__ uint32_t wc[SORT_THREADS / 64][256];
+    const int tile = blockIdx.x;
+    const int t = sort_table_of_tile(sm, tile);
+    const int64_t start = sm.seg_off[t] + static_cast<int64_t>(tile - sm.tile_off[t]) * SORT_TILE;
+    const int len = static_cast<int>(min<int64_t>(SORT_TILE, sm.seg_off[t + 1] - start));
+    if (pass >= sm.passes[t]) {          // this table is already sorted: carry it to the other buffer
+        for (int e = threadIdx.x; e < len; e += SORT_THREADS) {
+            kout[start + e] = kin[start + e];
+            vout[start + e] = vin[start + e];
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    off[threadIdx.x] = hist[static_cast<int64_t>(tile) * 256 + threadIdx.x];
+#pragma unroll
+    for (int w = 0; w < SORT_THREADS / 64; ++w) wc[w][threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int e = r * SORT_THREADS + threadIdx.x;
+        const bool valid = e < len;
+        uint32_t key = 0, val = 0;
+        if (valid) {
+            key = kin[start + e];
+            val = vin[start + e];
+        }
+        const uint32_t d = (key >> (8 * pass)) & 255u;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool b = (d >> bit) & 1u;
+            const unsigned long long mb = __ballot(valid && b);
+            mask &= b ? mb : ~mb;
+        }
+        const int rank = __popcll(mask & lt_mask);
+        if (valid && rank == 0) wc[wave][d] = static_cast<uint32_t>(__popcll(mask));
+        __syncthreads();
+        if (valid) {
+            uint32_t pre = off[d];
+            for (int w = 0; w < wave; ++w) pre += wc[w][d];
+            kout[pre + rank] = key;
+            vout[pre + rank] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_THREADS / 64; ++w) {
+            add += wc[w][threadIdx.x];
+            wc[w][threadIdx.x] = 0;
+        }
+        off[threadIdx.x] += add;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ reduce
 __device__ __forceinline__ void to_fixed(float x, long long& hi, long long& lo, uint32_t* err) {
     if (!(fabsf(x) < 1048576.f)) {            // also catches NaN / Inf
         if (err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
@@ -175,13 +309,8 @@ __device__ __forceinline__ float from_fixed(long long hi, long long lo) {
                               static_cast<double>(lo) * (1.0 / 1152921504606846976.0));
 }
 
-__device__ __forceinline__ int table_of(const BwdMeta& m, uint32_t key) {
-    return m.row_bits >= 32 ? 0 : static_cast<int>(key >> m.row_bits);
-}
-
-// first position whose key is >= key
-__device__ __forceinline__ int64_t lower_bound_key(const uint32_t* ck, int64_t n, uint32_t key) {
-    int64_t lo = 0, hi = n;
+// first position in [lo, hi) whose key is >= key
+__device__ __forceinline__ int64_t lower_bound_key(const uint32_t* ck, int64_t lo, int64_t hi, uint32_t key) {
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if (ck[mid] < key) lo = mid + 1; else hi = mid;
@@ -189,69 +318,84 @@ __device__ __forceinline__ int64_t lower_bound_key(const uint32_t* ck, int64_t n
     return lo;
 }
 
-// LPE lanes per entry (one lane per gradient column; dims above 64 are walked in 64-column blocks)
+// LPE lanes per entry (one lane per gradient column; dims above 64 are walked in 64-column blocks).
+// A chunk never crosses a table segment.
 template <int LPE>
-__global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, const uint32_t* __restrict__ ck,
+__global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int n_chunks, const uint32_t* __restrict__ ck,
                                                             const uint32_t* __restrict__ val,
                                                             const float* __restrict__ dE, int64_t ld,
                                                             unsigned long long* acc_hi, unsigned long long* acc_lo,
                                                             int64_t dense_acc_elems, uint32_t* err) {
     const int64_t gid = (static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x) / LPE;
     const int e0 = threadIdx.x % LPE;
-    const int64_t i0 = gid * CHUNK;
-    if (i0 >= m.n) return;
-    const int64_t i1 = min(i0 + CHUNK, m.n);
-    const uint32_t row_mask = (m.row_bits >= 32) ? 0xFFFFFFFFu : ((1u << m.row_bits) - 1u);
+    if (gid >= n_chunks) return;
+    int ti = 0;
+    while (ti + 1 < m.n_tables && m.chunk_off[ti + 1] <= gid) ++ti;
+    const TableMeta& t = m.tab[ti];
+    const int64_t seg0 = t.sorted_off;
+    const int64_t seg1 = (ti + 1 < m.n_tables) ? m.tab[ti + 1].sorted_off : m.n;
+    const int64_t i0 = seg0 + (gid - m.chunk_off[ti]) * CHUNK;
+    const int64_t i1 = min(i0 + CHUNK, seg1);
 
-    for (int c0 = 0; c0 < m.dim_max; c0 += LPE) {
+    for (int c0 = 0; c0 < t.dim; c0 += LPE) {
         const int e = c0 + e0;
         uint32_t cur = ck[i0];
         int64_t head = i0;
-        if (i0 > 0 && ck[i0 - 1] == cur && m.tab[table_of(m, cur)].mode != 0) head = lower_bound_key(ck, m.n, cur);
+        // a run that starts and ends inside this chunk is the only contributor to its row: plain stores;
+        // only runs cut by a chunk boundary (at most two per chunk) need atomics
+        bool whole_start = (i0 == seg0) || (ck[i0 - 1] != cur);
+        if (!whole_start && t.mode == 1) head = lower_bound_key(ck, seg0, i0, cur);
         long long s_hi = 0, s_lo = 0;
-        auto flush = [&](uint32_t key, int64_t head_pos) {
-            const TableMeta& t = m.tab[table_of(m, key)];
+        auto flush = [&](uint32_t key, int64_t head_pos, bool whole) {
             if (e >= t.dim) return;
             int64_t dst;
-            if (t.mode == 0)
-                dst = t.acc_off + static_cast<int64_t>(key & row_mask) * t.dim + e;
+            if (t.mode != 1)
+                dst = t.acc_off + static_cast<int64_t>(key) * t.dim + e;
             else
                 dst = dense_acc_elems + (head_pos - m.sparse_start) * m.dim_max + e;
-            atomicAdd(acc_hi + dst, static_cast<unsigned long long>(s_hi));
-            atomicAdd(acc_lo + dst, static_cast<unsigned long long>(s_lo));
+            if (whole) {
+                acc_hi[dst] = static_cast<unsigned long long>(s_hi);
+                acc_lo[dst] = static_cast<unsigned long long>(s_lo);
+            } else {
+                atomicAdd(acc_hi + dst, static_cast<unsigned long long>(s_hi));
+                atomicAdd(acc_lo + dst, static_cast<unsigned long long>(s_lo));
+            }
         };
 #pragma unroll 4
         for (int64_t i = i0; i < i1; ++i) {
             const uint32_t k = ck[i];
             const uint32_t v = val[i];
             if (k != cur) {
-                flush(cur, head);
+                flush(cur, head, whole_start);
                 cur = k;
                 head = i;
+                whole_start = true;
                 s_hi = 0;
                 s_lo = 0;
             }
             const int slot = static_cast<int>(v >> 24);
             const int64_t b = v & 0xFFFFFFu;
-            if (e < m.slot_dim[slot]) {
+            if (e < t.dim) {
                 long long h, l;
                 to_fixed(dE[b * ld + m.slot_col[slot] + e], h, l, err);
                 s_hi += h;
                 s_lo += l;
             }
         }
-        flush(cur, head);
+        flush(cur, head, whole_start && ((i1 == seg1) || (ck[i1] != cur)));
     }
 }
 
 __global__ __launch_bounds__(RB_THREADS) void finalize_dense_kernel(const BwdMeta m, const long long* __restrict__ acc_hi,
                                                                     const long long* __restrict__ acc_lo) {
     const TableMeta& t = m.tab[blockIdx.y];
-    if (t.mode != 0) return;
+    if (t.mode == 1) return;
     const int64_t n = t.vocab * t.dim;
     for (int64_t j = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x; j < n;
-         j += static_cast<int64_t>(gridDim.x) * RB_THREADS)
-        t.grad_dense[j] = from_fixed(acc_hi[t.acc_off + j], acc_lo[t.acc_off + j]);
+         j += static_cast<int64_t>(gridDim.x) * RB_THREADS) {
+        const float g = from_fixed(acc_hi[t.acc_off + j], acc_lo[t.acc_off + j]);
+        t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;     // mode 2: add to the caller's gradient arena
+    }
 }
 
 __global__ __launch_bounds__(RB_THREADS) void finalize_sparse_kernel(const BwdMeta m, const uint32_t* __restrict__ ck,
@@ -263,20 +407,21 @@ __global__ __launch_bounds__(RB_THREADS) void finalize_sparse_kernel(const BwdMe
     const int64_t i = m.sparse_start + idx / m.dim_max;
     const int e = static_cast<int>(idx % m.dim_max);
     if (i >= m.n) return;
-    const uint32_t key = ck[i];
-    const TableMeta& t = m.tab[table_of(m, key)];
+    int ti = m.n_tables - 1;
+    while (ti > 0 && m.tab[ti].sorted_off > i) --ti;
+    const TableMeta& t = m.tab[ti];
     if (e >= t.dim) return;
-    const bool head = (i == 0) || (ck[i - 1] != key);
+    const uint32_t key = ck[i];
+    const bool head = (i == t.sorted_off) || (ck[i - 1] != key);
     const int64_t local = i - t.sorted_off;
-    const uint32_t row_mask = (m.row_bits >= 32) ? 0xFFFFFFFFu : ((1u << m.row_bits) - 1u);
-    if (e == 0) t.urow[local] = head ? static_cast<int32_t>(key & row_mask) : -1;
+    if (e == 0) t.urow[local] = head ? static_cast<int32_t>(key) : -1;
     const int64_t a = dense_acc_elems + (i - m.sparse_start) * m.dim_max + e;
     t.ugrad[local * t.dim + e] = head ? from_fixed(acc_hi[a], acc_lo[a]) : 0.f;
 }
 
 extern "C" size_t swr_embed_bwd_workspace_bytes(const swr_embed_grad_slot* slots, int n_slots, int64_t B) {
     HostPlan p;
-    if (make_plan(slots, n_slots, B, true, p) != SWR_OK) return 0;
+    if (make_plan(slots, n_slots, B, p) != SWR_OK) return 0;
     return p.total;
 }
 
@@ -286,35 +431,40 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
     SWR_REQUIRE(keys && dE && workspace && ld > 0, SWR_ERR_ARG);
     if (B == 0) return SWR_OK;
     HostPlan p;
-    int rc = make_plan(slots, n_slots, B, true, p);
+    int rc = make_plan(slots, n_slots, B, p);
     if (rc != SWR_OK) return rc;
     SWR_REQUIRE(workspace_bytes >= p.total, SWR_ERR_WORKSPACE);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
-    uint32_t* ck0 = reinterpret_cast<uint32_t*>(ws + p.off_ck0);
-    uint32_t* ck1 = reinterpret_cast<uint32_t*>(ws + p.off_ck1);
-    uint32_t* v0 = reinterpret_cast<uint32_t*>(ws + p.off_v0);
-    uint32_t* v1 = reinterpret_cast<uint32_t*>(ws + p.off_v1);
+    uint32_t* kbuf[2] = {reinterpret_cast<uint32_t*>(ws + p.off_k0), reinterpret_cast<uint32_t*>(ws + p.off_k1)};
+    uint32_t* vbuf[2] = {reinterpret_cast<uint32_t*>(ws + p.off_v0), reinterpret_cast<uint32_t*>(ws + p.off_v1)};
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + p.off_hist);
     unsigned long long* acc_hi = reinterpret_cast<unsigned long long*>(ws + p.off_acc_hi);
     unsigned long long* acc_lo = reinterpret_cast<unsigned long long*>(ws + p.off_acc_lo);
     const BwdMeta& m = p.m;
     const int64_t n = m.n;
 
     hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
-                       st, m, keys, ck0, v0);
-    size_t temp = p.temp_bytes;
-    if (rocprim::radix_sort_pairs(ws + p.off_temp, temp, ck0, ck1, v0, v1, static_cast<size_t>(n), 0u,
-                                  static_cast<unsigned>(p.key_bits), st) != hipSuccess)
-        return SWR_ERR_LAUNCH;
-    // both accumulator limbs are contiguous: one memset
-    if (hipMemsetAsync(acc_hi, 0, (p.off_acc_lo - p.off_acc_hi) * 2, st) != hipSuccess) return SWR_ERR_LAUNCH;
+                       st, m, keys, kbuf[0], vbuf[0]);
+    int cur = 0;
+    for (int pass = 0; pass < p.n_passes; ++pass) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(256), 0, st, p.sm, pass, hist);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], vbuf[cur],
+                           kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
+        cur ^= 1;
+    }
+    const uint32_t* ck = kbuf[cur];
+    const uint32_t* sv = vbuf[cur];
+    // both accumulator limbs are contiguous: one zero-fill (a kernel, not a memset node)
+    rc = swr_zero_async(acc_hi, (p.off_acc_lo - p.off_acc_hi) * 2, st);
+    if (rc != SWR_OK) return rc;
 
     int lpe = 1;
     while (lpe < m.dim_max && lpe < 64) lpe <<= 1;
-    const int64_t groups = swr_ceil_div(n, CHUNK);
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(groups * lpe, RB_THREADS)));
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(p.n_chunks) * lpe, RB_THREADS)));
 #define LAUNCH_REDUCE(L)                                                                                              \
-    hipLaunchKernelGGL(reduce_kernel<L>, grid, dim3(RB_THREADS), 0, st, m, ck1, v1, dE, ld, acc_hi, acc_lo,            \
+    hipLaunchKernelGGL(reduce_kernel<L>, grid, dim3(RB_THREADS), 0, st, m, p.n_chunks, ck, sv, dE, ld, acc_hi, acc_lo,   \
                        p.dense_acc_elems, err_flag)
     switch (lpe) {
         case 1: LAUNCH_REDUCE(1); break;
@@ -329,7 +479,7 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
     if (p.dense_acc_elems > 0) {
         int64_t biggest = 1;
         for (int t = 0; t < m.n_tables; ++t)
-            if (m.tab[t].mode == 0 && m.tab[t].vocab * m.tab[t].dim > biggest) biggest = m.tab[t].vocab * m.tab[t].dim;
+            if (m.tab[t].mode != 1 && m.tab[t].vocab * m.tab[t].dim > biggest) biggest = m.tab[t].vocab * m.tab[t].dim;
         const unsigned gx = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(biggest, RB_THREADS), 1024));
         hipLaunchKernelGGL(finalize_dense_kernel, dim3(gx, static_cast<unsigned>(m.n_tables)), dim3(RB_THREADS), 0, st, m,
                            reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo));
@@ -337,7 +487,7 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
     if (m.sparse_start < n) {
         const int64_t work = (n - m.sparse_start) * m.dim_max;
         hipLaunchKernelGGL(finalize_sparse_kernel, dim3(static_cast<unsigned>(swr_ceil_div(work, RB_THREADS))),
-                           dim3(RB_THREADS), 0, st, m, ck1, reinterpret_cast<const long long*>(acc_hi),
+                           dim3(RB_THREADS), 0, st, m, ck, reinterpret_cast<const long long*>(acc_hi),
                            reinterpret_cast<const long long*>(acc_lo), p.dense_acc_elems);
     }
     return swr_launch_status();

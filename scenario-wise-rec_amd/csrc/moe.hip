@@ -7,78 +7,141 @@
 
 // ------------------------------------------------------------------------------------- gate mixing
 // expert_pooling = sum_j gate_j * expert_j   (mmoe.py:48-49, ple.py:121-126,131-133)
-__global__ __launch_bounds__(EW_THREADS) void mix_fwd_kernel(const swr_mix_desc d, const float* __restrict__ Y, int64_t ldy,
-                                                             float* __restrict__ P, int64_t ldp, int64_t M) {
-    const int width = d.n_out * d.H;
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
-    const int64_t m = idx / width;
-    if (m >= M) return;
-    const int c = static_cast<int>(idx - m * width);
-    const int o = c / d.H, h = c - o * d.H;
-    const float* y = Y + m * ldy;
-    float acc = 0.f;
-    for (int j = 0; j < d.n_sel; ++j)
-        acc = fmaf(y[d.g_col + o * d.g_stride + j], y[d.x_col + d.sel[o][j] * d.H + h], acc);
-    P[m * ldp + c] = acc;
+//
+// One wave per sample row: the row of activated experts + gate probabilities (and, backward, the row of
+// pooled gradients) is staged once in LDS with coalesced loads, every output of the row is then computed
+// from LDS and written with coalesced stores.  HBM traffic = each input row read once, each output row
+// written once.
+#define MIX_WAVES 4
+#define MIX_MAX_EXPERTS 64
+#define MIX_ROW_FLOATS 2560          // LDS floats per wave: Y row + dP row
+
+struct MixK {
+    swr_mix_desc d;
+    int32_t n_expert;
+    int32_t y_lo, y_hi;              // column span of Y that the kernel touches
+    uint8_t inv_cnt[MIX_MAX_EXPERTS];            // backward: (o, j) pairs that select expert e
+    uint8_t inv[MIX_MAX_EXPERTS][SWR_MIX_MAX_OUT];   // packed o * 16 + j
+};
+
+static int make_mix(const swr_mix_desc* desc, MixK& k) {
+    SWR_REQUIRE(desc->n_out > 0 && desc->n_out <= SWR_MIX_MAX_OUT && desc->n_sel > 0 && desc->n_sel <= SWR_MIX_MAX_SEL &&
+                    desc->H > 0 && desc->x_col >= 0 && desc->g_col >= 0 && desc->g_stride >= desc->n_sel, SWR_ERR_ARG);
+    k.d = *desc;
+    k.n_expert = 0;
+    for (int e = 0; e < MIX_MAX_EXPERTS; ++e) k.inv_cnt[e] = 0;
+    for (int o = 0; o < desc->n_out; ++o)
+        for (int j = 0; j < desc->n_sel; ++j) {
+            const int e = desc->sel[o][j];
+            SWR_REQUIRE(e < MIX_MAX_EXPERTS, SWR_ERR_UNSUPPORTED);
+            if (e + 1 > k.n_expert) k.n_expert = e + 1;
+            SWR_REQUIRE(k.inv_cnt[e] < SWR_MIX_MAX_OUT, SWR_ERR_UNSUPPORTED);
+            k.inv[e][k.inv_cnt[e]++] = static_cast<uint8_t>(o * 16 + j);
+        }
+    const int x_hi = desc->x_col + k.n_expert * desc->H;
+    const int g_hi = desc->g_col + (desc->n_out - 1) * desc->g_stride + desc->n_sel;
+    k.y_lo = desc->x_col < desc->g_col ? desc->x_col : desc->g_col;
+    k.y_hi = x_hi > g_hi ? x_hi : g_hi;
+    SWR_REQUIRE((k.y_hi - k.y_lo) + desc->n_out * desc->H <= MIX_ROW_FLOATS, SWR_ERR_UNSUPPORTED);
+    return SWR_OK;
+}
+
+__global__ __launch_bounds__(MIX_WAVES * 64) void mix_fwd_kernel(const MixK k, const float* __restrict__ Y, int64_t ldy,
+                                                                 float* __restrict__ P, int64_t ldp, int64_t M) {
+    __shared__ float lds[MIX_WAVES][MIX_ROW_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* row = lds[wave];
+    const swr_mix_desc& d = k.d;
+    const int wy = k.y_hi - k.y_lo, wp = d.n_out * d.H;
+    for (int64_t m = static_cast<int64_t>(blockIdx.x) * MIX_WAVES + wave; m < M; m += static_cast<int64_t>(gridDim.x) * MIX_WAVES) {
+        const float* y = Y + m * ldy + k.y_lo;
+        for (int c = lane; c < wy; c += 64) row[c] = y[c];
+        __builtin_amdgcn_wave_barrier();
+        const float* x = row + (d.x_col - k.y_lo);
+        const float* g = row + (d.g_col - k.y_lo);
+        for (int c = lane; c < wp; c += 64) {
+            const int o = c / d.H, h = c - o * d.H;
+            float acc = 0.f;
+            for (int j = 0; j < d.n_sel; ++j) acc = fmaf(g[o * d.g_stride + j], x[d.sel[o][j] * d.H + h], acc);
+            P[m * ldp + c] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t ldy, float* P, int64_t ldp, int64_t M,
                                void* stream) {
     SWR_REQUIRE(desc && Y && P && M >= 0, SWR_ERR_ARG);
-    SWR_REQUIRE(desc->n_out > 0 && desc->n_out <= SWR_MIX_MAX_OUT && desc->n_sel > 0 && desc->n_sel <= SWR_MIX_MAX_SEL &&
-                    desc->H > 0, SWR_ERR_ARG);
+    MixK k;
+    const int rc = make_mix(desc, k);
+    if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
-    const int64_t n = M * desc->n_out * desc->H;
-    hipLaunchKernelGGL(mix_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, EW_THREADS))), dim3(EW_THREADS), 0,
-                       static_cast<hipStream_t>(stream), *desc, Y, ldy, P, ldp, M);
+    const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 4096 ? swr_ceil_div(M, MIX_WAVES) : 4096);
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), 0, static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
     return swr_launch_status();
 }
 
 // dX[e, h] = sum over (o, j) with sel[o][j] == e of gate[o][j] * dP[o, h];  dG[o][j] = sum_h dP[o, h] X[sel[o][j], h]
-__global__ __launch_bounds__(EW_THREADS) void mix_bwd_kernel(const swr_mix_desc d, int n_expert, const float* __restrict__ dP,
-                                                             int64_t lddp, const float* __restrict__ Y, int64_t ldy,
-                                                             float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M) {
-    const int wx = n_expert * d.H;            // expert columns
-    const int wg = d.n_out * d.n_sel;         // gate columns
-    const int width = wx + wg;
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
-    const int64_t m = idx / width;
-    if (m >= M) return;
-    const int c = static_cast<int>(idx - m * width);
-    const float* y = Y + m * ldy;
-    const float* dp = dP + m * lddp;
-    float acc = 0.f;
-    int col;
-    if (c < wx) {
-        const int e = c / d.H, h = c - e * d.H;
-        for (int o = 0; o < d.n_out; ++o)
-            for (int j = 0; j < d.n_sel; ++j)
-                if (d.sel[o][j] == e) acc = fmaf(y[d.g_col + o * d.g_stride + j], dp[o * d.H + h], acc);
-        col = d.x_col + c;
-    } else {
-        const int gidx = c - wx;
-        const int o = gidx / d.n_sel, j = gidx - o * d.n_sel;
-        const float* x = y + d.x_col + d.sel[o][j] * d.H;
-        for (int h = 0; h < d.H; ++h) acc = fmaf(dp[o * d.H + h], x[h], acc);
-        col = d.g_col + o * d.g_stride + j;
+__global__ __launch_bounds__(MIX_WAVES * 64) void mix_bwd_kernel(const MixK k, const float* __restrict__ dP, int64_t lddp,
+                                                                 const float* __restrict__ Y, int64_t ldy,
+                                                                 float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M) {
+    __shared__ float lds[MIX_WAVES][MIX_ROW_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* row = lds[wave];
+    const swr_mix_desc& d = k.d;
+    const int wy = k.y_hi - k.y_lo, wp = d.n_out * d.H;
+    float* rdp = row + wy;
+    const int wx = k.n_expert * d.H, ng = d.n_out * d.n_sel;
+    for (int64_t m = static_cast<int64_t>(blockIdx.x) * MIX_WAVES + wave; m < M; m += static_cast<int64_t>(gridDim.x) * MIX_WAVES) {
+        const float* y = Y + m * ldy + k.y_lo;
+        const float* dp = dP + m * lddp;
+        for (int c = lane; c < wy; c += 64) row[c] = y[c];
+        for (int c = lane; c < wp; c += 64) rdp[c] = dp[c];
+        __builtin_amdgcn_wave_barrier();
+        const float* x = row + (d.x_col - k.y_lo);
+        const float* g = row + (d.g_col - k.y_lo);
+        float* out = dY + m * lddy;
+        for (int c = lane; c < wx; c += 64) {
+            const int e = c / d.H, h = c - e * d.H;
+            float acc = 0.f;
+            for (int q = 0; q < k.inv_cnt[e]; ++q) {
+                const int o = k.inv[e][q] >> 4, j = k.inv[e][q] & 15;
+                acc = fmaf(g[o * d.g_stride + j], rdp[o * d.H + h], acc);
+            }
+            float* dst = out + d.x_col + c;
+            *dst = accumulate ? *dst + acc : acc;
+        }
+        // gate gradients: 4 lanes share one (o, j) dot product over h
+        for (int q0 = 0; q0 < ng; q0 += 16) {
+            const int q = q0 + (lane >> 2), part = lane & 3;
+            float acc = 0.f;
+            if (q < ng) {
+                const int o = q / d.n_sel, j = q - o * d.n_sel;
+                const float* xe = x + d.sel[o][j] * d.H;
+                for (int h = part; h < d.H; h += 4) acc = fmaf(rdp[o * d.H + h], xe[h], acc);
+            }
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (q < ng && part == 0) {
+                const int o = q / d.n_sel, j = q - o * d.n_sel;
+                float* dst = out + d.g_col + o * d.g_stride + j;
+                *dst = accumulate ? *dst + acc : acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    float* dst = dY + m * lddy + col;
-    *dst = accumulate ? *dst + acc : acc;
 }
 
 extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_t lddp, const float* Y, int64_t ldy,
                                float* dY, int64_t lddy, int accumulate, int64_t M, void* stream) {
     SWR_REQUIRE(desc && dP && Y && dY && M >= 0, SWR_ERR_ARG);
-    SWR_REQUIRE(desc->n_out > 0 && desc->n_out <= SWR_MIX_MAX_OUT && desc->n_sel > 0 && desc->n_sel <= SWR_MIX_MAX_SEL &&
-                    desc->H > 0, SWR_ERR_ARG);
+    MixK k;
+    const int rc = make_mix(desc, k);
+    if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
-    int n_expert = 0;
-    for (int o = 0; o < desc->n_out; ++o)
-        for (int j = 0; j < desc->n_sel; ++j)
-            if (desc->sel[o][j] + 1 > n_expert) n_expert = desc->sel[o][j] + 1;
-    const int64_t n = M * (static_cast<int64_t>(n_expert) * desc->H + desc->n_out * desc->n_sel);
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, EW_THREADS))), dim3(EW_THREADS), 0,
-                       static_cast<hipStream_t>(stream), *desc, n_expert, dP, lddp, Y, ldy, dY, lddy, accumulate, M);
+    const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 4096 ? swr_ceil_div(M, MIX_WAVES) : 4096);
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), 0, static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy,
+                       dY, lddy, accumulate, M);
     return swr_launch_status();
 }
 
@@ -276,6 +339,24 @@ extern "C" int swr_colsum(const float* X, int64_t ldx, int64_t M, int N, float* 
 }
 
 // ------------------------------------------------------------------------------------------- misc
+__global__ void swr_zero_kernel(uint4* p, size_t n16, unsigned char* tail, size_t ntail) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+int swr_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return SWR_OK;
+    if (!swr_aligned16(p)) return SWR_ERR_ALIGN;
+    const size_t n16 = bytes / 16, ntail = bytes % 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(swr_zero_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<uint4*>(p), n16,
+                       static_cast<unsigned char*>(p) + n16 * 16, ntail);
+    return swr_launch_status();
+}
+
 extern "C" int swr_abi_version(void) { return SWR_ABI_VERSION; }
 
 extern "C" const char* swr_status_str(int status) {

@@ -89,6 +89,9 @@ class SwrModule(nn.Module):
     def _install_touch_hooks(self, params):
         """Record which parameters took a gradient in the last backward: Adam must skip the others
         entirely (torch leaves their `.grad` None: PPNet's agn tables, ppnet.py:54)."""
+        import os
+        if os.environ.get("SWR_NO_TOUCH_HOOKS"):
+            return
         for p in params:
             if p.requires_grad and not hasattr(p, "_swr_hooked"):
                 p._swr_hooked = True
@@ -113,7 +116,8 @@ class SwrModule(nn.Module):
             if p.requires_grad:
                 if p.grad is None or p.grad.data_ptr() != a["g"].data_ptr() + 4 * off:
                     p.grad = a["g"][off:off + n].view(p.shape)
-                p._swr_touched = False
+                if hasattr(p, "_swr_hooked"):
+                    p._swr_touched = False
         for p in a["big"]:
             p.grad = None
             p._swr_sparse_grad = None

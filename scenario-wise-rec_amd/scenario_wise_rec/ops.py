@@ -15,6 +15,10 @@ from . import _hip as H
 from ._hip import lib
 
 
+import os
+DIRECT_GRADS = int(os.environ.get("SWR_DIRECT_GRADS", "7"))      # A/B bitmask (bench only): 1 W/b, 2 BN, 4 tables
+
+
 # =========================================================================== raw launchers
 def _ld(t):
     return t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else (t.shape[-1] if t.dim() == 2 else 0)
@@ -89,6 +93,41 @@ def _cat_params(tensors):
             acc *= n
         return t0.as_strided(shape, tuple(reversed(strides)))
     return torch.cat([t.detach().reshape((-1,) + tail) for t in tensors])
+
+
+def _grad_alias(params, kind=1):
+    """The `.grad` tensors of `params` as ONE tensor when they sit back to back in the gradient arena
+    (basic/module.py), else None.  Backward kernels then accumulate straight into the arena instead of
+    returning per-parameter gradients for autograd to add one tiny launch at a time."""
+    if not (DIRECT_GRADS & kind):
+        return None
+    gs = []
+    for p in params:
+        g = getattr(p, "grad", None)
+        if g is None or not p.is_leaf or not p.requires_grad or g.dtype != torch.float32:
+            return None
+        gs.append(g)
+    if len(gs) == 1:
+        return gs[0] if gs[0].is_contiguous() else None
+    t0 = gs[0]
+    tail = tuple(t0.shape[1:])
+    ptr, store = t0.data_ptr(), t0.untyped_storage().data_ptr()
+    for g in gs:
+        if not g.is_contiguous() or g.data_ptr() != ptr or tuple(g.shape[1:]) != tail or g.untyped_storage().data_ptr() != store:
+            return None
+        ptr += g.numel() * 4
+    rows = sum(g.shape[0] if g.dim() > 0 else 1 for g in gs)
+    shape = (rows,) + tail
+    strides, acc = [], 1
+    for n in reversed(shape):
+        strides.append(acc)
+        acc *= n
+    return t0.as_strided(shape, tuple(reversed(strides)))
+
+
+def _mark_touched(params):
+    for p in params:
+        p._swr_touched = True
 
 
 def _split_like(flat, tensors):
@@ -167,18 +206,29 @@ class EmbedGather(Function):
                 slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 1, None, urow.data_ptr(), ugrad.data_ptr())
             else:
                 if grads[wpos] is None:
-                    grads[wpos] = torch.empty_like(w, memory_format=torch.contiguous_format)
-                slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 0, grads[wpos].data_ptr(), None, None)
+                    direct = _grad_alias([w], 4)
+                    if direct is not None:
+                        grads[wpos] = ("direct", direct)
+                    else:
+                        grads[wpos] = torch.empty_like(w, memory_format=torch.contiguous_format)
+                if isinstance(grads[wpos], tuple):          # accumulate into the gradient arena (mode 2)
+                    slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 2, grads[wpos][1].data_ptr(), None, None)
+                else:
+                    slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 0, grads[wpos].data_ptr(), None, None)
         ns = len(live)
         nbytes = lib.swr_embed_bwd_workspace_bytes(slots, ns, B)
         if nbytes == 0:
-            raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 48 slots or key width above 32 bits)")
+            raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 40 lookup slots)")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         H.check(lib.swr_embed_bwd(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
                                   H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd")
         for wpos, (urow, ugrad) in sparse_out.items():
             # row-sparse gradient of a large table: consumed by FusedAdam (optim.py); `.grad` stays None
             weights[wpos]._swr_sparse_grad = (urow, ugrad)
+        for i, g in enumerate(grads):
+            if isinstance(g, tuple):
+                weights[i]._swr_touched = True
+                grads[i] = None
         return (None,) + tuple(grads)
 
 
@@ -268,7 +318,14 @@ class LinearBNAct(Function):
         dev = x.device
         dY = H.f32c(dY)
         acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
+        nw = cfg["n_w"]
+        p_W = ctx.params[:nw]
+        p_b = ctx.params[nw:2 * nw] if cfg["has_bias"] else ()
+        off = nw * (2 if cfg["has_bias"] else 1)
+        p_g = ctx.params[off:off + cfg["n_bn"]] if cfg["bn"] is not None else ()
+        p_be = ctx.params[off + cfg["n_bn"]:off + 2 * cfg["n_bn"]] if cfg["bn"] is not None else ()
         dgamma = dbeta = None
+        direct_bn = False
         dZ = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
         if ctx.training_bn:
             nt = (M + 63) // 64
@@ -276,11 +333,14 @@ class LinearBNAct(Function):
             H.check(lib.swr_bn_act_bwd_stats(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(mean),
                                              H.ptr(rstd), acts, n_acts, H.ptr(partials), M, Ntot, H.stream()),
                     "swr_bn_act_bwd_stats")
-            dgamma = torch.empty(Ntot, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(Ntot, dtype=torch.float32, device=dev)
+            dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_be, 2)
+            direct_bn = dgamma is not None and dbeta is not None
+            if not direct_bn:
+                dgamma = torch.empty(Ntot, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(Ntot, dtype=torch.float32, device=dev)
             ca, cb, cc = (torch.empty(Ntot, dtype=torch.float32, device=dev) for _ in range(3))
             H.check(lib.swr_bn_bwd_finalize(H.ptr(partials), nt, M, Ntot, H.ptr(gamma), H.ptr(rstd), H.ptr(dgamma),
-                                            H.ptr(dbeta), 0, H.ptr(ca), H.ptr(cb), H.ptr(cc), H.stream()),
+                                            H.ptr(dbeta), int(direct_bn), H.ptr(ca), H.ptr(cb), H.ptr(cc), H.stream()),
                     "swr_bn_bwd_finalize")
             H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(ca), H.ptr(cb),
                                           H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
@@ -294,10 +354,16 @@ class LinearBNAct(Function):
                 H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(scale), None,
                                               None, None, acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
                         "swr_act_bwd_apply")
-        # parameter gradients: dW[g] = dZ_g^T x_g (+ db = column sums), dX = dZ W
-        dW = torch.empty((Ntot, K), dtype=torch.float32, device=dev)
-        db = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
-        gemm_tn(dZ, x, dW, M, N, K, colsum=db, groups=G, gsA=N, gsB=(K if G > 1 else 0), gsC=N * K, gsColsum=N)
+        # parameter gradients: dW[g] = dZ_g^T x_g (+ db = column sums), dX = dZ W.  When the layer's parameters sit
+        # in the arena the kernels accumulate into the gradient arena directly (it was zeroed by zero_grad).
+        dW = _grad_alias(p_W)
+        db = _grad_alias(p_b) if cfg["has_bias"] else None
+        direct_w = dW is not None and (db is not None or not cfg["has_bias"])
+        if not direct_w:
+            dW = torch.empty((Ntot, K), dtype=torch.float32, device=dev)
+            db = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
+        gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
+                gsC=N * K, gsColsum=N, ldc=K)
         dx = None
         if ctx.needs_input_grad[1]:
             if G > 1:
@@ -308,15 +374,19 @@ class LinearBNAct(Function):
                 gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:
                     dx = dx[:, :K]
-        nw = cfg["n_w"]
-        grads = list(_split_like(dW, ctx.params[:nw]))
-        if cfg["has_bias"]:
-            grads += _split_like(db, ctx.params[nw:2 * nw])
+        if direct_w:
+            _mark_touched(p_W + tuple(p_b))
+            grads = [None] * (nw * (2 if cfg["has_bias"] else 1))
+        else:
+            grads = list(_split_like(dW, p_W))
+            if cfg["has_bias"]:
+                grads += _split_like(db, p_b)
         if cfg["bn"] is not None:
-            off = nw * (2 if cfg["has_bias"] else 1)
-            gam = ctx.params[off:off + cfg["n_bn"]]
-            if dgamma is not None:
-                grads += _split_like(dgamma, gam) + _split_like(dbeta, gam)
+            if direct_bn:
+                _mark_touched(tuple(p_g) + tuple(p_be))
+                grads += [None] * (2 * cfg["n_bn"])
+            elif dgamma is not None:
+                grads += _split_like(dgamma, p_g) + _split_like(dbeta, p_g)
             else:
                 grads += [None] * (2 * cfg["n_bn"])
         return (None, dx) + tuple(grads)

@@ -11,6 +11,8 @@ optimizer, `trainers/ctr_trainer.py:50-52,73`) as HBM-streaming HIP kernels.
   * step count and bias corrections live in device memory (a captured hipGraph replays correctly).
 """
 import ctypes as C
+import os
+import sys
 
 import torch
 
@@ -97,6 +99,10 @@ class FusedAdam(torch.optim.Optimizer):
                         r[6].append(it[6])
                         continue
                 runs.append([it[0], it[1], it[2], it[3], it[4], it[5], [it[6]]])
+            if os.environ.get("SWR_DEBUG_ADAM"):
+                print(f"[adam] dense params {len(dense)} runs {[(r[4]) for r in runs]} sparse {len(sparse)} "
+                      f"untouched {sum(1 for p in group['params'] if p.grad is not None and not getattr(p, '_swr_touched', True))}",
+                      file=sys.stderr, flush=True)
             for p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep in runs:
                 H.check(lib.swr_adam_dense(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
                                            n, H.ptr(hyper), stream), "swr_adam_dense")

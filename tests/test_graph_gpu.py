@@ -1,0 +1,45 @@
+"""hipGraph capture of the whole training step (what bench.py times) must replay to exactly the state the
+eager launches reach: same kernels, same order, same buffers -> bitwise identical parameters."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import Case, build_product_model, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(case, n_steps, use_graph, limit=None):
+    from scenario_wise_rec.basic.module import SwrModule
+    from scenario_wise_rec.trainers import CTRTrainer
+    old = SwrModule.dense_table_limit_bytes
+    if limit is not None:
+        SwrModule.dense_table_limit_bytes = limit
+    try:
+        model = build_product_model(case)
+        tr = CTRTrainer(model, "g", optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device="cuda")
+        model.train()
+        x, y = case.batch(0)
+        xd, yd = to_device(x), torch.from_numpy(y).cuda()
+        done = 0
+        if use_graph:
+            from scenario_wise_rec.trainers.graph import GraphedStep
+            g = GraphedStep(tr, xd, yd, warmup=2)
+            for _ in range(n_steps - 2):
+                g.replay()
+        else:
+            for _ in range(n_steps):
+                tr.train_step(xd, yd)
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    finally:
+        SwrModule.dense_table_limit_bytes = old
+
+
+@pytest.mark.parametrize("name,limit", [("mmoe", None), ("mmoe", 2048), ("ple", None), ("ppnet", None), ("star", None)])
+def test_graph_replay_matches_eager(name, limit):
+    c = Case(name)
+    a = _run(c, 6, use_graph=False, limit=limit)
+    b = _run(c, 6, use_graph=True, limit=limit)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{k}: max diff {np.abs(a[k].astype(np.float64) - b[k]).max()}"
