@@ -83,41 +83,93 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_kernel(const GemmK kk)
         brow[t] = BT ? Bg + static_cast<int64_t>(min(n, N - 1)) * a.ldb : Bg + min(n, N - 1);
     }
 
-    for (int kb = 0; kb < K; kb += 8) {
-        const int k = kb + 4 * s;
-        float4 av = load_k4<VEC>(arow, k, K);
-        if (PRO) {
-            // previous layer's BatchNorm (+ReLU) applied while the operand is loaded
-            const float4 sc = load_k4<VEC>(psc, k, K), sh = load_k4<VEC>(psh, k, K);
-            av.x = fmaf(av.x, sc.x, sh.x); av.y = fmaf(av.y, sc.y, sh.y);
-            av.z = fmaf(av.z, sc.z, sh.z); av.w = fmaf(av.w, sc.w, sh.w);
-            if (a.a_relu) {
-                av.x = fmaxf(av.x, 0.f); av.y = fmaxf(av.y, 0.f); av.z = fmaxf(av.z, 0.f); av.w = fmaxf(av.w, 0.f);
-            }
-            if (k >= K) av.x = 0.f;
-            if (k + 1 >= K) av.y = 0.f;
-            if (k + 2 >= K) av.z = 0.f;
-            if (k + 3 >= K) av.w = 0.f;
+    // Software pipeline: the operands of k-group g+1 are in flight while the 4*NT MFMAs of group g issue
+    // (one MFMA = 64 cycles on its SIMD; an L2 round trip is several hundred).  hipcc keeps the loads of the
+    // next group outstanding behind counted s_waitcnt vmcnt(N).
+    struct Frag {
+        float4 a;
+        float4 b[NT];
+    };
+    // main loop: no predicates at all.  Rows beyond M and columns beyond N are clamped to valid addresses and
+    // produce values that are never stored; only the last partial k-group needs predicated loads.
+    auto load4 = [&](const float* __restrict__ p) -> float4 {
+        if (VEC) return *reinterpret_cast<const float4*>(p);
+        return make_float4(p[0], p[1], p[2], p[3]);
+    };
+    auto prologue = [&](float4& v, int k, bool tail) {
+        if (!PRO) return;
+        // previous layer's BatchNorm (+ReLU) applied while the operand is loaded
+        const float4 sc = tail ? load_k4<false>(psc, k, K) : load4(psc + k);
+        const float4 sh = tail ? load_k4<false>(psh, k, K) : load4(psh + k);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        if (a.a_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        float4 bv[NT];
+        if (tail) {
+            if (k >= K) v.x = 0.f;
+            if (k + 1 >= K) v.y = 0.f;
+            if (k + 2 >= K) v.z = 0.f;
+            if (k + 3 >= K) v.w = 0.f;
+        }
+    };
+    auto load_frag = [&](int kb, Frag& f) {              // full group: kb + 8 <= K
+        const int k = kb + 4 * s;
+        f.a = load4(arow + k);
+        prologue(f.a, k, false);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (BT) {
-                bv[t] = load_k4<VEC>(brow[t], k, K);
-                if (!bvalid[t]) bv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                f.b[t] = load4(brow[t] + k);
             } else {
                 const float* p = brow[t] + static_cast<int64_t>(k) * a.ldb;
-                bv[t].x = (bvalid[t] && k < K) ? p[0] : 0.f;
-                bv[t].y = (bvalid[t] && k + 1 < K) ? p[a.ldb] : 0.f;
-                bv[t].z = (bvalid[t] && k + 2 < K) ? p[2 * a.ldb] : 0.f;
-                bv[t].w = (bvalid[t] && k + 3 < K) ? p[3 * a.ldb] : 0.f;
+                f.b[t] = make_float4(p[0], p[a.ldb], p[2 * a.ldb], p[3 * a.ldb]);
             }
         }
+    };
+    auto load_frag_tail = [&](int kb, Frag& f) {         // last, partial group: zero beyond K
+        const int k = kb + 4 * s;
+        f.a = load_k4<false>(arow, k, K);
+        prologue(f.a, k, true);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (BT) {
+                f.b[t] = load_k4<false>(brow[t], k, K);
+            } else {
+                const float* p = brow[t] + static_cast<int64_t>(k) * a.ldb;
+                f.b[t].x = k < K ? p[0] : 0.f;
+                f.b[t].y = k + 1 < K ? p[a.ldb] : 0.f;
+                f.b[t].z = k + 2 < K ? p[2 * a.ldb] : 0.f;
+                f.b[t].w = k + 3 < K ? p[3 * a.ldb] : 0.f;
+            }
+        }
+    };
+    auto mma_frag = [&](const Frag& f) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(av, c), comp(bv[t], c), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(f.a, c), comp(f.b[t], c), acc[t], 0, 0, 0);
+    };
+    const int k_full = (K / 8) * 8;
+    Frag f0, f1;
+    int kb = 0;
+    if (k_full > 0) {
+        load_frag(0, f0);
+        for (; kb + 16 <= k_full; kb += 16) {
+            load_frag(kb + 8, f1);
+            mma_frag(f0);
+            if (kb + 16 < k_full) load_frag(kb + 16, f0);
+            mma_frag(f1);
+        }
+        if (kb < k_full) {               // one full group left (it is already loaded in f0)
+            mma_frag(f0);
+            kb += 8;
+        }
+    }
+    if (kb < K) {
+        load_frag_tail(kb, f1);
+        mma_frag(f1);
     }
 
     // epilogue: lane (i, s) holds column n0 + 32t + i, rows m0 + (r & 3) + 8 (r >> 2) + 4 s
@@ -222,15 +274,19 @@ struct TnK {
 
 template <int TA>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const TnK kk) {
+    // the 4 waves of a workgroup take 4 consecutive row slices of the SAME output tile and are summed in LDS in a
+    // fixed tree ((w0 + w1) + (w2 + w3)) before one partial tile per workgroup goes to the workspace
+    extern __shared__ __attribute__((aligned(16))) float red[];
     const swr_gemm_tn_args& a = kk.a;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, s = lane >> 5;
-    const int split = (blockIdx.z % ((kk.splits + GEMM_WAVES - 1) / GEMM_WAVES)) * GEMM_WAVES + wave;
-    const int g = blockIdx.z / ((kk.splits + GEMM_WAVES - 1) / GEMM_WAVES);
-    if (split >= kk.splits) return;
+    const int zsplit = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
+    const int part = blockIdx.z % zsplit;
+    const int g = blockIdx.z / zsplit;
+    const int split = part * GEMM_WAVES + wave;
     const int p0 = blockIdx.y * (32 * TA);
     const int q0 = blockIdx.x * (32 * TN_TB);
-    const int64_t ms = split * kk.rows_per_split;
+    const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
     const int64_t me = min(ms + kk.rows_per_split, a.M);
 
     const float* __restrict__ Ag = a.A + g * a.gsA;
@@ -253,31 +309,81 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const TnK kk) {
 #pragma unroll
     for (int t = 0; t < TA; ++t) cs[t] = 0.f;
 
-#pragma unroll 2
-    for (int64_t mb = ms; mb < me; mb += 2) {
+    struct Frag {
+        float a[TA];
+        float b[TN_TB];
+    };
+    // main loop without predicates: columns beyond K1 / K2 are clamped (their products are never stored)
+    auto load_frag = [&](int64_t mb, Frag& f) {               // rows mb, mb + 1 both valid
         const int64_t m = mb + s;
-        const bool okm = m < me;
-        const int64_t mc = okm ? m : me - 1;
-        float av[TA], bv[TN_TB];
 #pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            av[t] = Ag[mc * a.lda + ca[t]];
-            if (!(okm && pa[t])) av[t] = 0.f;
-            cs[t] += av[t];
-        }
+        for (int t = 0; t < TA; ++t) f.a[t] = Ag[m * a.lda + ca[t]];
 #pragma unroll
-        for (int t = 0; t < TN_TB; ++t) {
-            bv[t] = Bg[mc * a.ldb + cb[t]];
-            if (!(okm && pb[t])) bv[t] = 0.f;
-        }
+        for (int t = 0; t < TN_TB; ++t) f.b[t] = Bg[m * a.ldb + cb[t]];
+    };
+    auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int t = 0; t < TA; ++t) cs[t] += f.a[t];
 #pragma unroll
         for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
             for (int tb = 0; tb < TN_TB; ++tb)
-                acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta][tb], 0, 0, 0);
+                acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[ta], f.b[tb], acc[ta][tb], 0, 0, 0);
+    };
+    const int64_t me2 = ms + ((me - ms) / 2) * 2;              // rows taken in pairs
+    if (ms < me2) {
+        Frag f0, f1;
+        load_frag(ms, f0);
+        int64_t mb = ms;
+        for (; mb + 4 <= me2; mb += 4) {
+            load_frag(mb + 2, f1);
+            mma_frag(f0);
+            if (mb + 4 < me2) load_frag(mb + 4, f0);
+            mma_frag(f1);
+        }
+        if (mb < me2) mma_frag(f0);
+    }
+    if (me2 < me) {                                            // odd last row: slot 1 contributes zeros
+        Frag f;
+#pragma unroll
+        for (int t = 0; t < TA; ++t) f.a[t] = s == 0 ? Ag[me2 * a.lda + ca[t]] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TN_TB; ++t) f.b[t] = s == 0 ? Bg[me2 * a.ldb + cb[t]] : 0.f;
+        mma_frag(f);
     }
 
-    float* __restrict__ P = kk.part + (static_cast<int64_t>(g) * kk.splits + split) * a.K1 * a.K2;
+    // ---- workgroup reduction through LDS: [TA*TN_TB*16][64] floats + column sums
+    constexpr int PER_WAVE = TA * TN_TB * 16 * 64;
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TN_TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((ta * TN_TB + tb) * 16 + r) * 64 + lane] = acc[ta][tb][r];
+    };
+    auto take = [&](const float* src) {
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TN_TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ta][tb][r] += src[((ta * TN_TB + tb) * 16 + r) * 64 + lane];
+    };
+    float* csr = red + PER_WAVE;         // [4][TA][64] column-sum partials
+#pragma unroll
+    for (int t = 0; t < TA; ++t) csr[(wave * TA + t) * 64 + lane] = cs[t];
+    // one 40 KB staging buffer, three rounds: ((w0 + w1) + w2) + w3 -- keeps 3 workgroups resident per CU
+#pragma unroll
+    for (int w = 1; w < GEMM_WAVES; ++w) {
+        if (wave == w) put(red);
+        __syncthreads();
+        if (wave == 0) take(red);
+        __syncthreads();
+    }
+    if (wave != 0) return;
+
+    float* __restrict__ P = kk.part + (static_cast<int64_t>(g) * zsplit + part) * a.K1 * a.K2;
 #pragma unroll
     for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
@@ -292,9 +398,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const TnK kk) {
     if (kk.part_cs && blockIdx.x == 0) {
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
-            const float tot = cs[t] + __shfl_xor(cs[t], 32);
+            float tot = ((csr[(0 * TA + t) * 64 + lane] + csr[(1 * TA + t) * 64 + lane]) +
+                         csr[(2 * TA + t) * 64 + lane]) + csr[(3 * TA + t) * 64 + lane];
+            tot += __shfl_xor(tot, 32);
             const int p = p0 + 32 * t + i;
-            if (s == 0 && p < a.K1) kk.part_cs[(static_cast<int64_t>(g) * kk.splits + split) * a.K1 + p] = tot;
+            if (s == 0 && p < a.K1) kk.part_cs[(static_cast<int64_t>(g) * zsplit + part) * a.K1 + p] = tot;
         }
     }
 }
@@ -304,18 +412,19 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
     const int g = blockIdx.y;
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int nparts = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
     if (j < n) {
-        const float* p = kk.part + static_cast<int64_t>(g) * kk.splits * n + j;
+        const float* p = kk.part + static_cast<int64_t>(g) * nparts * n + j;
         float sum = 0.f;
-        for (int sp = 0; sp < kk.splits; ++sp) sum += p[sp * n];
+        for (int sp = 0; sp < nparts; ++sp) sum += p[sp * n];
         const int64_t r = j / a.K2, c = j - r * a.K2;
         float* dst = a.C + g * a.gsC + r * a.ldc + c;
         *dst = a.accumulate ? *dst + sum : sum;
     }
     if (kk.part_cs && j < a.K1) {
-        const float* p = kk.part_cs + static_cast<int64_t>(g) * kk.splits * a.K1 + j;
+        const float* p = kk.part_cs + static_cast<int64_t>(g) * nparts * a.K1 + j;
         float sum = 0.f;
-        for (int sp = 0; sp < kk.splits; ++sp) sum += p[sp * a.K1];
+        for (int sp = 0; sp < nparts; ++sp) sum += p[sp * a.K1];
         float* dst = a.colsum + g * a.gsColsum + j;
         *dst = a.accumulate ? *dst + sum : sum;
     }
@@ -372,13 +481,15 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
     const int zsplit = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.K2, 32 * TN_TB)), static_cast<unsigned>(pblk),
                     static_cast<unsigned>(zsplit * a.groups));
+#define TN_LDS(TAV) static_cast<unsigned>(((TAV) * TN_TB * 16 * 64 + 4 * (TAV) * 64) * sizeof(float))
     switch (ta) {
-        case 1: hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(GEMM_THREADS), 0, st, kk); break;
-        case 2: hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, dim3(GEMM_THREADS), 0, st, kk); break;
-        case 3: hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, dim3(GEMM_THREADS), 0, st, kk); break;
-        case 4: hipLaunchKernelGGL(gemm_tn_kernel<4>, grid, dim3(GEMM_THREADS), 0, st, kk); break;
-        default: hipLaunchKernelGGL(gemm_tn_kernel<5>, grid, dim3(GEMM_THREADS), 0, st, kk); break;
+        case 1: hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(GEMM_THREADS), TN_LDS(1), st, kk); break;
+        case 2: hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, dim3(GEMM_THREADS), TN_LDS(2), st, kk); break;
+        case 3: hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, dim3(GEMM_THREADS), TN_LDS(3), st, kk); break;
+        case 4: hipLaunchKernelGGL(gemm_tn_kernel<4>, grid, dim3(GEMM_THREADS), TN_LDS(4), st, kk); break;
+        default: hipLaunchKernelGGL(gemm_tn_kernel<5>, grid, dim3(GEMM_THREADS), TN_LDS(5), st, kk); break;
     }
+#undef TN_LDS
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, 256)), static_cast<unsigned>(a.groups)),
                        dim3(256), 0, st, kk);
