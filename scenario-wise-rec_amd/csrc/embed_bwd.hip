@@ -337,13 +337,19 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
     const int64_t i0 = seg0 + (gid - m.chunk_off[ti]) * CHUNK;
     const int64_t i1 = min(i0 + CHUNK, seg1);
 
+    // entries are taken in batches of BATCH: the BATCH key / payload loads, then the BATCH gradient loads are
+    // independent and in flight together; only then does the run logic walk them (no per-entry load chain)
+    constexpr int BATCH = 8;
+    const int cnt = static_cast<int>(i1 - i0);
+    const uint32_t prev_key = (i0 > seg0) ? ck[i0 - 1] : 0u;
+    const uint32_t next_key = (i1 < seg1) ? ck[i1] : 0u;
     for (int c0 = 0; c0 < t.dim; c0 += LPE) {
         const int e = c0 + e0;
         uint32_t cur = ck[i0];
         int64_t head = i0;
         // a run that starts and ends inside this chunk is the only contributor to its row: plain stores;
         // only runs cut by a chunk boundary (at most two per chunk) need atomics
-        bool whole_start = (i0 == seg0) || (ck[i0 - 1] != cur);
+        bool whole_start = (i0 == seg0) || (prev_key != cur);
         if (!whole_start && t.mode == 1) head = lower_bound_key(ck, seg0, i0, cur);
         long long s_hi = 0, s_lo = 0;
         auto flush = [&](uint32_t key, int64_t head_pos, bool whole) {
@@ -361,28 +367,40 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
                 atomicAdd(acc_lo + dst, static_cast<unsigned long long>(s_lo));
             }
         };
-#pragma unroll 4
-        for (int64_t i = i0; i < i1; ++i) {
-            const uint32_t k = ck[i];
-            const uint32_t v = val[i];
-            if (k != cur) {
-                flush(cur, head, whole_start);
-                cur = k;
-                head = i;
-                whole_start = true;
-                s_hi = 0;
-                s_lo = 0;
+        for (int j0 = 0; j0 < cnt; j0 += BATCH) {
+            uint32_t ks[BATCH], vs[BATCH];
+            float x[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int64_t i = i0 + min(j0 + j, cnt - 1);
+                ks[j] = ck[i];
+                vs[j] = val[i];
             }
-            const int slot = static_cast<int>(v >> 24);
-            const int64_t b = v & 0xFFFFFFu;
-            if (e < t.dim) {
-                long long h, l;
-                to_fixed(dE[b * ld + m.slot_col[slot] + e], h, l, err);
-                s_hi += h;
-                s_lo += l;
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int slot = static_cast<int>(vs[j] >> 24);
+                const int64_t b = vs[j] & 0xFFFFFFu;
+                x[j] = e < t.dim ? dE[b * ld + m.slot_col[slot] + e] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (j0 + j < cnt) {
+                    if (ks[j] != cur) {
+                        flush(cur, head, whole_start);
+                        cur = ks[j];
+                        head = i0 + j0 + j;
+                        whole_start = true;
+                        s_hi = 0;
+                        s_lo = 0;
+                    }
+                    long long h, l;
+                    to_fixed(x[j], h, l, err);
+                    s_hi += h;
+                    s_lo += l;
+                }
             }
         }
-        flush(cur, head, whole_start && ((i1 == seg1) || (ck[i1] != cur)));
+        flush(cur, head, whole_start && ((i1 == seg1) || (next_key != cur)));
     }
 }
 

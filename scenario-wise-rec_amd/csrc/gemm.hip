@@ -151,25 +151,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_kernel(const GemmK kk)
             for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(f.a, c), comp(f.b[t], c), acc[t], 0, 0, 0);
     };
-    const int k_full = (K / 8) * 8;
-    Frag f0, f1;
-    int kb = 0;
-    if (k_full > 0) {
-        load_frag(0, f0);
-        for (; kb + 16 <= k_full; kb += 16) {
-            load_frag(kb + 8, f1);
-            mma_frag(f0);
-            if (kb + 16 < k_full) load_frag(kb + 16, f0);
-            mma_frag(f1);
-        }
-        if (kb < k_full) {               // one full group left (it is already loaded in f0)
-            mma_frag(f0);
-            kb += 8;
+    // ring of ROWS_DEPTH register sets: the operands of the next ROWS_DEPTH-1 k-groups are in flight while one group's
+    // MFMAs issue (A streams from HBM: one group of MFMAs is shorter than an HBM round trip)
+    constexpr int DEPTH = 3;
+    const int n_full = K / 8;
+    Frag f[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+        if (d < n_full) load_frag(8 * d, f[d]);
+    int gi = 0;
+    for (; gi + DEPTH <= n_full; gi += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int nxt = gi + d + DEPTH - 1;
+            if (nxt < n_full) load_frag(8 * nxt, f[(d + DEPTH - 1) % DEPTH]);
+            mma_frag(f[d]);
         }
     }
-    if (kb < K) {
-        load_frag_tail(kb, f1);
-        mma_frag(f1);
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)          // the last (n_full % DEPTH) groups are already loaded
+        if (gi + d < n_full) mma_frag(f[d]);
+    if (n_full * 8 < K) {
+        Frag ft;
+        load_frag_tail(n_full * 8, ft);
+        mma_frag(ft);
     }
 
     // epilogue: lane (i, s) holds column n0 + 32t + i, rows m0 + (r & 3) + 8 (r >> 2) + 4 s
@@ -331,17 +336,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const TnK kk) {
                 acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[ta], f.b[tb], acc[ta][tb], 0, 0, 0);
     };
     const int64_t me2 = ms + ((me - ms) / 2) * 2;              // rows taken in pairs
-    if (ms < me2) {
-        Frag f0, f1;
-        load_frag(ms, f0);
-        int64_t mb = ms;
-        for (; mb + 4 <= me2; mb += 4) {
-            load_frag(mb + 2, f1);
-            mma_frag(f0);
-            if (mb + 4 < me2) load_frag(mb + 4, f0);
-            mma_frag(f1);
+    {
+        // ring of TN_DEPTH register sets (7 dwords each): the next TN_DEPTH-1 row pairs are in flight
+        constexpr int DEPTH = 4;
+        const int64_t n_pairs = (me2 - ms) / 2;
+        Frag f[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d)
+            if (d < n_pairs) load_frag(ms + 2 * d, f[d]);
+        int64_t pi = 0;
+        for (; pi + DEPTH <= n_pairs; pi += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int64_t nxt = pi + d + DEPTH - 1;
+                if (nxt < n_pairs) load_frag(ms + 2 * nxt, f[(d + DEPTH - 1) % DEPTH]);
+                mma_frag(f[d]);
+            }
         }
-        if (mb < me2) mma_frag(f0);
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d)
+            if (pi + d < n_pairs) mma_frag(f[d]);
     }
     if (me2 < me) {                                            // odd last row: slot 1 contributes zeros
         Frag f;
