@@ -38,6 +38,157 @@ __device__ __forceinline__ int find_act(const ActSpec& a, int n, int& lo, int& g
     return SWR_ACT_NONE;
 }
 
+#define BWD_TILE 64
+
+// =========================================================================================== fast paths
+// Rows are 16-byte aligned multiples of 4 floats and activation ranges do not cut a float4 (softmax groups are
+// exactly one float4): every thread owns ONE float4 column slot for all the rows it visits, so the per-column
+// coefficients are loaded once per thread and every access is a 16-byte load / store.
+struct V4Plan {
+    int vpr;        // float4 per row
+    int rows;       // rows covered by one pass of the 256-thread block
+};
+
+static bool v4_ok(const ActSpec& as, int N, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3, const void* p0, const void* p1,
+                  const void* p2, const void* p3, const void* c0, const void* c1, const void* c2, const void* c3) {
+    if (N % 4 != 0 || N / 4 > BN_THREADS) return false;
+    const int64_t lds[4] = {ld0, ld1, ld2, ld3};
+    for (int i = 0; i < 4; ++i)
+        if (lds[i] % 4 != 0) return false;
+    const void* ps[8] = {p0, p1, p2, p3, c0, c1, c2, c3};
+    for (int i = 0; i < 8; ++i)
+        if (ps[i] && !swr_aligned16(ps[i])) return false;
+    for (int i = 0; i < as.n; ++i) {
+        if (as.r[i].col_lo % 4 != 0 || as.r[i].col_hi % 4 != 0) return false;
+        if (as.r[i].act == SWR_ACT_SOFTMAX && as.r[i].group != 4) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ int act_of_col(const ActSpec& a, int n) {
+    for (int i = 0; i < a.n; ++i)
+        if (n >= a.r[i].col_lo && n < a.r[i].col_hi) return a.r[i].act;
+    return SWR_ACT_NONE;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4_or(const float* p, int n, float dflt) { return p ? ld4(p + n) : make_float4(dflt, dflt, dflt, dflt); }
+
+__device__ __forceinline__ float4 act_fwd4(int act, float4 v) {
+    if (act == SWR_ACT_RELU) return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    if (act == SWR_ACT_SIGMOID) return make_float4(swr_sigmoid(v.x), swr_sigmoid(v.y), swr_sigmoid(v.z), swr_sigmoid(v.w));
+    if (act == SWR_ACT_SOFTMAX) {
+        const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        const float ex = expf(v.x - mx), ey = expf(v.y - mx), ez = expf(v.z - mx), ew = expf(v.w - mx);
+        const float den = ex + ey + ez + ew;        // same left-to-right order as the scalar kernel
+        return make_float4(ex / den, ey / den, ez / den, ew / den);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float4 act_bwd4(int act, float4 dy, float4 y) {
+    if (act == SWR_ACT_RELU) return make_float4(y.x > 0.f ? dy.x : 0.f, y.y > 0.f ? dy.y : 0.f, y.z > 0.f ? dy.z : 0.f, y.w > 0.f ? dy.w : 0.f);
+    if (act == SWR_ACT_SIGMOID)
+        return make_float4(dy.x * y.x * (1.f - y.x), dy.y * y.y * (1.f - y.y), dy.z * y.z * (1.f - y.z), dy.w * y.w * (1.f - y.w));
+    if (act == SWR_ACT_SOFTMAX) {
+        float dot = 0.f;
+        dot = fmaf(dy.x, y.x, dot); dot = fmaf(dy.y, y.y, dot); dot = fmaf(dy.z, y.z, dot); dot = fmaf(dy.w, y.w, dot);
+        return make_float4(y.x * (dy.x - dot), y.y * (dy.y - dot), y.z * (dy.z - dot), y.w * (dy.w - dot));
+    }
+    return dy;
+}
+
+#define V4_ITERS 8
+__global__ __launch_bounds__(BN_THREADS) void affine_act_fwd_v4_kernel(const float* __restrict__ Z, int64_t ldz,
+                                                                       const float* __restrict__ scale,
+                                                                       const float* __restrict__ shift, const ActSpec acts,
+                                                                       float* __restrict__ Y, int64_t ldy, int64_t M, int N,
+                                                                       const V4Plan pl) {
+    const int r_in = threadIdx.x / pl.vpr, v = threadIdx.x - r_in * pl.vpr;
+    if (r_in >= pl.rows) return;
+    const int n = 4 * v;
+    const int act = act_of_col(acts, n);
+    const float4 sc = ld4_or(scale, n, 1.f), sh = ld4_or(shift, n, 0.f);
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * pl.rows * V4_ITERS + r_in;
+#pragma unroll
+    for (int it = 0; it < V4_ITERS; ++it) {
+        const int64_t m = m0 + static_cast<int64_t>(it) * pl.rows;
+        if (m < M) {
+            const float4 z = ld4(Z + m * ldz + n);
+            const float4 a = make_float4(sc.x * z.x + sh.x, sc.y * z.y + sh.y, sc.z * z.z + sh.z, sc.w * z.w + sh.w);
+            *reinterpret_cast<float4*>(Y + m * ldy + n) = act_fwd4(act, a);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_v4_kernel(
+    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
+    int64_t ldz, const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ cc,
+    const float* __restrict__ mean, const ActSpec acts, float* __restrict__ dZ, int64_t lddz, int64_t M, int N, const V4Plan pl) {
+    const int r_in = threadIdx.x / pl.vpr, v = threadIdx.x - r_in * pl.vpr;
+    if (r_in >= pl.rows) return;
+    const int n = 4 * v;
+    const int act = act_of_col(acts, n);
+    const float4 a4 = ld4_or(ca, n, 1.f), b4 = ld4_or(cb, n, 0.f), c4 = ld4_or(cc, n, 0.f), mu = ld4_or(mean, n, 0.f);
+    const bool has_b = cb != nullptr;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * pl.rows * V4_ITERS + r_in;
+#pragma unroll
+    for (int it = 0; it < V4_ITERS; ++it) {
+        const int64_t m = m0 + static_cast<int64_t>(it) * pl.rows;
+        if (m < M) {
+            float4 g = act_bwd4(act, ld4(dY + m * lddy + n), ld4(Y + m * ldy + n));
+            g.x *= a4.x; g.y *= a4.y; g.z *= a4.z; g.w *= a4.w;
+            if (has_b) {
+                const float4 z = ld4(Z + m * ldz + n);
+                g.x = fmaf(b4.x, z.x - mu.x, g.x) + c4.x; g.y = fmaf(b4.y, z.y - mu.y, g.y) + c4.y;
+                g.z = fmaf(b4.z, z.z - mu.z, g.z) + c4.z; g.w = fmaf(b4.w, z.w - mu.w, g.w) + c4.w;
+            }
+            *reinterpret_cast<float4*>(dZ + m * lddz + n) = g;
+        }
+    }
+}
+
+// one workgroup per 64-row tile (the layout swr_bn_bwd_finalize expects); threads with the same column slot are
+// summed through LDS in fixed order
+__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_v4_kernel(
+    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
+    int64_t ldz, const float* __restrict__ mean, const float* __restrict__ rstd, const ActSpec acts,
+    float* __restrict__ partials, int64_t M, int N, const V4Plan pl) {
+    __shared__ float4 s1[BN_THREADS], s2[BN_THREADS];
+    const int r_in = threadIdx.x / pl.vpr, v = threadIdx.x - r_in * pl.vpr;
+    const bool active = r_in < pl.rows;
+    const int n = 4 * v;
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+    if (active) {
+        const int act = act_of_col(acts, n);
+        const float4 mu = ld4(mean + n), rs = ld4(rstd + n);
+        const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BWD_TILE;
+        for (int r = r_in; r < BWD_TILE; r += pl.rows) {
+            const int64_t m = m0 + r;
+            if (m >= M) break;
+            const float4 g = act_bwd4(act, ld4(dY + m * lddy + n), ld4(Y + m * ldy + n));
+            const float4 z = ld4(Z + m * ldz + n);
+            a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
+            a2.x = fmaf(g.x, (z.x - mu.x) * rs.x, a2.x); a2.y = fmaf(g.y, (z.y - mu.y) * rs.y, a2.y);
+            a2.z = fmaf(g.z, (z.z - mu.z) * rs.z, a2.z); a2.w = fmaf(g.w, (z.w - mu.w) * rs.w, a2.w);
+        }
+    }
+    s1[threadIdx.x] = a1;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    if (active && r_in == 0) {
+        for (int r = 1; r < pl.rows; ++r) {
+            const float4 b1 = s1[r * pl.vpr + v], b2 = s2[r * pl.vpr + v];
+            a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+            a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+        }
+        float* p = partials + (static_cast<int64_t>(blockIdx.x) * N + n) * 2;
+        *reinterpret_cast<float4*>(p) = make_float4(a1.x, a2.x, a1.y, a2.y);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(a1.z, a2.z, a1.w, a2.w);
+    }
+}
+
+
 // ---------------------------------------------------------------------------------- forward stats
 __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
     const float* __restrict__ part, int n_tiles, int64_t M, int N, const float* __restrict__ gamma,
@@ -153,6 +304,14 @@ extern "C" int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scal
     const int rc = make_acts(acts, n_acts, N, as);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
+    if (v4_ok(as, N, ldz, ldy, 4, 4, Z, Y, nullptr, nullptr, scale, shift, nullptr, nullptr)) {
+        V4Plan pl;
+        pl.vpr = N / 4;
+        pl.rows = BN_THREADS / pl.vpr;
+        hipLaunchKernelGGL(affine_act_fwd_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, pl.rows * V4_ITERS))),
+                           dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N, pl);
+        return swr_launch_status();
+    }
     hipLaunchKernelGGL(affine_act_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M * N, BN_THREADS))), dim3(BN_THREADS),
                        0, static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N);
     return swr_launch_status();
@@ -175,7 +334,6 @@ __device__ __forceinline__ float act_grad(const ActSpec& acts, const float* __re
     return g;
 }
 
-#define BWD_TILE 64
 // block = 64 columns x 4 row phases over a 64-row tile; partials[tile][n] = (sum dA, sum dA * xhat)
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
@@ -213,6 +371,14 @@ extern "C" int swr_bn_act_bwd_stats(const float* dY, int64_t lddy, const float* 
     ActSpec as;
     const int rc = make_acts(acts, n_acts, N, as);
     if (rc != SWR_OK) return rc;
+    if (v4_ok(as, N, lddy, ldy, ldz, 4, dY, Y, Z, partials, mean, rstd, nullptr, nullptr)) {
+        V4Plan pl;
+        pl.vpr = N / 4;
+        pl.rows = BN_THREADS / pl.vpr;
+        hipLaunchKernelGGL(bn_act_bwd_stats_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE))), dim3(BN_THREADS), 0,
+                           static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, mean, rstd, as, partials, M, N, pl);
+        return swr_launch_status();
+    }
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE)), static_cast<unsigned>(swr_ceil_div(N, 64)));
     hipLaunchKernelGGL(bn_act_bwd_stats_kernel, grid, dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dY, lddy, Y,
                        ldy, Z, ldz, mean, rstd, as, partials, M, N);
@@ -290,6 +456,15 @@ extern "C" int swr_act_bwd_apply(const float* dY, int64_t lddy, const float* Y, 
     const int rc = make_acts(acts, n_acts, N, as);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
+    if (v4_ok(as, N, lddy, ldy, cb ? ldz : 4, lddz, dY, Y, cb ? Z : nullptr, dZ, ca, cb, cc, mean)) {
+        V4Plan pl;
+        pl.vpr = N / 4;
+        pl.rows = BN_THREADS / pl.vpr;
+        hipLaunchKernelGGL(act_bwd_apply_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, pl.rows * V4_ITERS))),
+                           dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, as,
+                           dZ, lddz, M, N, pl);
+        return swr_launch_status();
+    }
     hipLaunchKernelGGL(act_bwd_apply_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M * N, BN_THREADS))), dim3(BN_THREADS),
                        0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, as, dZ, lddz, M, N);
     return swr_launch_status();
