@@ -14,12 +14,13 @@
 // written once.
 #define MIX_WAVES 4
 #define MIX_MAX_EXPERTS 64
-#define MIX_ROW_FLOATS 2560          // LDS floats per wave: Y row + dP row
+#define MIX_ROW_FLOATS 2560          // upper bound of LDS floats per wave: Y row + dP row
 
 struct MixK {
     swr_mix_desc d;
     int32_t n_expert;
     int32_t y_lo, y_hi;              // column span of Y that the kernel touches
+    int32_t row_floats;              // LDS floats per wave (rounded up to 4)
     uint8_t inv_cnt[MIX_MAX_EXPERTS];            // backward: (o, j) pairs that select expert e
     uint8_t inv[MIX_MAX_EXPERTS][SWR_MIX_MAX_OUT];   // packed o * 16 + j
 };
@@ -43,14 +44,15 @@ static int make_mix(const swr_mix_desc* desc, MixK& k) {
     k.y_lo = desc->x_col < desc->g_col ? desc->x_col : desc->g_col;
     k.y_hi = x_hi > g_hi ? x_hi : g_hi;
     SWR_REQUIRE((k.y_hi - k.y_lo) + desc->n_out * desc->H <= MIX_ROW_FLOATS, SWR_ERR_UNSUPPORTED);
+    k.row_floats = ((k.y_hi - k.y_lo) + desc->n_out * desc->H + 3) / 4 * 4;
     return SWR_OK;
 }
 
 __global__ __launch_bounds__(MIX_WAVES * 64) void mix_fwd_kernel(const MixK k, const float* __restrict__ Y, int64_t ldy,
                                                                  float* __restrict__ P, int64_t ldp, int64_t M) {
-    __shared__ float lds[MIX_WAVES][MIX_ROW_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* row = lds[wave];
+    float* row = lds + wave * k.row_floats;
     const swr_mix_desc& d = k.d;
     const int wy = k.y_hi - k.y_lo, wp = d.n_out * d.H;
     for (int64_t m = static_cast<int64_t>(blockIdx.x) * MIX_WAVES + wave; m < M; m += static_cast<int64_t>(gridDim.x) * MIX_WAVES) {
@@ -76,8 +78,9 @@ extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t
     const int rc = make_mix(desc, k);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
-    const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 4096 ? swr_ceil_div(M, MIX_WAVES) : 4096);
-    hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), 0, static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
+    const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 8192 ? swr_ceil_div(M, MIX_WAVES) : 8192);
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), MIX_WAVES * k.row_floats * sizeof(float),
+                       static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
     return swr_launch_status();
 }
 
@@ -85,9 +88,9 @@ extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t
 __global__ __launch_bounds__(MIX_WAVES * 64) void mix_bwd_kernel(const MixK k, const float* __restrict__ dP, int64_t lddp,
                                                                  const float* __restrict__ Y, int64_t ldy,
                                                                  float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M) {
-    __shared__ float lds[MIX_WAVES][MIX_ROW_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* row = lds[wave];
+    float* row = lds + wave * k.row_floats;
     const swr_mix_desc& d = k.d;
     const int wy = k.y_hi - k.y_lo, wp = d.n_out * d.H;
     float* rdp = row + wy;
@@ -139,9 +142,9 @@ extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_
     const int rc = make_mix(desc, k);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
-    const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 4096 ? swr_ceil_div(M, MIX_WAVES) : 4096);
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), 0, static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy,
-                       dY, lddy, accumulate, M);
+    const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 8192 ? swr_ceil_div(M, MIX_WAVES) : 8192);
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), MIX_WAVES * k.row_floats * sizeof(float),
+                       static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy, dY, lddy, accumulate, M);
     return swr_launch_status();
 }
 
