@@ -204,31 +204,50 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const SortMeta 
     hist[static_cast<int64_t>(tile) * 256 + threadIdx.x] = lh[threadIdx.x];
 }
 
-// one workgroup per table, thread = digit: hist[tile][digit] -> global output offset of (tile, digit)
-__global__ __launch_bounds__(256) void sort_scan_kernel(const SortMeta sm, int pass, uint32_t* __restrict__ hist) {
+// one workgroup per table: hist[tile][digit] -> global output offset of (tile, digit).  Thread = digit for the digit
+// totals; the running offsets over the table's tiles are produced by 4 tile-strided passes per digit quarter so that
+// 1024 threads share the work of long tables (the big table has 32+ tiles, shared small tables 64).
+#define SCAN_THREADS 1024
+__global__ __launch_bounds__(SCAN_THREADS) void sort_scan_kernel(const SortMeta sm, int pass, uint32_t* __restrict__ hist) {
     __shared__ uint32_t tot[256];
+    __shared__ uint32_t partial[4][256];
     const int t = blockIdx.x;
     if (pass >= sm.passes[t]) return;
     const int t0 = sm.tile_off[t], t1 = sm.tile_off[t + 1];
+    const int nt = t1 - t0;
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;          // digit, tile quarter
+    const int per = (nt + 3) / 4;
+    const int qa = t0 + min(q * per, nt), qb = t0 + min((q + 1) * per, nt);
+    // pass 1: per-quarter totals of this digit
     uint32_t run = 0;
-    for (int tile = t0; tile < t1; ++tile) {
-        const uint32_t c = hist[static_cast<int64_t>(tile) * 256 + threadIdx.x];
-        hist[static_cast<int64_t>(tile) * 256 + threadIdx.x] = run;
-        run += c;
-    }
-    tot[threadIdx.x] = run;
+    for (int tile = qa; tile < qb; ++tile) run += hist[static_cast<int64_t>(tile) * 256 + d];
+    partial[q][d] = run;
     __syncthreads();
-    // exclusive scan of the 256 digit totals (Hillis-Steele in LDS)
-    uint32_t v = run;
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < q) before += partial[k][d];
+        total += partial[k][d];
+    }
+    // exclusive scan of the 256 digit totals (Hillis-Steele in LDS), done by quarter 0, read by all
+    if (q == 0) tot[d] = total;
+    __syncthreads();
+    uint32_t v = total;
     for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t add = threadIdx.x >= off ? tot[threadIdx.x - off] : 0u;
+        const uint32_t add = (q == 0 && d >= off) ? tot[d - off] : 0u;
         __syncthreads();
         v += add;
-        tot[threadIdx.x] = v;
+        if (q == 0) tot[d] = v;
         __syncthreads();
     }
-    const uint32_t base = static_cast<uint32_t>(sm.seg_off[t]) + (v - run);
-    for (int tile = t0; tile < t1; ++tile) hist[static_cast<int64_t>(tile) * 256 + threadIdx.x] += base;
+    const uint32_t digit_base = static_cast<uint32_t>(sm.seg_off[t]) + (tot[d] - total);
+    // pass 2: exclusive running offsets inside the quarter
+    uint32_t off = digit_base + before;
+    for (int tile = qa; tile < qb; ++tile) {
+        const uint32_t c = hist[static_cast<int64_t>(tile) * 256 + d];
+        hist[static_cast<int64_t>(tile) * 256 + d] = off;
+        off += c;
+    }
 }
 
 // stable scatter: element order inside a tile is round-major, then wave, then lane (= memory order)
@@ -467,7 +486,7 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
     int cur = 0;
     for (int pass = 0; pass < p.n_passes; ++pass) {
         hipLaunchKernelGGL(sort_hist_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(256), 0, st, p.sm, pass, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(SCAN_THREADS), 0, st, p.sm, pass, hist);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], vbuf[cur],
                            kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
         cur ^= 1;
