@@ -19,6 +19,7 @@
 //                                          the batch dimension m is split over waves, partial tiles are
 //                                          written to a workspace and summed in fixed order
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -47,6 +48,188 @@ __device__ __forceinline__ float4 load_k4(const float* __restrict__ row, int k, 
 }
 
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// epilogue shared by the row-parallel kernels: lane (i, s) holds column n0 + 32t + i, rows m0 + (r & 3) + 8 (r >> 2) + 4 s
+template <int NT>
+__device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tiles_m, f32x16 (&acc)[NT], int g, int64_t tile_m,
+                                              int64_t m0, int n0, int i, int s) {
+    const int N = a.N;
+    float* __restrict__ Cg = a.C + g * a.gsC;
+    const float* __restrict__ bias = a.bias ? a.bias + g * a.gsBias : nullptr;
+    const int nvalid = static_cast<int>(min<int64_t>(32, a.M - m0));
+    if (nvalid <= 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 32 * t + i;
+        const float bn = (bias && n < N) ? bias[n] : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
+            float v = acc[t][r] + bn;
+            const bool ok = row < nvalid && n < N;
+            if (ok) {
+                float* c = Cg + (m0 + row) * a.ldc + n;
+                if (a.accumulate) v += *c;
+                *c = v;
+                sum += v;
+            }
+            acc[t][r] = v;
+        }
+        if (a.stat_partials) {
+            // BatchNorm batch statistics of this 32-row tile, two-pass in registers (SURVEY.md 7 step 5)
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / static_cast<float>(nvalid);
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
+                const float d = acc[t][r] - mean;
+                if (row < nvalid) m2 = fmaf(d, d, m2);
+            }
+            m2 += __shfl_xor(m2, 32);
+            if (s == 0 && n < N) {
+                float* sp = a.stat_partials + ((tile_m * a.groups + g) * N + n) * 2;   // [tiles][groups * N][2]
+                sp[0] = mean;
+                sp[1] = m2;
+            }
+        }
+    }
+}
+
+// ---- LDS variant: the B operand (weights) of a k-chunk is staged once per workgroup in LDS and shared by the four
+// waves (4x less L2 traffic, no B registers); the A operand (activations, streamed from HBM, private to a wave) stays on
+// the direct global -> register path with a deep prefetch ring.  One MFMA consumes one ds_read_b32 per lane.
+#define LDS_KC 32                       // k per chunk (4 MFMA k-groups)
+template <int NT, bool BT, bool PRO>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_lds_kernel(const GemmK kk) {
+    constexpr int LDN = NT * 32 + 4;                    // row pitch of the k-major B tile
+    constexpr int F4 = NT * 32 * LDS_KC / 4;            // float4 per chunk
+    constexpr int F4_PER_THREAD = (F4 + GEMM_THREADS - 1) / GEMM_THREADS;
+    extern __shared__ __attribute__((aligned(16))) float Bs[];       // [2][LDS_KC * LDN]
+    const swr_gemm_args& a = kk.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, s = lane >> 5;
+    const int g = blockIdx.z;
+    const int64_t tile_m = static_cast<int64_t>(blockIdx.x) * GEMM_WAVES + wave;
+    const int64_t m0 = tile_m * 32;
+    const int n0 = blockIdx.y * (32 * NT);
+    const int K = a.K, N = a.N;
+    const float* __restrict__ Ag = a.A + g * a.gsA;
+    const float* __restrict__ Bg = a.B + g * a.gsB;
+    const int64_t ra = max<int64_t>(0, min(m0 + i, a.M - 1));
+    const float* __restrict__ arow = Ag + ra * a.lda;
+    const float* __restrict__ psc = PRO ? a.a_scale + g * a.gsScale : nullptr;
+    const float* __restrict__ psh = PRO ? a.a_shift + g * a.gsScale : nullptr;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // Everything below is branch-free (clamped addresses + selects) so that hipcc can keep counted
+    // s_waitcnt vmcnt / lgkmcnt across the unrolled body.  Requires K % 4 == 0 (and N % 4 == 0 for [K, N] weights).
+    auto ld4c = [&](const float* __restrict__ row, int k) -> float4 {      // k % 4 == 0; zero when k >= K
+        const float4 v = *reinterpret_cast<const float4*>(row + min(k, K - 4));
+        const bool ok = k < K;
+        return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    };
+    // ---- B staging: global -> registers (issued a chunk ahead) -> LDS
+    float4 stage[F4_PER_THREAD];
+    auto stage_load = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < F4_PER_THREAD; ++u) {
+            const int q = min(static_cast<int>(threadIdx.x) + u * GEMM_THREADS, F4 - 1);
+            if (BT) {                                   // W[n][k]: 8 float4 along k per output column
+                const int n = min(n0 + (q >> 3), N - 1);
+                stage[u] = ld4c(Bg + static_cast<int64_t>(n) * a.ldb, kc + 4 * (q & 7));
+            } else {                                    // W[k][n]: NT*8 float4 along n per k row
+                const int kr = q / (NT * 8), n = n0 + 4 * (q - kr * (NT * 8)), k = kc + kr;
+                const float4 v = *reinterpret_cast<const float4*>(Bg + static_cast<int64_t>(min(k, K - 1)) * a.ldb + min(n, N - 4));
+                const bool ok = k < K && n < N;
+                stage[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < F4_PER_THREAD; ++u) {
+            const int q = threadIdx.x + u * GEMM_THREADS;
+            if (q < F4) {
+                if (BT) {
+                    const int n = q >> 3, kq = 4 * (q & 7);
+                    float* d = Bs + buf * (LDS_KC * LDN) + kq * LDN + n;
+                    d[0] = stage[u].x; d[LDN] = stage[u].y; d[2 * LDN] = stage[u].z; d[3 * LDN] = stage[u].w;
+                } else {
+                    const int kr = q / (NT * 8), nq = 4 * (q - kr * (NT * 8));
+                    *reinterpret_cast<float4*>(Bs + buf * (LDS_KC * LDN) + kr * LDN + nq) = stage[u];
+                }
+            }
+        }
+    };
+
+    // ---- A ring: one float4 per k-group, DEPTH groups (two chunks) in flight
+    constexpr int DEPTH = 8;
+    float4 ar[DEPTH];
+    auto a_load = [&](int gi) -> float4 {
+        const int k = 8 * gi + 4 * s;
+        float4 v = ld4c(arow, k);
+        if (PRO) {
+            const float4 sc = ld4c(psc, k), sh = ld4c(psh, k);         // zero beyond K: the product stays zero
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            if (a.a_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        return v;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ar[d] = a_load(d);
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    const int n_chunks = (K + LDS_KC - 1) / LDS_KC;
+    // B fragments of a k-group: 4 steps x NT tiles, read from LDS one group ahead of the MFMAs that use them
+    auto b_read = [&](float (&bf)[4 * NT], int half, int gq) {
+        const float* bp = Bs + half * (LDS_KC * LDN) + (8 * gq + 4 * s) * LDN + i;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[cc * NT + t] = bp[cc * LDN + 32 * t];
+    };
+    // ring slots are compile-time constants: DEPTH = 2 chunks, chunk parity selects the half of the ring
+    auto do_chunk = [&](int c, auto half) {
+        constexpr int HALF = decltype(half)::value;
+        stage_load((c + 1) * LDS_KC);                  // beyond K this loads zeros (never stored)
+        float bf0[4 * NT], bf1[4 * NT];
+        b_read(bf0, HALF, 0);
+#pragma unroll
+        for (int gq = 0; gq < LDS_KC / 8; ++gq) {
+            float (&cur)[4 * NT] = (gq & 1) ? bf1 : bf0;
+            float (&nxt)[4 * NT] = (gq & 1) ? bf0 : bf1;
+            if (gq + 1 < LDS_KC / 8) b_read(nxt, HALF, gq + 1);
+            // pin the order: the LDS reads of the NEXT group are issued before this group's MFMAs, which then wait only
+            // for the older reads (counted lgkmcnt) -- otherwise the scheduler sinks every read next to its use
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 av = ar[gq + HALF * (DEPTH / 2)];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(av, cc), cur[cc * NT + t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ar[gq + HALF * (DEPTH / 2)] = a_load(c * (LDS_KC / 8) + gq + DEPTH);
+        }
+        __syncthreads();                       // all waves are done with the other buffer (read one chunk ago)
+        if (c + 1 < n_chunks) stage_store(HALF ^ 1);
+        __syncthreads();
+    };
+    for (int c = 0; c < n_chunks; c += 2) {
+        do_chunk(c, std::integral_constant<int, 0>{});
+        if (c + 1 < n_chunks) do_chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
+}
 
 // NT output tiles (32 columns each) per wave; BT: B is [N, K] (nt) else [K, N] (nn)
 template <int NT, bool BT, bool VEC, bool PRO>
@@ -177,47 +360,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_kernel(const GemmK kk)
         mma_frag(ft);
     }
 
-    // epilogue: lane (i, s) holds column n0 + 32t + i, rows m0 + (r & 3) + 8 (r >> 2) + 4 s
-    float* __restrict__ Cg = a.C + g * a.gsC;
-    const float* __restrict__ bias = a.bias ? a.bias + g * a.gsBias : nullptr;
-    const int nvalid = static_cast<int>(min<int64_t>(32, a.M - m0));
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n0 + 32 * t + i;
-        const float bn = (bias && n < N) ? bias[n] : 0.f;
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            float v = acc[t][r] + bn;
-            const bool ok = row < nvalid && n < N;
-            if (ok) {
-                float* c = Cg + (m0 + row) * a.ldc + n;
-                if (a.accumulate) v += *c;
-                *c = v;
-                sum += v;
-            }
-            acc[t][r] = v;
-        }
-        if (a.stat_partials) {
-            // BatchNorm batch statistics of this 32-row tile, two-pass in registers (SURVEY.md 7 step 5)
-            sum += __shfl_xor(sum, 32);
-            const float mean = sum / static_cast<float>(nvalid);
-            float m2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-                const float d = acc[t][r] - mean;
-                if (row < nvalid) m2 = fmaf(d, d, m2);
-            }
-            m2 += __shfl_xor(m2, 32);
-            if (s == 0 && n < N) {
-                float* sp = a.stat_partials + ((tile_m * a.groups + g) * N + n) * 2;   // [tiles][groups * N][2]
-                sp[0] = mean;
-                sp[1] = m2;
-            }
-        }
-    }
+    rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
 }
 
 template <bool BT>
@@ -233,17 +376,22 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     kk.n_tiles_m = static_cast<int>(swr_ceil_div(a.M, 32));
     const bool pro = a.a_scale != nullptr;
     bool vec = swr_aligned16(a.A) && a.lda % 4 == 0 && a.gsA % 4 == 0;
-    if (BT) vec = vec && swr_aligned16(a.B) && a.ldb % 4 == 0 && a.gsB % 4 == 0;
+    vec = vec && swr_aligned16(a.B) && a.ldb % 4 == 0 && a.gsB % 4 == 0;      // both layouts are staged with 16-byte loads
     if (pro) vec = vec && swr_aligned16(a.a_scale) && swr_aligned16(a.a_shift) && a.gsScale % 4 == 0;
+    const bool lds_ok = vec && a.K % 4 == 0 && a.K >= 4 && (BT || (a.N % 4 == 0 && a.N >= 4));
     const int tiles = static_cast<int>(swr_ceil_div(a.N, 32));
-    const int nblk = static_cast<int>(swr_ceil_div(tiles, 8));
+    // tiles per wave: the LDS kernel keeps two waves per SIMD up to 5 tiles (VGPR + AGPR <= 256)
+    const int nblk = static_cast<int>(swr_ceil_div(tiles, lds_ok ? 5 : 8));
     const int nt = static_cast<int>(swr_ceil_div(tiles, nblk));
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(kk.n_tiles_m, GEMM_WAVES)), static_cast<unsigned>(nblk),
                     static_cast<unsigned>(a.groups));
     hipStream_t st = static_cast<hipStream_t>(stream);
+#define LDS_BYTES(NTV) static_cast<unsigned>(2 * LDS_KC * ((NTV) * 32 + 4) * sizeof(float))
 #define GO(NTV)                                                                                                   \
     do {                                                                                                          \
-        if (vec && pro) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, true>), grid, dim3(GEMM_THREADS), 0, st, kk);   \
+        if (lds_ok && pro) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, true>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk);   \
+        else if (lds_ok) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, false>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk); \
+        else if (vec && pro) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, true>), grid, dim3(GEMM_THREADS), 0, st, kk);   \
         else if (vec) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, false>), grid, dim3(GEMM_THREADS), 0, st, kk);    \
         else if (pro) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, false, true>), grid, dim3(GEMM_THREADS), 0, st, kk);    \
         else hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, false, false>), grid, dim3(GEMM_THREADS), 0, st, kk);            \
@@ -259,6 +407,7 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
         default: GO(8); break;
     }
 #undef GO
+#undef LDS_BYTES
     return swr_launch_status();
 }
 
