@@ -257,7 +257,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters):
     stream = torch.cuda.Stream()
 
     def launch():
-        H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap),
+        H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap), 0,
                                              H.ptr(hyper), H.stream()), "swr_adam_sweep_untouched")
     backup = (p.detach().clone(), m.clone(), v.clone())
     ms = time_kernel_events(launch, max(10, iters), stream)

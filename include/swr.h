@@ -308,7 +308,8 @@ int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int dim,
                   const int32_t* urow, const float* ugrad, int64_t n_entries,
                   uint32_t* bitmap, const swr_adam_hyper* hyper_dev, void* stream);
 int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vocab, int dim,
-                             uint32_t* bitmap, const swr_adam_hyper* hyper_dev, void* stream);
+                             uint32_t* bitmap, int clear_bitmap /* 1: zero the bitmap afterwards (normal use) */,
+                             const swr_adam_hyper* hyper_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,11 +104,12 @@ __global__ __launch_bounds__(AD_THREADS) void adam_sweep_kernel(float* __restric
 }
 
 extern "C" int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vocab, int dim, uint32_t* bitmap,
-                                        const swr_adam_hyper* hyper, void* stream) {
+                                        int clear_bitmap, const swr_adam_hyper* hyper, void* stream) {
     SWR_REQUIRE(p && m && v && bitmap && hyper && vocab > 0 && dim > 0, SWR_ERR_ARG);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = vocab * dim;
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(n, AD_THREADS) < 8192 ? swr_ceil_div(n, AD_THREADS) : 8192);
     hipLaunchKernelGGL(adam_sweep_kernel, dim3(grid), dim3(AD_THREADS), 0, st, p, m, v, vocab, dim, bitmap, hyper);
+    if (!clear_bitmap) return swr_launch_status();
     return swr_zero_async(bitmap, static_cast<size_t>(swr_ceil_div(vocab, 32)) * 4, st);
 }

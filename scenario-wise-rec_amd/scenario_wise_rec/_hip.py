@@ -131,7 +131,7 @@ _SIGS = {
     "swr_adam_advance": (C.c_int, [_P, _P]),
     "swr_adam_dense": (C.c_int, [_P, _P, _P, _P, _L, _P, _P]),
     "swr_adam_rows": (C.c_int, [_P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P]),
-    "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _P, _P]),
+    "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 for _name, (_res, _args) in _SIGS.items():

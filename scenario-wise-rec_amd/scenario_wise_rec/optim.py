@@ -113,6 +113,6 @@ class FusedAdam(torch.optim.Optimizer):
                 m, v, bitmap = self._big[id(p)]
                 H.check(lib.swr_adam_rows(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(urow), H.ptr(ugrad),
                                           urow.numel(), H.ptr(bitmap), H.ptr(hyper), stream), "swr_adam_rows")
-                H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap),
+                H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap), 1,
                                                      H.ptr(hyper), stream), "swr_adam_sweep_untouched")
         return loss
