@@ -175,12 +175,17 @@ def main():
     else:
         step_fn = lambda: trainer.train_step(x, y)
 
-    # ---- warm-up (eager), then capture the whole step into a hipGraph -------------------------------------
+    # ---- warm-up (eager), then capture the step into hipGraph(s) ------------------------------------------
+    # 1 GPU: the whole step is ONE graph.  N GPUs: forward+backward and merge+optimizer are two graphs with the
+    # RCCL collectives (one all-reduce + two all-gathers) issued eagerly in between (parallel.DataParallelStep).
     graph = None
-    if not args.no_graph and world == 1:
-        from scenario_wise_rec.trainers.graph import GraphedStep
+    if not args.no_graph:
         try:
-            graph = GraphedStep(trainer, x, y, warmup=args.warmup)
+            if world == 1:
+                from scenario_wise_rec.trainers.graph import GraphedStep
+                graph = GraphedStep(trainer, x, y, warmup=args.warmup)
+            else:
+                graph = stepper.capture(x, y, warmup=args.warmup)
             _stage("captured")
             graph.replay()
             torch.cuda.synchronize()

@@ -41,27 +41,51 @@ def hip_merge_rows(urow, ugrad, vocab):
     return out_row, out_grad
 
 
-def exchange_gradients(dense_grad, sparse_grads, world_size, group=None, merge_rows=hip_merge_rows):
-    """The exchange step.  `dense_grad`: the flat gradient arena (averaged in place).
-    `sparse_grads`: list of (urow int32 [n], ugrad fp32 [n, dim], vocab) per large table.
-    Returns the merged, averaged (urow, ugrad) per table."""
+def communicate(dense_grad, sparse_grads, world_size, group=None, buffers=None):
+    """The collectives of the exchange step, nothing else: one all-reduce of the flat gradient arena and, per large
+    table, all-gathers of the per-rank (row id, gradient) entries.  Returns the gathered (rows, grads, vocab) list.
+    `buffers` (optional) are preallocated gather targets [(rows, grads), ...] -- static addresses for hipGraph use."""
     if dense_grad is not None and dense_grad.numel():
         dist.all_reduce(dense_grad, op=dist.ReduceOp.SUM, group=group)
-        dense_grad.mul_(1.0 / world_size)
-    merged = []
-    for urow, ugrad, vocab in sparse_grads:
+    gathered = []
+    for t, (urow, ugrad, vocab) in enumerate(sparse_grads):
         n, dim = ugrad.shape
-        rows = torch.empty(world_size * n, dtype=urow.dtype, device=urow.device)
-        grads = torch.empty((world_size * n, dim), dtype=ugrad.dtype, device=ugrad.device)
+        if buffers is not None:
+            rows, grads = buffers[t]
+        else:
+            rows = torch.empty(world_size * n, dtype=urow.dtype, device=urow.device)
+            grads = torch.empty((world_size * n, dim), dtype=ugrad.dtype, device=ugrad.device)
         dist.all_gather_into_tensor(rows, urow.contiguous(), group=group)
         dist.all_gather_into_tensor(grads, ugrad.contiguous(), group=group)
+        gathered.append((rows, grads, vocab))
+    return gathered
+
+
+def finish(dense_grad, gathered, world_size, merge_rows=hip_merge_rows):
+    """Device-side remainder of the exchange: gradient averaging and the deterministic merge of the gathered row
+    entries (every rank computes bit-identical results)."""
+    if dense_grad is not None and dense_grad.numel():
+        dense_grad.mul_(1.0 / world_size)
+    merged = []
+    for rows, grads, vocab in gathered:
         r, g = merge_rows(rows, grads, vocab)
         merged.append((r, g.mul_(1.0 / world_size)))
     return merged
 
 
+def exchange_gradients(dense_grad, sparse_grads, world_size, group=None, merge_rows=hip_merge_rows):
+    """The exchange step.  `dense_grad`: the flat gradient arena (averaged in place).
+    `sparse_grads`: list of (urow int32 [n], ugrad fp32 [n, dim], vocab) per large table.
+    Returns the merged, averaged (urow, ugrad) per table."""
+    return finish(dense_grad, communicate(dense_grad, sparse_grads, world_size, group), world_size, merge_rows)
+
+
 class DataParallelStep(object):
-    """`CTRTrainer.train_step` with the gradient exchange between backward and the optimizer step."""
+    """`CTRTrainer.train_step` with the gradient exchange between backward and the optimizer step.
+
+    `train_step` launches everything eagerly.  `capture(x, y)` records the step as TWO hipGraphs -- forward +
+    backward, and merge + optimizer -- with the RCCL collectives issued eagerly in between (3 calls at the
+    KuaiRand config), so a replayed step costs two graph launches and the collectives instead of ~60 launches."""
 
     def __init__(self, trainer, world_size=None, group=None):
         self.trainer = trainer
@@ -73,14 +97,26 @@ class DataParallelStep(object):
         # identical replicas at step 0: broadcast rank 0's parameters and buffers once
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0, group=group)
+        self._graphs = None
+
+    # ---- pieces ---------------------------------------------------------------------------------------
+    def _forward_backward(self, x_dict, y):
+        tr = self.trainer
+        y_pred = tr.model(x_dict)
+        loss = tr.criterion(y_pred, y)
+        tr.model.zero_grad()
+        loss.backward()
+        return loss.detach()
+
+    def _sparse(self):
+        arena = self.trainer.model.arena()
+        big = [p for p in arena["big"] if getattr(p, "_swr_sparse_grad", None) is not None]
+        return arena, big, [(p._swr_sparse_grad[0], p._swr_sparse_grad[1], p.shape[0]) for p in big]
 
     def train_step(self, x_dict, y):
         tr = self.trainer
         model = tr.model
-        y_pred = model(x_dict)
-        loss = tr.criterion(y_pred, y)
-        model.zero_grad()
-        loss.backward()
+        loss = self._forward_backward(x_dict, y)
         arena = model.arena() if hasattr(model, "arena") else None
         if arena is None:
             # no arena (foreign module): per-tensor exchange
@@ -89,10 +125,51 @@ class DataParallelStep(object):
                     dist.all_reduce(p.grad, group=self.group)
                     p.grad.mul_(1.0 / self.world_size)
         else:
-            big = [p for p in arena["big"] if getattr(p, "_swr_sparse_grad", None) is not None]
-            merged = exchange_gradients(arena["g"], [(p._swr_sparse_grad[0], p._swr_sparse_grad[1], p.shape[0]) for p in big],
-                                        self.world_size, self.group)
+            arena, big, sparse = self._sparse()
+            merged = exchange_gradients(arena["g"], sparse, self.world_size, self.group)
             for p, rg in zip(big, merged):
                 p._swr_sparse_grad = rg
         tr.optimizer.step()
         return loss
+
+    # ---- captured variant -----------------------------------------------------------------------------
+    def capture(self, x_dict, y, warmup=2):
+        """Static input buffers + two captured graphs.  Feed batches with `load`, run with `replay`."""
+        self.x = {k: v.clone() for k, v in x_dict.items()}
+        self.y = y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.train_step(self.x, self.y)          # results dropped at once (see trainers/graph.py)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            loss = self._forward_backward(self.x, self.y)
+        arena, big, sparse = self._sparse()
+        buffers = [(torch.empty(self.world_size * r.numel(), dtype=r.dtype, device=r.device),
+                    torch.empty((self.world_size * g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device))
+                   for r, g, _ in sparse]
+        gathered = [(rows, grads, v) for (rows, grads), (_, _, v) in zip(buffers, sparse)]
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            merged = finish(arena["g"], gathered, self.world_size)
+            for p, rg in zip(big, merged):
+                p._swr_sparse_grad = rg
+            self.trainer.optimizer.step()
+        self._graphs = (g1, g2, arena["g"], sparse, buffers)
+        self.loss = loss
+        return self
+
+    def load(self, x_dict, y):
+        for k, v in x_dict.items():
+            self.x[k].copy_(v, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+
+    def replay(self):
+        g1, g2, dense, sparse, buffers = self._graphs
+        g1.replay()
+        communicate(dense, sparse, self.world_size, self.group, buffers)
+        g2.replay()
+        return self.loss

@@ -6,7 +6,7 @@ mode "exchange-cpu": gloo on CPU.  Each rank takes its row shard of the golden c
     from the oracle (test infrastructure), packs them the way the product does (flat dense arena + row-sparse
     entries for the largest table) and runs the product's exchange step (scenario_wise_rec.parallel) with a
     numpy row merge injected.  Rank 0 dumps the exchanged gradients.
-mode "full-gpu": gloo over device tensors, every rank on cuda:0.  The whole HIP path (DataParallelStep) for one
+mode "full-gpu" / "graph-gpu": gloo over device tensors, every rank on cuda:0.  The whole HIP path (DataParallelStep) for one
     step; rank 0 dumps gradients and the state after the step.
 """
 import os
@@ -88,7 +88,18 @@ def main():
                         device="cuda:0")
         step = DataParallelStep(tr, world)
         model.train()
-        step.train_step(to_device(x, "cuda:0"), torch.from_numpy(y).cuda())
+        if mode == "graph-gpu":
+            # two captured graphs + eager collectives; the captured step must land where the eager one does.
+            # capture() runs 2 eager warm-up steps, so compare after 3 steps in total on the same batch.
+            xd, yd = to_device(x, "cuda:0"), torch.from_numpy(y).cuda()
+            if os.environ.get("DP_EAGER_REFERENCE"):
+                for _ in range(3):
+                    step.train_step(xd, yd)
+            else:
+                step.capture(xd, yd, warmup=2)
+                step.replay()
+        else:
+            step.train_step(to_device(x, "cuda:0"), torch.from_numpy(y).cuda())
         torch.cuda.synchronize()
         H.check_errors()
         if rank == 0:

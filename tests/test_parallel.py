@@ -23,13 +23,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_workers(mode, case, world, extra=()):
+def run_workers(mode, case, world, extra=(), env_extra=None):
     out = tempfile.mkdtemp()
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+                   OMP_NUM_THREADS="1", **(env_extra or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, case, out, *extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -60,3 +60,15 @@ def test_two_ranks_full_hip_step(limit):
             assert int(got[k]) == int(v)
         else:
             np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=state_atol(c, k, 1), err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit", [None, 2048])
+def test_two_rank_captured_step_matches_eager(limit):
+    """DataParallelStep.capture (two hipGraphs around eager collectives) vs three eager steps: identical state."""
+    extra = () if limit is None else (str(limit),)
+    a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra), "state1.npz"))
+    b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra, env_extra={"DP_EAGER_REFERENCE": "1"}),
+                             "state1.npz"))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
