@@ -146,13 +146,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SWR_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (ranks share cuda:0); the driver's
+    # multi-GPU runs use the default: backend nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("SWR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from scenario_wise_rec import _hip as H
     from scenario_wise_rec.trainers import CTRTrainer
