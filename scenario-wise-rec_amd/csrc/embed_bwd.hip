@@ -26,6 +26,8 @@
 #define MAX_SLOTS 40   // BwdMeta travels by value in the kernarg segment (4 KiB)
 #define CHUNK 32
 #define RB_THREADS 256
+#define ACC_STRIPES 16   // copies of the dense accumulators: chunk c adds into stripe c % 16, so a hot row of a tiny
+                       // table (V = 2: 1000+ partial runs per row) does not serialise its atomics on one address
 #define SORT_THREADS 256
 #define SORT_ITEMS 8
 #define SORT_TILE (SORT_THREADS * SORT_ITEMS)
@@ -163,7 +165,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     p.off_v0 = off; off += kb;
     p.off_v1 = off; off += kb;
     p.off_hist = off; off += align_up(static_cast<size_t>(tiles) * 256 * 4);
-    const size_t ab = align_up(static_cast<size_t>(p.dense_acc_elems + p.sparse_acc_elems) * 8);
+    const size_t ab = align_up(static_cast<size_t>(p.dense_acc_elems * ACC_STRIPES + p.sparse_acc_elems) * 8);
     p.off_acc_hi = off; off += ab;
     p.off_acc_lo = off; off += ab;
     p.total = off;
@@ -375,9 +377,9 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
             if (e >= t.dim) return;
             int64_t dst;
             if (t.mode != 1)
-                dst = t.acc_off + static_cast<int64_t>(key) * t.dim + e;
+                dst = (gid % ACC_STRIPES) * dense_acc_elems + t.acc_off + static_cast<int64_t>(key) * t.dim + e;
             else
-                dst = dense_acc_elems + (head_pos - m.sparse_start) * m.dim_max + e;
+                dst = ACC_STRIPES * dense_acc_elems + (head_pos - m.sparse_start) * m.dim_max + e;
             if (whole) {
                 acc_hi[dst] = static_cast<unsigned long long>(s_hi);
                 acc_lo[dst] = static_cast<unsigned long long>(s_lo);
@@ -424,13 +426,20 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
 }
 
 __global__ __launch_bounds__(RB_THREADS) void finalize_dense_kernel(const BwdMeta m, const long long* __restrict__ acc_hi,
-                                                                    const long long* __restrict__ acc_lo) {
+                                                                    const long long* __restrict__ acc_lo,
+                                                                    int64_t dense_acc_elems) {
     const TableMeta& t = m.tab[blockIdx.y];
     if (t.mode == 1) return;
     const int64_t n = t.vocab * t.dim;
     for (int64_t j = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x; j < n;
          j += static_cast<int64_t>(gridDim.x) * RB_THREADS) {
-        const float g = from_fixed(acc_hi[t.acc_off + j], acc_lo[t.acc_off + j]);
+        long long hi = 0, lo = 0;                                     // integer sums: order-free, exact
+#pragma unroll
+        for (int st = 0; st < ACC_STRIPES; ++st) {
+            hi += acc_hi[st * dense_acc_elems + t.acc_off + j];
+            lo += acc_lo[st * dense_acc_elems + t.acc_off + j];
+        }
+        const float g = from_fixed(hi, lo);
         t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;     // mode 2: add to the caller's gradient arena
     }
 }
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(RB_THREADS) void finalize_sparse_kernel(const BwdMe
     const bool head = (i == t.sorted_off) || (ck[i - 1] != key);
     const int64_t local = i - t.sorted_off;
     if (e == 0) t.urow[local] = head ? static_cast<int32_t>(key) : -1;
-    const int64_t a = dense_acc_elems + (i - m.sparse_start) * m.dim_max + e;
+    const int64_t a = ACC_STRIPES * dense_acc_elems + (i - m.sparse_start) * m.dim_max + e;
     t.ugrad[local * t.dim + e] = head ? from_fixed(acc_hi[a], acc_lo[a]) : 0.f;
 }
 
@@ -519,7 +528,8 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
             if (m.tab[t].mode != 1 && m.tab[t].vocab * m.tab[t].dim > biggest) biggest = m.tab[t].vocab * m.tab[t].dim;
         const unsigned gx = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(biggest, RB_THREADS), 1024));
         hipLaunchKernelGGL(finalize_dense_kernel, dim3(gx, static_cast<unsigned>(m.n_tables)), dim3(RB_THREADS), 0, st, m,
-                           reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo));
+                           reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo),
+                           p.dense_acc_elems);
     }
     if (m.sparse_start < n) {
         const int64_t work = (n - m.sparse_start) * m.dim_max;
