@@ -19,6 +19,7 @@
 //                                          the batch dimension m is split over waves, partial tiles are
 //                                          written to a workspace and summed in fixed order
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -231,6 +232,171 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_lds_kernel(const GemmK
     rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
 }
 
+// ---- bf16 x 3 split variant ("x6"): every fp32 operand is split exactly into three bf16 pieces x = h + m + l
+// (8 + 8 + 8 significant bits) and the product is rebuilt from the six partial products that matter,
+//     a b ~= ah bh + ah bm + am bh + ah bl + al bh + am bm            (dropped terms are <= 2^-24 |a b|),
+// each one a bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate, exact bf16 x bf16 products).  Six bf16 MFMAs cover
+// 16 k in 6 x 32 cycles where the f32 MFMA needs 8 x 64: 2.7x the matrix rate at fp32-class accuracy, which is what the
+// 1e-4 logit bar needs (a plain bf16 product misses it by two orders of magnitude).
+// Structure as the LDS kernel above: B (weights, [N, K] only) split once per workgroup while it is staged into LDS as
+// three bf16 planes [plane][col][k]; A split in registers after its 16-byte loads.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define X6_KC 32                        // k per chunk (2 MFMA groups of 16)
+#define X6_PITCH 40                     // bf16 per LDS row: 32 + 8 pad -> 80-byte pitch, conflict-free ds_read_b128
+
+struct Bf3 {
+    __bf16 h, m, l;
+};
+__device__ __forceinline__ Bf3 split3(float x) {
+    Bf3 r;
+    r.h = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(r.h);
+    r.m = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(r.m);
+    r.l = static_cast<__bf16>(r2);
+    return r;
+}
+#define SPLIT3_INTO(x, H, M, L, idx)       \
+    do {                                   \
+        const Bf3 s3_ = split3(x);         \
+        H[idx] = s3_.h;                    \
+        M[idx] = s3_.m;                    \
+        L[idx] = s3_.l;                    \
+    } while (0)
+
+template <int NT, bool PRO>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD
+    constexpr int NCOL = NT * 32;
+    constexpr int PLANE = NCOL * X6_PITCH;              // bf16 elements per plane
+    constexpr int F4 = NCOL * X6_KC / 4;                // float4 of W per chunk
+    constexpr int F4_PER_THREAD = (F4 + GEMM_THREADS - 1) / GEMM_THREADS;
+    extern __shared__ __attribute__((aligned(16))) __bf16 Bx[];     // [3 planes][NCOL][X6_PITCH], ONE buffer (38 KB at NT = 5:
+                                                                    // two workgroups per CU; the refill costs two barriers per chunk)
+    const swr_gemm_args& a = kk.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, s = lane >> 5;
+    const int g = blockIdx.z;
+    const int64_t tile_m = static_cast<int64_t>(blockIdx.x) * GEMM_WAVES + wave;
+    const int64_t m0 = tile_m * 32;
+    const int n0 = blockIdx.y * NCOL;
+    const int K = a.K, N = a.N;
+    const float* __restrict__ Ag = a.A + g * a.gsA;
+    const float* __restrict__ Bg = a.B + g * a.gsB;
+    const int64_t ra = max<int64_t>(0, min(m0 + i, a.M - 1));
+    const float* __restrict__ arow = Ag + ra * a.lda;
+    const float* __restrict__ psc = PRO ? a.a_scale + g * a.gsScale : nullptr;
+    const float* __restrict__ psh = PRO ? a.a_shift + g * a.gsScale : nullptr;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto ld4c = [&](const float* __restrict__ row, int k) -> float4 {      // k % 4 == 0; zero when k >= K
+        const float4 v = *reinterpret_cast<const float4*>(row + min(k, K - 4));
+        const bool ok = k < K;
+        return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    };
+    // ---- B staging: fp32 global -> registers (a chunk ahead) -> split -> three bf16 planes in LDS
+    float4 stage[F4_PER_THREAD];
+    auto stage_load = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < F4_PER_THREAD; ++u) {
+            const int q = min(static_cast<int>(threadIdx.x) + u * GEMM_THREADS, F4 - 1);
+            const int n = min(n0 + (q >> 3), N - 1);
+            stage[u] = ld4c(Bg + static_cast<int64_t>(n) * a.ldb, kc + 4 * (q & 7));
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < F4_PER_THREAD; ++u) {
+            const int q = threadIdx.x + u * GEMM_THREADS;
+            if (q < F4) {
+                const int n = q >> 3, kq = 4 * (q & 7);
+                bf16x4 h, m, l;
+                SPLIT3_INTO(stage[u].x, h, m, l, 0);
+                SPLIT3_INTO(stage[u].y, h, m, l, 1);
+                SPLIT3_INTO(stage[u].z, h, m, l, 2);
+                SPLIT3_INTO(stage[u].w, h, m, l, 3);
+                __bf16* d = Bx + n * X6_PITCH + kq;
+                *reinterpret_cast<bf16x4*>(d) = h;
+                *reinterpret_cast<bf16x4*>(d + PLANE) = m;
+                *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = l;
+            }
+        }
+    };
+
+    // ---- A ring: 8 fp32 (two float4) per 16-k group per lane, DEPTH groups (two chunks) in flight
+    constexpr int DEPTH = 4;
+    float4 ar[DEPTH][2];
+    auto a_load = [&](int gi, float4 (&dst)[2]) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int k = 16 * gi + 8 * s + 4 * hh;
+            float4 v = ld4c(arow, k);
+            if (PRO) {
+                const float4 sc = ld4c(psc, k), sh = ld4c(psh, k);
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                if (a.a_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            dst[hh] = v;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) a_load(d, ar[d]);
+
+    stage_load(0);
+    stage_store();
+    __syncthreads();
+    const int n_chunks = (K + X6_KC - 1) / X6_KC;
+    auto b_read = [&](bf16x8 (&bf)[3], int gq, int t) {
+        const __bf16* bp = Bx + (32 * t + i) * X6_PITCH + 16 * gq + 8 * s;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(bp + p * PLANE);
+    };
+    auto do_chunk = [&](int c, auto half) {
+        constexpr int HALF = decltype(half)::value;
+        stage_load((c + 1) * X6_KC);                   // beyond K this loads zeros (never stored)
+#pragma unroll
+        for (int gq = 0; gq < X6_KC / 16; ++gq) {
+            const float4 (&av)[2] = ar[gq + HALF * (DEPTH / 2)];
+            bf16x8 ah, am, al;
+            SPLIT3_INTO(av[0].x, ah, am, al, 0); SPLIT3_INTO(av[0].y, ah, am, al, 1);
+            SPLIT3_INTO(av[0].z, ah, am, al, 2); SPLIT3_INTO(av[0].w, ah, am, al, 3);
+            SPLIT3_INTO(av[1].x, ah, am, al, 4); SPLIT3_INTO(av[1].y, ah, am, al, 5);
+            SPLIT3_INTO(av[1].z, ah, am, al, 6); SPLIT3_INTO(av[1].w, ah, am, al, 7);
+            bf16x8 b0[3], b1[3];
+            b_read(b0, gq, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bf16x8 (&cur)[3] = (t & 1) ? b1 : b0;
+                bf16x8 (&nxt)[3] = (t & 1) ? b0 : b1;
+                if (t + 1 < NT) b_read(nxt, gq, t + 1);
+                __builtin_amdgcn_sched_barrier(0);      // next tile's LDS reads are issued before this tile's MFMAs
+                f32x16 c_ = acc[t];
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cur[0], c_, 0, 0, 0);     // small terms first
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[2], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[1], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[0], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[1], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[0], c_, 0, 0, 0);
+                acc[t] = c_;
+            }
+            a_load(c * (X6_KC / 16) + gq + DEPTH, ar[gq + HALF * (DEPTH / 2)]);
+        }
+        __syncthreads();                       // every wave is done reading this chunk's planes
+        if (c + 1 < n_chunks) stage_store();
+        __syncthreads();
+    };
+    for (int c = 0; c < n_chunks; c += 2) {
+        do_chunk(c, std::integral_constant<int, 0>{});
+        if (c + 1 < n_chunks) do_chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
+}
+
 // NT output tiles (32 columns each) per wave; BT: B is [N, K] (nt) else [K, N] (nn)
 template <int NT, bool BT, bool VEC, bool PRO>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_kernel(const GemmK kk) {
@@ -363,6 +529,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_kernel(const GemmK kk)
     rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
 }
 
+// SWR_GEMM=f32 forces the f32-MFMA kernels (default: bf16x3-split "x6" kernels where applicable)
+static bool use_x6() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SWR_GEMM");
+        v = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <bool BT>
 static int launch_rows(const swr_gemm_args* args, void* stream) {
     SWR_REQUIRE(args != nullptr, SWR_ERR_ARG);
@@ -386,10 +562,14 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(kk.n_tiles_m, GEMM_WAVES)), static_cast<unsigned>(nblk),
                     static_cast<unsigned>(a.groups));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool x6_ok = BT && lds_ok && use_x6();
+#define X6_BYTES(NTV) static_cast<unsigned>(3 * (NTV) * 32 * X6_PITCH * 2)
 #define LDS_BYTES(NTV) static_cast<unsigned>(2 * LDS_KC * ((NTV) * 32 + 4) * sizeof(float))
 #define GO(NTV)                                                                                                   \
     do {                                                                                                          \
-        if (lds_ok && pro) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, true>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk);   \
+        if (x6_ok && pro) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, true>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
+        else if (x6_ok) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, false>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
+        else if (lds_ok && pro) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, true>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk);   \
         else if (lds_ok) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, false>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk); \
         else if (vec && pro) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, true>), grid, dim3(GEMM_THREADS), 0, st, kk);   \
         else if (vec) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, false>), grid, dim3(GEMM_THREADS), 0, st, kk);    \
@@ -408,6 +588,7 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     }
 #undef GO
 #undef LDS_BYTES
+#undef X6_BYTES
     return swr_launch_status();
 }
 

@@ -371,7 +371,12 @@ class LinearBNAct(Function):
                 gemm("nn", dZ, W, dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
             else:
                 dx = torch.empty((M, _pad4(K)), dtype=torch.float32, device=dev)
-                gemm("nn", dZ, W, dx, M, K, Ntot)
+                if Ntot % 4 == 0 and K >= 32:
+                    # dX = dZ @ W as an "nt" product against the transposed weights (a small copy): the [N, K]
+                    # layout is the one the bf16-split MFMA kernel stages into LDS
+                    gemm("nt", dZ, W.t().contiguous(), dx, M, K, Ntot)
+                else:
+                    gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:
                     dx = dx[:, :K]
         if direct_w:
