@@ -296,7 +296,9 @@ typedef struct {
     float one_minus_b1, b2, one_minus_b2, eps_f, wd_f, pad;
 } swr_adam_hyper;
 
-int swr_adam_advance(swr_adam_hyper* hyper_dev, void* stream);
+/* `hist` (nullable, float [hist_cap][2], device): step s writes its (step_size, inv_bc2_sqrt) to hist[s]; the lazy
+ * row updates below replay them. */
+int swr_adam_advance(swr_adam_hyper* hyper_dev, float* hist, int64_t hist_cap, void* stream);
 /* dense update of a flat fp32 arena */
 int swr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n,
                    const swr_adam_hyper* hyper_dev, void* stream);
@@ -306,10 +308,24 @@ int swr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n,
  * exit) marks touched rows between the two launches. */
 int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int dim,
                   const int32_t* urow, const float* ugrad, int64_t n_entries,
-                  uint32_t* bitmap, const swr_adam_hyper* hyper_dev, void* stream);
+                  uint32_t* bitmap /* sweep mode, nullable */, int32_t* last /* lazy mode, nullable */,
+                  const swr_adam_hyper* hyper_dev, void* stream);
 int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vocab, int dim,
                              uint32_t* bitmap, int clear_bitmap /* 1: zero the bitmap afterwards (normal use) */,
                              const swr_adam_hyper* hyper_dev, void* stream);
+
+/* Lazy but EXACT alternative to the sweep: a row that is not looked up still takes g = weight_decay * p every step,
+ * an update that depends only on the row's own (p, m, v) and the step's scalars -- so it is replayed, bit for bit,
+ * when the row is next looked up (`swr_adam_catchup_rows`, called by the forward lookup before the gather) or when
+ * the table is materialised (`swr_adam_flush`, checkpoints).  `last[vocab]` (int32, zero-initialised) holds the step
+ * each row is current for.  Workspace of catch-up: 8 * n bytes. */
+int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last, int32_t* claim /* [vocab] scratch, any contents */,
+                          int64_t vocab, int dim,
+                          const void* idx, int idx_dtype, uint32_t hash_seed, int64_t n,
+                          const float* hist, const swr_adam_hyper* hyper_dev,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t vocab, int dim,
+                   const float* hist, const swr_adam_hyper* hyper_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,7 @@ class EmbeddingLayer(SwrModule):
 def _new_plan(layer):
     plan = ops._GatherPlan()
     plan.sparse, plan.dense, plan.width = [], [], 0
+    plan.lazy = {}
     plan.dense_limit_bytes = layer.dense_table_limit_bytes
     return plan, []
 
@@ -78,6 +79,9 @@ def _plan_part(plan, weights, wpos, layer, x, sparse, dense):
         if key not in wpos:
             wpos[key] = len(weights)
             weights.append(layer.embed_dict[owner].weight)
+            lazy = getattr(layer.embed_dict[owner].weight, "_swr_lazy", None)
+            if lazy is not None:
+                plan.lazy[wpos[key]] = lazy
         w = weights[wpos[key]]
         plan.sparse.append((wpos[key], x[fea.name], w.shape[0], w.shape[1], col, getattr(fea, "hash_seed", 0)))
         col += w.shape[1]

@@ -107,6 +107,18 @@ class SwrModule(nn.Module):
                 return None
         return a
 
+    def materialize(self):
+        """Bring lazily updated tables (optim.LazyRows) fully up to date; exact, no-op when nothing is pending."""
+        for p in self.parameters():
+            lazy = getattr(p, "_swr_lazy", None)
+            if lazy is not None:
+                lazy.flush()
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        self.materialize()
+        return super().state_dict(*args, **kwargs)
+
     def zero_grad(self, set_to_none=True):
         a = self.arena()
         if a is None:

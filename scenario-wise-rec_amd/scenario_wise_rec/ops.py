@@ -143,7 +143,7 @@ def _split_like(flat, tensors):
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy")
 
 
 class EmbedGather(Function):
@@ -167,6 +167,13 @@ class EmbedGather(Function):
         for i, (vals, col) in enumerate(plan.dense):
             H.require_device(vals)
             dn[i] = H.DenseSlot(vals.data_ptr(), H.dtype_code(vals), col)
+        # lazily updated tables (optim.LazyRows): bring the rows about to be read up to date first (exact replay)
+        seen = set()
+        for wpos, idx, vocab, dim, col, seed in plan.sparse:
+            lazy = getattr(plan, "lazy", {}).get(wpos)
+            if lazy is not None and (wpos, idx.data_ptr()) not in seen:
+                seen.add((wpos, idx.data_ptr()))
+                lazy.catchup(idx, seed)
         need_keys = ctx.n_grad_slots > 0
         keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
         flag = H.err_flag(dev)

@@ -20,13 +20,47 @@ from . import _hip as H
 from ._hip import lib
 
 
+HIST_CAP = 1 << 20          # steps of (step_size, inv_bc2_sqrt) history kept on the device (8 MB)
+
+
+class LazyRows(object):
+    """Optimizer state of one large table under the exact lazy update (csrc/adam.hip, "lazy (exact) row updates"):
+    `last[row]` = the step the row is current for.  Attached to the parameter as `_swr_lazy`, so the forward lookup
+    can bring the rows it is about to read up to date, and `state_dict()` can materialise the table."""
+
+    def __init__(self, p, hist, hyper):
+        self.p = p
+        self.m = torch.zeros_like(p)
+        self.v = torch.zeros_like(p)
+        self.last = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+        self.claim = torch.empty(p.shape[0], dtype=torch.int32, device=p.device)      # ticket scratch of the catch-up
+        self.hist, self.hyper = hist, hyper
+
+    def catchup(self, idx, hash_seed=0):
+        """Replay the pending decay-only updates of the rows `idx` refers to (ids, any integer dtype; -1 = skip)."""
+        idx = idx.contiguous()
+        n = idx.numel()
+        ws = torch.empty(max(n, 1) * 8, dtype=torch.uint8, device=idx.device)
+        p = self.p
+        H.check(lib.swr_adam_catchup_rows(H.ptr(p), H.ptr(self.m), H.ptr(self.v), H.ptr(self.last), H.ptr(self.claim), p.shape[0], p.shape[1],
+                                          H.ptr(idx), H.dtype_code(idx), hash_seed, n, H.ptr(self.hist), H.ptr(self.hyper),
+                                          H.ptr(ws), ws.numel(), H.stream()), "swr_adam_catchup_rows")
+
+    def flush(self):
+        """Materialise every row (checkpoints, direct reads of the table)."""
+        p = self.p
+        H.check(lib.swr_adam_flush(H.ptr(p), H.ptr(self.m), H.ptr(self.v), H.ptr(self.last), p.shape[0], p.shape[1],
+                                   H.ptr(self.hist), H.ptr(self.hyper), H.stream()), "swr_adam_flush")
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_rows=True):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
-        self._hyper = {}        # group index -> (device uint8 tensor holding swr_adam_hyper, uploaded host copy)
+        self.lazy_rows = lazy_rows
+        self._hyper = {}        # group index -> [device swr_adam_hyper, uploaded host copy, hist, host step count]
         self._mv = {}           # storage ptr -> (m_flat, v_flat) shadowing a parameter storage
-        self._big = {}          # id(param) -> (m, v, bitmap)
+        self._big = {}          # id(param) -> (m, v, bitmap)   (sweep mode)  |  LazyRows  (lazy mode)
 
     # ---- device-side hyper-parameters ---------------------------------------------------------------
     def _hyper_dev(self, gi, group, device):
@@ -36,8 +70,12 @@ class FusedAdam(torch.optim.Optimizer):
         if ent is None:
             h = H.AdamHyper(*want, 0)
             buf = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).to(device)
-            self._hyper[gi] = [buf, want]
+            hist = torch.zeros((HIST_CAP, 2), dtype=torch.float32, device=device) if self.lazy_rows else None
+            self._hyper[gi] = [buf, want, hist, 0]
         elif ent[1] != want:
+            if self.lazy_rows and ent[1][1:] != want[1:]:
+                # betas / eps / weight_decay changed: pending lazy updates belong to the old values
+                self.materialize()
             # lr (scheduler) or another hyper-parameter changed on the host: refresh the five doubles, keep the step
             host = torch.tensor(want, dtype=torch.float64).view(torch.uint8)
             ent[0][:40].copy_(host.to(device))
@@ -55,6 +93,20 @@ class FusedAdam(torch.optim.Optimizer):
         off = (p.data_ptr() - key) // 4
         m, v = self._mv[key]
         return m[off:off + p.numel()], v[off:off + p.numel()], key
+
+    def _lazy_state(self, p, hist, hyper):
+        st = self._big.get(id(p))
+        if st is None:
+            st = self._big[id(p)] = LazyRows(p, hist, hyper)
+            p._swr_lazy = st
+        return st
+
+    @torch.no_grad()
+    def materialize(self):
+        """Bring every lazily updated table fully up to date (exact); cheap no-op when nothing is pending."""
+        for st in self._big.values():
+            if isinstance(st, LazyRows):
+                st.flush()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -76,7 +128,18 @@ class FusedAdam(torch.optim.Optimizer):
             dev = (dense[0] if dense else sparse[0][0]).device
             H.require_device(*(dense[:1] + [s[0] for s in sparse[:1]]))
             hyper = self._hyper_dev(gi, group, dev)
-            H.check(lib.swr_adam_advance(H.ptr(hyper), stream), "swr_adam_advance")
+            ent = self._hyper[gi]
+            hist = ent[2]
+            if self.lazy_rows:
+                for p, (urow, ugrad) in sparse:
+                    # rows that take a gradient must be current BEFORE the step advances: those looked up by this
+                    # rank were caught up by the forward lookup, those that only other ranks touched are caught up here
+                    self._lazy_state(p, hist, hyper).catchup(urow)
+                if ent[3] + 2 >= HIST_CAP:
+                    raise H.SwrError("FusedAdam: step history full; call materialize() and rebuild the optimizer")
+            H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, stream),
+                    "swr_adam_advance")
+            ent[3] += 1
             # contiguous runs: parameter, gradient and state addresses all advance together
             items = []
             for p in dense:
@@ -107,12 +170,18 @@ class FusedAdam(torch.optim.Optimizer):
                 H.check(lib.swr_adam_dense(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
                                            n, H.ptr(hyper), stream), "swr_adam_dense")
             for p, (urow, ugrad) in sparse:
+                if self.lazy_rows:
+                    st = self._lazy_state(p, hist, hyper)
+                    H.check(lib.swr_adam_rows(H.ptr(p), H.ptr(st.m), H.ptr(st.v), p.shape[0], p.shape[1], H.ptr(urow),
+                                              H.ptr(ugrad), urow.numel(), None, H.ptr(st.last), H.ptr(hyper), stream),
+                            "swr_adam_rows")
+                    continue
                 if id(p) not in self._big:
                     self._big[id(p)] = (torch.zeros_like(p), torch.zeros_like(p),
                                         torch.zeros((p.shape[0] + 31) // 32, dtype=torch.int32, device=p.device))
                 m, v, bitmap = self._big[id(p)]
                 H.check(lib.swr_adam_rows(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(urow), H.ptr(ugrad),
-                                          urow.numel(), H.ptr(bitmap), H.ptr(hyper), stream), "swr_adam_rows")
+                                          urow.numel(), H.ptr(bitmap), None, H.ptr(hyper), stream), "swr_adam_rows")
                 H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap), 1,
                                                      H.ptr(hyper), stream), "swr_adam_sweep_untouched")
         return loss
