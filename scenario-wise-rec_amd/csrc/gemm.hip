@@ -597,7 +597,7 @@ extern "C" int swr_gemm_nn(const swr_gemm_args* args, void* stream) { return lau
 
 // ------------------------------------------------------------------------------------------------ tn
 #define TN_TA_MAX 5
-#define TN_TB 2
+#define TN_TB 1
 
 struct TnK {
     swr_gemm_tn_args a;
@@ -608,7 +608,7 @@ struct TnK {
 };
 
 template <int TA>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const TnK kk) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) {   // two waves per SIMD
     // the 4 waves of a workgroup take 4 consecutive row slices of the SAME output tile and are summed in LDS in a
     // fixed tree ((w0 + w1) + (w2 + w3)) before one partial tile per workgroup goes to the workspace
     extern __shared__ __attribute__((aligned(16))) float red[];
