@@ -605,6 +605,7 @@ struct TnK {
     int64_t rows_per_split;   // even
     float* part;              // [groups][splits][K1][K2]
     float* part_cs;           // [groups][splits][K1]  (colsum) or null
+    unsigned qblk, pblk, n_tiles;   // column tiles, row-tile groups, qblk * pblk * zsplit * groups
 };
 
 template <int TA>
@@ -613,14 +614,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) 
     // fixed tree ((w0 + w1) + (w2 + w3)) before one partial tile per workgroup goes to the workspace
     extern __shared__ __attribute__((aligned(16))) float red[];
     const swr_gemm_tn_args& a = kk.a;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR
     const int i = lane & 31, s = lane >> 5;
     const int zsplit = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
-    const int part = blockIdx.z % zsplit;
-    const int g = blockIdx.z / zsplit;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so id -> (id % 8) * (n / 8) + id / 8 puts
+    // the workgroups that share one row slice of A (all column tiles q, then all row tiles p) on ONE XCD's L2
+    const unsigned per_xcd = gridDim.x / 8;
+    const unsigned lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (lin >= kk.n_tiles) return;
+    const int bq = lin % kk.qblk, bp = (lin / kk.qblk) % kk.pblk, bz = lin / (kk.qblk * kk.pblk);
+    const int part = bz % zsplit;
+    const int g = bz / zsplit;
     const int split = part * GEMM_WAVES + wave;
-    const int p0 = blockIdx.y * (32 * TA);
-    const int q0 = blockIdx.x * (32 * TN_TB);
+    const int p0 = bp * (32 * TA);
+    const int q0 = bq * (32 * TN_TB);
     const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
     const int64_t me = min(ms + kk.rows_per_split, a.M);
 
@@ -648,39 +655,54 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) 
         float a[TA];
         float b[TN_TB];
     };
-    // main loop without predicates: columns beyond K1 / K2 are clamped (their products are never stored)
-    auto load_frag = [&](int64_t mb, Frag& f) {               // rows mb, mb + 1 both valid
-        const int64_t m = mb + s;
+    // main loop without predicates: columns beyond K1 / K2 are clamped (their products are never stored).
+    // Addressing = wave-uniform row-pair base (SGPR pair, advanced by scalar adds) + a fixed 32-bit lane offset
+    // (slot * ld + column): one global_load per operand with no per-load 64-bit vector arithmetic.
+    uint32_t offa[TA], offb[TN_TB];
 #pragma unroll
-        for (int t = 0; t < TA; ++t) f.a[t] = Ag[m * a.lda + ca[t]];
+    for (int t = 0; t < TA; ++t) offa[t] = static_cast<uint32_t>(s * a.lda + ca[t]);
 #pragma unroll
-        for (int t = 0; t < TN_TB; ++t) f.b[t] = Bg[m * a.ldb + cb[t]];
+    for (int t = 0; t < TN_TB; ++t) offb[t] = static_cast<uint32_t>(s * a.ldb + cb[t]);
+    auto load_frag = [&](int64_t mb, Frag& f) {               // rows mb, mb + 1 both valid; mb wave-uniform
+        const float* __restrict__ ra = Ag + mb * a.lda;
+        const float* __restrict__ rb = Bg + mb * a.ldb;
+#pragma unroll
+        for (int t = 0; t < TA; ++t) f.a[t] = ra[offa[t]];
+#pragma unroll
+        for (int t = 0; t < TN_TB; ++t) f.b[t] = rb[offb[t]];
     };
     auto mma_frag = [&](const Frag& f) {
-#pragma unroll
-        for (int t = 0; t < TA; ++t) cs[t] += f.a[t];
 #pragma unroll
         for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
             for (int tb = 0; tb < TN_TB; ++tb)
                 acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[ta], f.b[tb], acc[ta][tb], 0, 0, 0);
+        // column sums as opaque scalar adds: left to the SLP vectoriser they become v_pk_add_f32 on register pairs
+        // assembled with v_mov from freshly loaded ring slots, which forces a wait on nearly every load in flight
+#pragma unroll
+        for (int t = 0; t < TA; ++t) asm volatile("v_add_f32 %0, %0, %1" : "+v"(cs[t]) : "v"(f.a[t]));
     };
     const int64_t me2 = ms + ((me - ms) / 2) * 2;              // rows taken in pairs
-    {
-        // ring of TN_DEPTH register sets (7 dwords each): the next TN_DEPTH-1 row pairs are in flight
-        constexpr int DEPTH = 4;
-        const int64_t n_pairs = (me2 - ms) / 2;
+    // wave-uniform trip count in an SGPR: the loop control is scalar and the loads of the main loop are
+    // unconditional (pair index clamped to the last valid pair), so the compiler can keep DEPTH-1 row pairs in flight
+    // with exact vmcnt waits instead of draining the queue at every conditional load
+    const int n_pairs = __builtin_amdgcn_readfirstlane(static_cast<int>((me2 - ms) / 2));
+    if (n_pairs > 0) {
+        constexpr int DEPTH = 6;
+        const int last = n_pairs - 1;
         Frag f[DEPTH];
 #pragma unroll
-        for (int d = 0; d < DEPTH - 1; ++d)
-            if (d < n_pairs) load_frag(ms + 2 * d, f[d]);
-        int64_t pi = 0;
+        for (int d = 0; d < DEPTH - 1; ++d) load_frag(ms + 2 * static_cast<int64_t>(min(d, last)), f[d]);
+        int pi = 0;
         for (; pi + DEPTH <= n_pairs; pi += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
-                const int64_t nxt = pi + d + DEPTH - 1;
-                if (nxt < n_pairs) load_frag(ms + 2 * nxt, f[(d + DEPTH - 1) % DEPTH]);
+                // the scheduler must not sink the loads or hoist the products across a ring step (it otherwise
+                // shortens the prefetch distance to ~1 step to save registers)
+                load_frag(ms + 2 * static_cast<int64_t>(min(pi + d + DEPTH - 1, last)), f[(d + DEPTH - 1) % DEPTH]);
+                __builtin_amdgcn_sched_barrier(0);
                 mma_frag(f[d]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -739,7 +761,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) 
                 if (p < a.K1 && q < a.K2) P[static_cast<int64_t>(p) * a.K2 + q] = acc[ta][tb][r];
             }
         }
-    if (kk.part_cs && blockIdx.x == 0) {
+    if (kk.part_cs && bq == 0) {
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             float tot = ((csr[(0 * TA + t) * 64 + lane] + csr[(1 * TA + t) * 64 + lane]) +
@@ -835,8 +857,10 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
     kk.part = static_cast<float*>(workspace);
     kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(a.groups) * kk.splits * a.K1 * a.K2 : nullptr;
     const int zsplit = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.K2, 32 * TN_TB)), static_cast<unsigned>(pblk),
-                    static_cast<unsigned>(zsplit * a.groups));
+    kk.qblk = static_cast<unsigned>(swr_ceil_div(a.K2, 32 * TN_TB));
+    kk.pblk = static_cast<unsigned>(pblk);
+    kk.n_tiles = kk.qblk * kk.pblk * static_cast<unsigned>(zsplit * a.groups);
+    const dim3 grid((kk.n_tiles + 7) / 8 * 8);
 #define TN_LDS(TAV) static_cast<unsigned>(((TAV) * TN_TB * 16 * 64 + 4 * (TAV) * 64) * sizeof(float))
     switch (ta) {
         case 1: hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(GEMM_THREADS), TN_LDS(1), st, kk); break;
