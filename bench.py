@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the stand-alone kernel timing leg")
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids for the large tables (worst case for the gather)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -243,7 +244,7 @@ def main():
 
     # ---- roofline of the dominant kernel (see DESIGN.md "Measurement") ------------------------------------
     print(f"[bench] timed region done: {ms:.3f} ms/step", file=sys.stderr, flush=True)
-    roof = measure_roofline(cfg, model, trainer, x, dev, args.steps)
+    roof = None if args.no_roofline else measure_roofline(cfg, model, trainer, x, dev, args.steps)
     out = {
         "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

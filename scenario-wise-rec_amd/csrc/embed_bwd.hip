@@ -1,17 +1,20 @@
 // K3: backward of the embedding lookup for ALL features of a batch at once
 // (replaces F_s x aten::embedding_dense_backward).
 //
-//   1. build_keys : entries (row, slot << 24 | sample) written grouped by table (one segment per table)
+//   0. direct     : lookups of SMALL dense-gradient tables (<= DIRECT_MAX_PARTS x 64 KB of accumulators) skip the
+//                   sort: a workgroup owns a span of adjacent lookup columns and a chunk of samples, adds the
+//                   fixed-point gradients into LDS accumulators (ds_add_u64) and flushes the non-zero ones
+//   1. build_keys : the other entries (row, slot << 24 | sample) written grouped by table (one segment per table)
 //   2. sort       : segmented LSD radix sort of every table segment by row, 8 bits per pass, stable; pass p
 //                   only does work for tables whose row ids need more than 8p bits (others copy through).
 //                   Hand-written (histogram -> per-table scan -> ranked scatter), no atomics on global
 //                   memory, no memset nodes, no inter-workgroup spinning: safe to capture and replay.
-//   3. reduce     : each group of LPE lanes walks a fixed chunk of CHUNK sorted entries of one table, sums
+//   3. reduce     : each group of LPE lanes walks a fixed chunk of 8-32 sorted entries of one table, sums
 //                   runs of equal rows in registers and flushes each run (plain stores for runs that lie
 //                   inside the chunk, two 64-bit integer atomics for runs cut by a chunk boundary)
 //   4. finalise   : integer accumulators -> fp32 gradients (dense tables) or per-row entries (sparse)
 //
-// Accumulation is dual-limb fixed point: x * 2^20 = hi + frac, hi in 2^-20 units, frac kept in 2^-60
+// Accumulation is dual-limb fixed point: x * 2^60 (truncated) = hi * 2^40 + lo, hi in 2^-20 units, lo in 2^-60
 // units.  Both limbs are integers, so the sum is exact (to 2^-60) and independent of the order in which
 // runs, chunks and workgroups meet: bitwise deterministic, identical on every data-parallel rank.
 // Representable range |x| < 2^20 (flagged otherwise); sums of up to 2^22 entries per row cannot overflow.
@@ -24,13 +27,41 @@
 #include "common.h"
 
 #define MAX_SLOTS 40   // BwdMeta travels by value in the kernarg segment (4 KiB)
-#define CHUNK 32
+#define CHUNK_MAX 32     // sorted entries per reduce walker; 8 / 16 when there are few entries
 #define RB_THREADS 256
 #define ACC_STRIPES 16   // copies of the dense accumulators: chunk c adds into stripe c % 16, so a hot row of a tiny
                        // table (V = 2: 1000+ partial runs per row) does not serialise its atomics on one address
 #define SORT_THREADS 256
-#define SORT_ITEMS 8
-#define SORT_TILE (SORT_THREADS * SORT_ITEMS)
+#define SORT_ITEMS_MAX 8   // keys per thread and tile; fewer when there are few keys (more, smaller tiles fill the chip)
+
+#define DIRECT_THREADS 512
+#define DIRECT_CAP_ELEMS 4096     // (hi, lo) int64 accumulator pairs per workgroup = 64 KB of LDS, 2 workgroups per CU
+#define DIRECT_MAX_PARTS 8        // a table larger than the cap is cut into row ranges, one workgroup column each
+#define DIRECT_MAX_MEMBERS 72
+#define DIRECT_MAX_GROUPS 48
+#define DIRECT_TARGET 32768       // (sample, column) elements per workgroup
+
+struct DirectMember {
+    int64_t acc_off;      // dense accumulator offset of (row_lo, column 0) of the member's table
+    int32_t col;          // first column of the lookup in dE
+    int32_t row_lo, rows; // row range accumulated by this member
+    int32_t lds_off;      // first LDS accumulator element
+    int16_t dim, slot;
+    int32_t pad;
+};
+struct DirectGroup {
+    int32_t col0, width;  // contiguous column span of dE
+    int32_t chunk;        // samples per workgroup
+    int32_t block0;       // first workgroup of the group
+    int16_t member0, n_members;
+    int32_t elems;        // LDS accumulator elements
+};
+struct DirectMeta {
+    DirectMember mem[DIRECT_MAX_MEMBERS];
+    DirectGroup grp[DIRECT_MAX_GROUPS];
+    int32_t n_groups, n_blocks, n_members, pad;
+    int64_t B;
+};
 
 struct TableMeta {
     int64_t vocab;
@@ -49,10 +80,12 @@ struct BwdMeta {
     int32_t slot_dim[MAX_SLOTS];
     int64_t slot_dst[MAX_SLOTS];     // where this slot's B entries start inside its table segment
     int32_t chunk_off[MAX_SLOTS + 1];   // first reduce chunk of each table
+    int16_t sorted_slot[MAX_SLOTS];     // the slots that go through the sort (the others take the direct path)
+    int32_t n_sorted_slots;
     int32_t n_slots, n_tables;
     int32_t dim_max;
-    int32_t pad;
-    int64_t B, n;
+    int32_t chunk;          // sorted entries per reduce walker
+    int64_t B, n;           // n = number of SORTED entries (n_sorted_slots * B)
     int64_t sparse_start;   // first sorted position belonging to a sparse-mode table
 };
 
@@ -62,11 +95,14 @@ struct SortMeta {
     int32_t passes[MAX_SLOTS];
     int32_t n_tables;
     int32_t n_tiles;
+    int32_t items;        // keys per thread of a tile
+    int32_t tile;         // SORT_THREADS * items
 };
 
 struct HostPlan {
     BwdMeta m;
     SortMeta sm;
+    DirectMeta dm;
     int64_t dense_acc_elems;
     int64_t sparse_acc_elems;
     size_t off_k0, off_k1, off_v0, off_v1, off_hist, off_acc_hi, off_acc_lo, total;
@@ -87,7 +123,6 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     BwdMeta& m = p.m;
     m.n_slots = n_slots;
     m.B = B;
-    m.n = static_cast<int64_t>(n_slots) * B;
     int n_tables = 0;
     int dim_max = 1;
     for (int s = 0; s < n_slots; ++s) {
@@ -114,14 +149,49 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         } else {
             SWR_REQUIRE(t.vocab == sl.vocab && t.dim == sl.dim && t.mode == sl.mode, SWR_ERR_ARG);
         }
-        m.slot_dst[s] = count[sl.table_id];          // offset inside the table segment (segment base added below)
-        count[sl.table_id] += B;
         m.slot_col[s] = sl.in_col;
         m.slot_dim[s] = sl.dim;
         if (sl.dim > dim_max) dim_max = sl.dim;
     }
+    // ---- direct path: which tables, and the workgroup layout (groups of adjacent lookup columns x sample chunks)
+    bool direct[MAX_SLOTS] = {false};
+    DirectMeta& dm = p.dm;
+    dm.n_groups = dm.n_blocks = dm.n_members = 0;
+    dm.B = B;
+    {
+        int need_members = 0, need_groups = 0;     // worst case: one group per member
+        for (int t = 0; t < n_tables; ++t) {
+            if (!seen[t] || m.tab[t].mode == 1 || m.tab[t].dim > DIRECT_THREADS) continue;
+            const int64_t elems = m.tab[t].vocab * m.tab[t].dim;
+            if (elems > static_cast<int64_t>(DIRECT_CAP_ELEMS) * DIRECT_MAX_PARTS || m.tab[t].dim > DIRECT_CAP_ELEMS) continue;
+            int uses = 0;
+            for (int s = 0; s < n_slots; ++s) uses += slots[s].table_id == t;
+            const int parts = static_cast<int>(swr_ceil_div(elems, DIRECT_CAP_ELEMS));
+            if (need_members + uses * parts > DIRECT_MAX_MEMBERS || need_groups + uses * parts > DIRECT_MAX_GROUPS) continue;
+            need_members += uses * parts;
+            need_groups += uses * parts;
+            direct[t] = true;
+        }
+    }
+    m.n_sorted_slots = 0;
+    for (int s = 0; s < n_slots; ++s) {
+        const int t = slots[s].table_id;
+        if (direct[t]) continue;
+        m.sorted_slot[m.n_sorted_slots++] = static_cast<int16_t>(s);
+        m.slot_dst[s] = count[t];                    // offset inside the table segment (segment base added below)
+        count[t] += B;
+    }
+    m.n = static_cast<int64_t>(m.n_sorted_slots) * B;
     int64_t acc = 0, pos = 0;
     int tiles = 0, chunks = 0, passes = 0;
+    // few sorted entries: smaller sort tiles and reduce chunks, so that the launch still covers the chip and the
+    // per-walker dependent-load chain stays short
+    int items = SORT_ITEMS_MAX;
+    while (items > 1 && m.n / (SORT_THREADS * items) < 512) items >>= 1;
+    p.sm.items = items;
+    p.sm.tile = SORT_THREADS * items;
+    m.chunk = CHUNK_MAX;
+    while (m.chunk > 8 && m.n / m.chunk < 16384) m.chunk >>= 1;
     m.sparse_start = -1;
     for (int t = 0; t < n_tables; ++t) {
         SWR_REQUIRE(seen[t], SWR_ERR_ARG);                       // table ids must be dense 0..n_tables-1
@@ -138,13 +208,64 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         p.sm.seg_off[t] = pos;
         p.sm.tile_off[t] = tiles;
         p.sm.passes[t] = (bits_for(static_cast<uint64_t>(tm.vocab - 1)) + 7) / 8;
-        if (p.sm.passes[t] > passes) passes = p.sm.passes[t];
+        if (count[t] > 0 && p.sm.passes[t] > passes) passes = p.sm.passes[t];
         m.chunk_off[t] = chunks;
-        tiles += static_cast<int>(swr_ceil_div(count[t], SORT_TILE));
-        chunks += static_cast<int>(swr_ceil_div(count[t], CHUNK));
+        tiles += static_cast<int>(swr_ceil_div(count[t], p.sm.tile));
+        chunks += static_cast<int>(swr_ceil_div(count[t], m.chunk));
         pos += count[t];
     }
-    for (int s = 0; s < n_slots; ++s) m.slot_dst[s] += m.tab[slots[s].table_id].sorted_off;
+    for (int s = 0; s < n_slots; ++s)
+        if (!direct[slots[s].table_id]) m.slot_dst[s] += m.tab[slots[s].table_id].sorted_off;
+    // direct groups (needs the accumulator offsets assigned above)
+    {
+        int open = -1;                               // group still accepting adjacent small lookups
+        auto new_group = [&](int col0) {
+            DirectGroup& g = dm.grp[dm.n_groups];
+            g.col0 = col0; g.width = 0; g.member0 = static_cast<int16_t>(dm.n_members); g.n_members = 0; g.elems = 0;
+            return dm.n_groups++;
+        };
+        auto add_member = [&](int gi, int s, int row_lo, int rows) {
+            const TableMeta& tm = m.tab[slots[s].table_id];
+            DirectGroup& g = dm.grp[gi];
+            DirectMember& mb = dm.mem[dm.n_members++];
+            mb.acc_off = tm.acc_off + static_cast<int64_t>(row_lo) * tm.dim;
+            mb.col = slots[s].in_col; mb.row_lo = row_lo; mb.rows = rows; mb.lds_off = g.elems;
+            mb.dim = static_cast<int16_t>(tm.dim); mb.slot = static_cast<int16_t>(s); mb.pad = 0;
+            g.elems += rows * tm.dim;
+            g.width += tm.dim;
+            g.n_members++;
+        };
+        for (int s = 0; s < n_slots; ++s) {
+            const int t = slots[s].table_id;
+            if (!direct[t]) { open = -1; continue; }
+            const TableMeta& tm = m.tab[t];
+            const int64_t elems = tm.vocab * tm.dim;
+            if (elems > DIRECT_CAP_ELEMS) {          // row ranges, one single-member group each
+                const int parts = static_cast<int>(swr_ceil_div(elems, DIRECT_CAP_ELEMS));
+                const int rpp = static_cast<int>(swr_ceil_div(tm.vocab, parts));
+                for (int r0 = 0; r0 < tm.vocab; r0 += rpp)
+                    add_member(new_group(slots[s].in_col), s, r0, static_cast<int>(std::min<int64_t>(rpp, tm.vocab - r0)));
+                open = -1;
+                continue;
+            }
+            if (open >= 0) {
+                const DirectGroup& g = dm.grp[open];
+                if (g.col0 + g.width != slots[s].in_col || g.elems + elems > DIRECT_CAP_ELEMS ||
+                    g.width + tm.dim > DIRECT_THREADS)
+                    open = -1;
+            }
+            if (open < 0) open = new_group(slots[s].in_col);
+            add_member(open, s, 0, static_cast<int>(tm.vocab));
+        }
+        int blocks = 0;
+        for (int gi = 0; gi < dm.n_groups; ++gi) {
+            DirectGroup& g = dm.grp[gi];
+            g.chunk = static_cast<int32_t>(std::min<int64_t>(B, std::max<int64_t>(64, DIRECT_TARGET / g.width)));
+            g.block0 = blocks;
+            blocks += static_cast<int>(swr_ceil_div(B, g.chunk));
+        }
+        dm.n_blocks = blocks;
+    }
     p.sm.seg_off[n_tables] = pos;
     p.sm.tile_off[n_tables] = tiles;
     p.sm.n_tables = n_tables;
@@ -176,10 +297,10 @@ __global__ __launch_bounds__(RB_THREADS) void build_keys_kernel(const BwdMeta m,
                                                                 uint32_t* __restrict__ ck, uint32_t* __restrict__ val) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x;
     if (i >= m.n) return;
-    const int slot = static_cast<int>(i / m.B);
-    const int64_t b = i - static_cast<int64_t>(slot) * m.B;
+    const int slot = m.sorted_slot[i / m.B];
+    const int64_t b = i % m.B;
     const int64_t dst = m.slot_dst[slot] + b;
-    ck[dst] = keys[i];
+    ck[dst] = keys[static_cast<int64_t>(slot) * m.B + b];
     val[dst] = (static_cast<uint32_t>(slot) << 24) | static_cast<uint32_t>(b);
 }
 
@@ -197,8 +318,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const SortMeta 
     const int tile = blockIdx.x;
     const int t = sort_table_of_tile(sm, tile);
     if (pass >= sm.passes[t]) return;
-    const int64_t start = sm.seg_off[t] + static_cast<int64_t>(tile - sm.tile_off[t]) * SORT_TILE;
-    const int len = static_cast<int>(min<int64_t>(SORT_TILE, sm.seg_off[t + 1] - start));
+    const int64_t start = sm.seg_off[t] + static_cast<int64_t>(tile - sm.tile_off[t]) * sm.tile;
+    const int len = static_cast<int>(min<int64_t>(sm.tile, sm.seg_off[t + 1] - start));
     lh[threadIdx.x] = 0;
     __syncthreads();
     for (int e = threadIdx.x; e < len; e += SORT_THREADS) atomicAdd(&lh[(kin[start + e] >> (8 * pass)) & 255u], 1u);
@@ -222,7 +343,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void sort_scan_kernel(const SortMeta 
     const int qa = t0 + min(q * per, nt), qb = t0 + min((q + 1) * per, nt);
     // pass 1: per-quarter totals of this digit
     uint32_t run = 0;
-    for (int tile = qa; tile < qb; ++tile) run += hist[static_cast<int64_t>(tile) * 256 + d];
+    {
+        int tile = qa;
+        for (; tile + 8 <= qb; tile += 8) {              // 8 independent loads in flight, then the adds
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = hist[static_cast<int64_t>(tile + k) * 256 + d];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) run += v[k];
+        }
+        for (; tile < qb; ++tile) run += hist[static_cast<int64_t>(tile) * 256 + d];
+    }
     partial[q][d] = run;
     __syncthreads();
     uint32_t before = 0, total = 0;
@@ -245,7 +376,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void sort_scan_kernel(const SortMeta 
     const uint32_t digit_base = static_cast<uint32_t>(sm.seg_off[t]) + (tot[d] - total);
     // pass 2: exclusive running offsets inside the quarter
     uint32_t off = digit_base + before;
-    for (int tile = qa; tile < qb; ++tile) {
+    int tile = qa;
+    for (; tile + 8 <= qb; tile += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = hist[static_cast<int64_t>(tile + k) * 256 + d];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hist[static_cast<int64_t>(tile + k) * 256 + d] = off;
+            off += v[k];
+        }
+    }
+    for (; tile < qb; ++tile) {
         const uint32_t c = hist[static_cast<int64_t>(tile) * 256 + d];
         hist[static_cast<int64_t>(tile) * 256 + d] = off;
         off += c;
@@ -261,8 +403,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const SortMe
     __shared__ uint32_t wc[SORT_THREADS / 64][256];
     const int tile = blockIdx.x;
     const int t = sort_table_of_tile(sm, tile);
-    const int64_t start = sm.seg_off[t] + static_cast<int64_t>(tile - sm.tile_off[t]) * SORT_TILE;
-    const int len = static_cast<int>(min<int64_t>(SORT_TILE, sm.seg_off[t + 1] - start));
+    const int64_t start = sm.seg_off[t] + static_cast<int64_t>(tile - sm.tile_off[t]) * sm.tile;
+    const int len = static_cast<int>(min<int64_t>(sm.tile, sm.seg_off[t + 1] - start));
     if (pass >= sm.passes[t]) {          // this table is already sorted: carry it to the other buffer
         for (int e = threadIdx.x; e < len; e += SORT_THREADS) {
             kout[start + e] = kin[start + e];
@@ -276,7 +418,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const SortMe
     for (int w = 0; w < SORT_THREADS / 64; ++w) wc[w][threadIdx.x] = 0;
     __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < sm.items; ++r) {
         const int e = r * SORT_THREADS + threadIdx.x;
         const bool valid = e < len;
         uint32_t key = 0, val = 0;
@@ -314,20 +456,146 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const SortMe
 }
 
 // ------------------------------------------------------------------------------------------ reduce
-__device__ __forceinline__ void to_fixed(float x, long long& hi, long long& lo, uint32_t* err) {
-    if (!(fabsf(x) < 1048576.f)) {            // also catches NaN / Inf
-        if (err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
-        x = x > 0.f ? 1048575.f : (x < 0.f ? -1048575.f : 0.f);
+// floor(x * 2^60) as two limbs: x * 2^60 ~ hi * 2^40 + lo, 0 <= lo < 2^40 for normal-sized x (tiny x: lo in {-1, 0, ..}).
+// Integer-only and BRANCH-FREE (selects on 32-bit halves): the fp64 version made the reduction VALU-bound, a branchy
+// one spends more on exec-mask bookkeeping than on arithmetic.  Signed mantissa sm and exponent e of the fp32 word,
+// value = sm << (e - 90).  |x| >= 2^20, Inf and NaN contribute nothing and set `bad` (reported once per thread).
+__device__ __forceinline__ void to_fixed_general(float x, long long& hi, long long& lo, uint32_t& bad) {
+    const uint32_t u = __float_as_uint(x);
+    const int e = static_cast<int>((u >> 23) & 0xFFu);
+    bad |= e >= 147 ? 1u : 0u;
+    const int m = static_cast<uint32_t>(e - 1) < 146u ? static_cast<int>((u & 0x7FFFFFu) | 0x800000u) : 0;   // 0, subnormal, bad -> 0
+    const int sm = static_cast<int>(u) < 0 ? -m : m;
+    const int sh = e - 90;                                   // A: sh >= 40, B: 0 <= sh < 40, C: sh < 0
+    const bool A = sh >= 40, C = sh < 0;
+    const int left = A ? sh - 40 : (C ? 0 : sh);
+    const long long t = static_cast<long long>(sm) << left; // |t| < 2^63
+    const int tl = static_cast<int>(t), th = static_cast<int>(t >> 32);
+    const int c = sm >> min(max(-sh, 0), 31);                // C: floor(sm / 2^-sh)
+    const int hi_lo = A ? tl : (C ? 0 : th >> 8);
+    const int hi_hi = A ? th : (C ? 0 : th >> 31);
+    const int lo_lo = A ? 0 : (C ? c : tl);
+    const int lo_hi = A ? 0 : (C ? c >> 31 : (th & 0xFF));
+    hi = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(hi_hi)) << 32) | static_cast<uint32_t>(hi_lo));
+    lo = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(lo_hi)) << 32) | static_cast<uint32_t>(lo_lo));
+}
+
+// Case B only (2^-37 <= |x| < 8, or x == 0): what gradients are in practice.  Half the instructions of the general form.
+__device__ __forceinline__ void to_fixed_mid(float x, long long& hi, long long& lo) {
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t e = (u >> 23) & 0xFFu;
+    const int m = e ? static_cast<int>((u & 0x7FFFFFu) | 0x800000u) : 0;
+    const int s = static_cast<int>(u) >> 31;
+    const int sm = (m ^ s) - s;
+    const long long t = static_cast<long long>(sm) << ((e - 90u) & 63u);   // e == 0: sm == 0, any shift will do
+    const int tl = static_cast<int>(t), th = static_cast<int>(t >> 32);
+    hi = static_cast<long long>(th >> 8);
+    lo = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(th & 0xFF)) << 32) | static_cast<uint32_t>(tl));
+}
+
+// N values at once: the wave takes the short form when every value of every lane is in case B (wave-uniform branch)
+template <int N>
+__device__ __forceinline__ void to_fixed_n(const float (&x)[N], long long (&hi)[N], long long (&lo)[N], uint32_t& bad) {
+    bool mid = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t e = (__float_as_uint(x[i]) >> 23) & 0xFFu;
+        mid = mid && (e == 0u || (e - 90u) < 40u);
     }
-    const double xd = static_cast<double>(x) * 1048576.0;       // exact
-    const double fl = floor(xd);
-    hi = static_cast<long long>(fl);
-    lo = static_cast<long long>(rint((xd - fl) * 1099511627776.0));   // frac * 2^40
+    if (__all(mid)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) to_fixed_mid(x[i], hi[i], lo[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) to_fixed_general(x[i], hi[i], lo[i], bad);
+    }
 }
 
 __device__ __forceinline__ float from_fixed(long long hi, long long lo) {
     return static_cast<float>(static_cast<double>(hi) * (1.0 / 1048576.0) +
                               static_cast<double>(lo) * (1.0 / 1152921504606846976.0));
+}
+
+// ------------------------------------------------------------------------------------------ direct
+// Small tables: no sort.  Thread = V adjacent gradient columns of one lookup of the group's span (V = 4: one 16-byte
+// load + one key load feed 4 accumulator elements); the DIRECT_THREADS / (width / V) sample lanes of a workgroup walk
+// the chunk with U row loads in flight each.  Every addend is the same fixed-point pair the sorted path would add,
+// and integer addition commutes, so the result is bit-identical to the sorted path whatever the order of the
+// LDS / memory-side atomics.
+template <int V>
+__global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta dm, const uint32_t* __restrict__ keys,
+                                                                const float* __restrict__ dE, int64_t ld,
+                                                                unsigned long long* acc_hi, unsigned long long* acc_lo,
+                                                                int64_t dense_acc_elems, uint32_t* err) {
+    extern __shared__ unsigned long long lacc[];              // [elems] hi limbs, then [elems] lo limbs
+    int gi = 0;
+    while (gi + 1 < dm.n_groups && dm.grp[gi + 1].block0 <= static_cast<int>(blockIdx.x)) ++gi;
+    const DirectGroup& G = dm.grp[gi];
+    const int chunk_id = static_cast<int>(blockIdx.x) - G.block0;
+    const int64_t b0 = static_cast<int64_t>(chunk_id) * G.chunk;
+    const int64_t b1 = min(b0 + G.chunk, dm.B);
+    const int elems = G.elems;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < 2 * elems; j += DIRECT_THREADS) lacc[j] = 0ull;
+    __syncthreads();
+
+    const int W = G.width / V;                                // threads per sample row
+    const int spl = DIRECT_THREADS / W;                       // sample lanes
+    if (tid < spl * W) {
+        const int c = (tid % W) * V, sl = tid / W;
+        int mi = G.member0, cc = c;
+        while (cc >= dm.mem[mi].dim) { cc -= dm.mem[mi].dim; ++mi; }
+        const int dim = dm.mem[mi].dim, row_lo = dm.mem[mi].row_lo, rows = dm.mem[mi].rows;
+        const int base = dm.mem[mi].lds_off + cc;
+        const uint32_t* __restrict__ kp = keys + static_cast<int64_t>(dm.mem[mi].slot) * dm.B;
+        const float* __restrict__ xp = dE + G.col0 + c;
+        constexpr int U = 4;                                  // row loads in flight per thread
+        uint32_t bad = 0u;
+        for (int64_t s0 = b0 + sl; s0 < b1; s0 += static_cast<int64_t>(spl) * U) {
+            float x[U][V];
+            uint32_t k[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t sidx = min(s0 + static_cast<int64_t>(u) * spl, b1 - 1);
+                if (V == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xp + sidx * ld);
+                    x[u][0] = v.x; x[u][1 % V] = v.y; x[u][2 % V] = v.z; x[u][3 % V] = v.w;
+                } else {
+                    x[u][0] = xp[sidx * ld];
+                }
+                k[u] = kp[sidx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = k[u] - static_cast<uint32_t>(row_lo);
+                if (s0 + static_cast<int64_t>(u) * spl < b1 && r < static_cast<uint32_t>(rows)) {
+                    const int a = base + static_cast<int>(r) * dim;
+                    long long h[V], l[V];
+                    to_fixed_n<V>(x[u], h, l, bad);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        atomicAdd(&lacc[a + v], static_cast<unsigned long long>(h[v]));
+                        atomicAdd(&lacc[elems + a + v], static_cast<unsigned long long>(l[v]));
+                    }
+                }
+            }
+        }
+        if (bad && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
+    }
+    __syncthreads();
+    // flush the touched accumulators into stripe (chunk % ACC_STRIPES) of the dense accumulators
+    const int64_t stripe = static_cast<int64_t>(chunk_id % ACC_STRIPES) * dense_acc_elems;
+    for (int q = 0; q < G.n_members; ++q) {
+        const DirectMember& M = dm.mem[G.member0 + q];
+        const int n = M.rows * M.dim;
+        for (int j = tid; j < n; j += DIRECT_THREADS) {
+            const unsigned long long h = lacc[M.lds_off + j], l = lacc[elems + M.lds_off + j];
+            if ((h | l) != 0ull) {
+                atomicAdd(acc_hi + stripe + M.acc_off + j, h);
+                atomicAdd(acc_lo + stripe + M.acc_off + j, l);
+            }
+        }
+    }
 }
 
 // first position in [lo, hi) whose key is >= key
@@ -340,89 +608,167 @@ __device__ __forceinline__ int64_t lower_bound_key(const uint32_t* ck, int64_t l
 }
 
 // LPE lanes per entry (one lane per gradient column; dims above 64 are walked in 64-column blocks).
-// A chunk never crosses a table segment.
+// A chunk never crosses a table segment.  Runs that lie inside one chunk are the only contributors to their row and
+// are stored plainly.  Runs cut by chunk boundaries are first joined ACROSS THE WALKERS OF THE WORKGROUP in LDS (walker
+// q's open tail + the "through" chunks after it + the open head that ends the run), so a hot row whose run spans
+// thousands of entries costs one atomic pair per workgroup instead of one per chunk (same-address atomics serialise
+// at ~0.2 us each on the memory side); only runs that cross a workgroup boundary use atomics.
 template <int LPE>
 __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int n_chunks, const uint32_t* __restrict__ ck,
                                                             const uint32_t* __restrict__ val,
                                                             const float* __restrict__ dE, int64_t ld,
                                                             unsigned long long* acc_hi, unsigned long long* acc_lo,
                                                             int64_t dense_acc_elems, uint32_t* err) {
-    const int64_t gid = (static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x) / LPE;
-    const int e0 = threadIdx.x % LPE;
-    if (gid >= n_chunks) return;
+    constexpr int NW = RB_THREADS / LPE;
+    __shared__ long long sh_sum[4][RB_THREADS];     // open head (hi, lo), open tail (hi, lo) per walker lane
+    __shared__ long long w_head[2][NW];             // sorted position where the open head / tail run starts
+    __shared__ uint32_t w_key[2][NW];
+    __shared__ int w_info[NW];                      // bit 0 head open, bit 1 tail open, bit 2 through; table << 8
+    const int w = threadIdx.x / LPE, e0 = threadIdx.x % LPE;
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * NW + w;
+    const bool valid = gid < n_chunks;
     int ti = 0;
-    while (ti + 1 < m.n_tables && m.chunk_off[ti + 1] <= gid) ++ti;
+    if (valid)
+        while (ti + 1 < m.n_tables && m.chunk_off[ti + 1] <= gid) ++ti;
     const TableMeta& t = m.tab[ti];
     const int64_t seg0 = t.sorted_off;
     const int64_t seg1 = (ti + 1 < m.n_tables) ? m.tab[ti + 1].sorted_off : m.n;
-    const int64_t i0 = seg0 + (gid - m.chunk_off[ti]) * CHUNK;
-    const int64_t i1 = min(i0 + CHUNK, seg1);
+    const int64_t i0 = valid ? seg0 + (gid - m.chunk_off[ti]) * m.chunk : 0;
+    const int64_t i1 = valid ? min(i0 + m.chunk, seg1) : 0;
+
+    auto emit = [&](int tab, uint32_t key, int64_t head_pos, int e, long long hi, long long lo, bool plain, int64_t walker) {
+        const TableMeta& tt = m.tab[tab];
+        if (e >= tt.dim) return;
+        int64_t dst;
+        if (tt.mode != 1)
+            dst = (walker % ACC_STRIPES) * dense_acc_elems + tt.acc_off + static_cast<int64_t>(key) * tt.dim + e;
+        else
+            dst = ACC_STRIPES * dense_acc_elems + (head_pos - m.sparse_start) * m.dim_max + e;
+        if (plain) {
+            acc_hi[dst] = static_cast<unsigned long long>(hi);
+            acc_lo[dst] = static_cast<unsigned long long>(lo);
+        } else {
+            atomicAdd(acc_hi + dst, static_cast<unsigned long long>(hi));
+            atomicAdd(acc_lo + dst, static_cast<unsigned long long>(lo));
+        }
+    };
 
     // entries are taken in batches of BATCH: the BATCH key / payload loads, then the BATCH gradient loads are
     // independent and in flight together; only then does the run logic walk them (no per-entry load chain)
     constexpr int BATCH = 8;
     const int cnt = static_cast<int>(i1 - i0);
-    const uint32_t prev_key = (i0 > seg0) ? ck[i0 - 1] : 0u;
-    const uint32_t next_key = (i1 < seg1) ? ck[i1] : 0u;
-    for (int c0 = 0; c0 < t.dim; c0 += LPE) {
+    uint32_t prev_key = 0u, next_key = 0u;
+    if (valid) {
+        prev_key = (i0 > seg0) ? ck[i0 - 1] : 0u;
+        next_key = (i1 < seg1) ? ck[i1] : 0u;
+    }
+    uint32_t bad = 0u;
+    for (int c0 = 0; c0 < m.dim_max; c0 += LPE) {          // same trip count for every walker (barriers inside)
         const int e = c0 + e0;
-        uint32_t cur = ck[i0];
-        int64_t head = i0;
-        // a run that starts and ends inside this chunk is the only contributor to its row: plain stores;
-        // only runs cut by a chunk boundary (at most two per chunk) need atomics
-        bool whole_start = (i0 == seg0) || (prev_key != cur);
-        if (!whole_start && t.mode == 1) head = lower_bound_key(ck, seg0, i0, cur);
-        long long s_hi = 0, s_lo = 0;
-        auto flush = [&](uint32_t key, int64_t head_pos, bool whole) {
-            if (e >= t.dim) return;
-            int64_t dst;
-            if (t.mode != 1)
-                dst = (gid % ACC_STRIPES) * dense_acc_elems + t.acc_off + static_cast<int64_t>(key) * t.dim + e;
-            else
-                dst = ACC_STRIPES * dense_acc_elems + (head_pos - m.sparse_start) * m.dim_max + e;
-            if (whole) {
-                acc_hi[dst] = static_cast<unsigned long long>(s_hi);
-                acc_lo[dst] = static_cast<unsigned long long>(s_lo);
-            } else {
-                atomicAdd(acc_hi + dst, static_cast<unsigned long long>(s_hi));
-                atomicAdd(acc_lo + dst, static_cast<unsigned long long>(s_lo));
-            }
-        };
-        for (int j0 = 0; j0 < cnt; j0 += BATCH) {
-            uint32_t ks[BATCH], vs[BATCH];
-            float x[BATCH];
+        int info = 0;
+        long long hh = 0, hl = 0, th = 0, tl = 0;
+        int64_t head_h = 0, head_t = 0;
+        uint32_t key_h = 0u, key_t = 0u;
+        if (valid) {
+            uint32_t cur = ck[i0];
+            int64_t head = i0;
+            bool in_first = !((i0 == seg0) || (prev_key != cur));   // the first run continues the previous chunk's
+            long long s_hi = 0, s_lo = 0;
+            for (int j0 = 0; j0 < cnt; j0 += BATCH) {
+                uint32_t ks[BATCH], vs[BATCH];
+                float x[BATCH];
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                const int64_t i = i0 + min(j0 + j, cnt - 1);
-                ks[j] = ck[i];
-                vs[j] = val[i];
-            }
+                for (int j = 0; j < BATCH; ++j) {
+                    const int64_t i = i0 + min(j0 + j, cnt - 1);
+                    ks[j] = ck[i];
+                    vs[j] = val[i];
+                }
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                const int slot = static_cast<int>(vs[j] >> 24);
-                const int64_t b = vs[j] & 0xFFFFFFu;
-                x[j] = e < t.dim ? dE[b * ld + m.slot_col[slot] + e] : 0.f;
-            }
+                for (int j = 0; j < BATCH; ++j) {
+                    const int slot = static_cast<int>(vs[j] >> 24);
+                    const int64_t b = vs[j] & 0xFFFFFFu;
+                    x[j] = e < t.dim ? dE[b * ld + m.slot_col[slot] + e] : 0.f;
+                }
+                long long fh[BATCH], fl[BATCH];
+                to_fixed_n<BATCH>(x, fh, fl, bad);
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                if (j0 + j < cnt) {
-                    if (ks[j] != cur) {
-                        flush(cur, head, whole_start);
-                        cur = ks[j];
-                        head = i0 + j0 + j;
-                        whole_start = true;
-                        s_hi = 0;
-                        s_lo = 0;
+                for (int j = 0; j < BATCH; ++j) {
+                    if (j0 + j < cnt) {
+                        if (ks[j] != cur) {
+                            if (in_first) {
+                                info |= 1; hh = s_hi; hl = s_lo; key_h = cur;
+                                in_first = false;
+                            } else {
+                                emit(ti, cur, head, e, s_hi, s_lo, true, gid);
+                            }
+                            cur = ks[j];
+                            head = i0 + j0 + j;
+                            s_hi = 0;
+                            s_lo = 0;
+                        }
+                        s_hi += fh[j];
+                        s_lo += fl[j];
                     }
-                    long long h, l;
-                    to_fixed(x[j], h, l, err);
-                    s_hi += h;
-                    s_lo += l;
                 }
             }
+            const bool last_open = !((i1 == seg1) || (next_key != cur));
+            if (in_first) {
+                info |= last_open ? 4 : 1; hh = s_hi; hl = s_lo; key_h = cur;
+            } else if (last_open) {
+                info |= 2; th = s_hi; tl = s_lo; key_t = cur; head_t = head;
+            } else {
+                emit(ti, cur, head, e, s_hi, s_lo, true, gid);
+            }
+            // only the first walker can meet a run that started in another workgroup: find where it starts
+            if ((info & 5) && w == 0 && t.mode == 1) head_h = lower_bound_key(ck, seg0, i0, key_h);
         }
-        flush(cur, head, whole_start && ((i1 == seg1) || (next_key != cur)));
+        sh_sum[0][threadIdx.x] = hh; sh_sum[1][threadIdx.x] = hl;
+        sh_sum[2][threadIdx.x] = th; sh_sum[3][threadIdx.x] = tl;
+        if (e0 == 0) {
+            w_info[w] = info | (ti << 8);
+            w_key[0][w] = key_h; w_key[1][w] = key_t;
+            w_head[0][w] = head_h; w_head[1][w] = head_t;
+        }
+        __syncthreads();
+        if (w == 0) {                                       // lanes e0 of walker 0 join the open runs, in walker order
+            bool have = false, outside = false;
+            long long c_hi = 0, c_lo = 0;
+            int64_t c_head = 0;
+            uint32_t c_key = 0u;
+            int c_tab = 0;
+            const int64_t g0 = static_cast<int64_t>(blockIdx.x) * NW;
+            for (int q = 0; q < NW; ++q) {
+                const int inf = w_info[q];
+                const int idx = q * LPE + e0;
+                if (inf & 4) {
+                    if (have) {
+                        c_hi += sh_sum[0][idx]; c_lo += sh_sum[1][idx];
+                    } else {
+                        have = true; outside = true;
+                        c_hi = sh_sum[0][idx]; c_lo = sh_sum[1][idx];
+                        c_key = w_key[0][q]; c_head = w_head[0][q]; c_tab = inf >> 8;
+                    }
+                    continue;
+                }
+                if (inf & 1) {
+                    if (have) {
+                        emit(c_tab, c_key, c_head, e, c_hi + sh_sum[0][idx], c_lo + sh_sum[1][idx], !outside, g0 + q);
+                        have = false;
+                    } else {
+                        emit(inf >> 8, w_key[0][q], w_head[0][q], e, sh_sum[0][idx], sh_sum[1][idx], false, g0 + q);
+                    }
+                }
+                if (inf & 2) {
+                    have = true; outside = false;
+                    c_hi = sh_sum[2][idx]; c_lo = sh_sum[3][idx];
+                    c_key = w_key[1][q]; c_head = w_head[1][q]; c_tab = inf >> 8;
+                }
+            }
+            if (have) emit(c_tab, c_key, c_head, e, c_hi, c_lo, false, g0 + NW - 1);
+        }
+        __syncthreads();
     }
+    if (bad && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
 }
 
 __global__ __launch_bounds__(RB_THREADS) void finalize_dense_kernel(const BwdMeta m, const long long* __restrict__ acc_hi,
@@ -490,25 +836,45 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
     const BwdMeta& m = p.m;
     const int64_t n = m.n;
 
-    hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
-                       st, m, keys, kbuf[0], vbuf[0]);
-    int cur = 0;
-    for (int pass = 0; pass < p.n_passes; ++pass) {
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(SCAN_THREADS), 0, st, p.sm, pass, hist);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], vbuf[cur],
-                           kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
-        cur ^= 1;
-    }
-    const uint32_t* ck = kbuf[cur];
-    const uint32_t* sv = vbuf[cur];
     // both accumulator limbs are contiguous: one zero-fill (a kernel, not a memset node)
     rc = swr_zero_async(acc_hi, (p.off_acc_lo - p.off_acc_hi) * 2, st);
     if (rc != SWR_OK) return rc;
+    if (p.dm.n_blocks > 0) {
+        // LDS sized by the largest group (small groups -> more workgroups per CU); 16-byte loads when every lookup
+        // column span is 4-float aligned
+        int max_elems = 0;
+        bool vec4 = (ld % 4 == 0) && swr_aligned16(dE);
+        for (int g = 0; g < p.dm.n_groups; ++g) max_elems = std::max(max_elems, p.dm.grp[g].elems);
+        for (int q = 0; q < p.dm.n_members; ++q) vec4 = vec4 && p.dm.mem[q].dim % 4 == 0 && p.dm.mem[q].col % 4 == 0;
+        const size_t lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long);
+        if (vec4)
+            hipLaunchKernelGGL(direct_kernel<4>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
+                               p.dm, keys, dE, ld, acc_hi, acc_lo, p.dense_acc_elems, err_flag);
+        else
+            hipLaunchKernelGGL(direct_kernel<1>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
+                               p.dm, keys, dE, ld, acc_hi, acc_lo, p.dense_acc_elems, err_flag);
+    }
+    const uint32_t* ck = kbuf[0];
+    const uint32_t* sv = vbuf[0];
+    if (n > 0) {
+        hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
+                           st, m, keys, kbuf[0], vbuf[0]);
+        int cur = 0;
+        for (int pass = 0; pass < p.n_passes; ++pass) {
+            hipLaunchKernelGGL(sort_hist_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], hist);
+            hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(SCAN_THREADS), 0, st, p.sm, pass, hist);
+            hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur],
+                               vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
+            cur ^= 1;
+        }
+        ck = kbuf[cur];
+        sv = vbuf[cur];
+    }
 
+    if (n > 0) {
     int lpe = 1;
     while (lpe < m.dim_max && lpe < 64) lpe <<= 1;
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(p.n_chunks) * lpe, RB_THREADS)));
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(p.n_chunks), RB_THREADS / lpe)));
 #define LAUNCH_REDUCE(L)                                                                                              \
     hipLaunchKernelGGL(reduce_kernel<L>, grid, dim3(RB_THREADS), 0, st, m, p.n_chunks, ck, sv, dE, ld, acc_hi, acc_lo,   \
                        p.dense_acc_elems, err_flag)
@@ -522,6 +888,7 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
         default: LAUNCH_REDUCE(64); break;
     }
 #undef LAUNCH_REDUCE
+    }
     if (p.dense_acc_elems > 0) {
         int64_t biggest = 1;
         for (int t = 0; t < m.n_tables; ++t)

@@ -54,7 +54,9 @@ def test_gather_out_of_range_index_raises():
 
 @pytest.mark.parametrize("B,dim,vocabs,limit", [(250, 16, [2, 7, 200], 1 << 30), (1000, 8, [3, 500], 1 << 30),
                                                 (777, 16, [5, 4000, 9000], 64 * 1024),     # two sparse-mode tables
-                                                (512, 12, [40], 1 << 30), (300, 64, [11, 13], 1 << 30)])
+                                                (512, 12, [40], 1 << 30), (300, 64, [11, 13], 1 << 30),
+                                                (2000, 16, [1000, 3000, 70000], 1 << 30),  # row-range parts; sorted dense
+                                                (600, 6, [40, 3000], 1 << 30)])            # columns not 16-byte aligned
 def test_embedding_backward(B, dim, vocabs, limit):
     """K3 against np.add.at in fp64.  The fixed-point accumulation is exact to 2^-60, so the only error
     is the final fp32 rounding: rtol 2e-7 of the largest entry."""
@@ -90,6 +92,56 @@ def test_embedding_backward(B, dim, vocabs, limit):
         else:
             got = w.grad.cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("limit", [1 << 30, 1024])
+def test_embedding_backward_wide_dynamic_range(limit):
+    """Gradients from 1e-15 to 5e5, signed zeros, a subnormal: the general (three-case) fixed-point conversion and
+    the short mid-range one must agree with an fp64 sum; dense (direct / sorted) and sparse-mode tables."""
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(11)
+    B, dim = 3000, 16
+    feats = [SparseFeature("a", 5, dim), SparseFeature("b", 3000, dim), SparseFeature("c", 40000, dim)]
+    layer = EmbeddingLayer(feats)
+    layer.dense_table_limit_bytes = limit
+    layer.to("cuda")
+    x = {f.name: rng.integers(0, f.vocab_size, size=B) for f in feats}
+    mag = 10.0 ** rng.integers(-15, 6, size=(B, 3 * dim))
+    g = (rng.standard_normal((B, 3 * dim)) * mag).astype(np.float32)
+    g[::7, ::3] = 0.0
+    g[1::7, 1::3] = -0.0
+    g[5, 5] = 1e-41                                   # subnormal: below the accumulator resolution, counts as 0
+    g[6, :] = 1e-3                                    # one all-mid-range row next to the wild ones
+    layer(({k: _dev(v) for k, v in x.items()}), feats, squeeze_dim=True).backward(_dev(g))
+    torch.cuda.synchronize()
+    from scenario_wise_rec import _hip as H
+    H.check_errors()
+    for i, f in enumerate(feats):
+        want = np.zeros((f.vocab_size, dim), np.float64)
+        np.add.at(want, x[f.name], g[:, i * dim:(i + 1) * dim].astype(np.float64))
+        w = layer.embed_dict[f.name].weight
+        if f.vocab_size * dim * 4 > limit:
+            urow, ugrad = (t.cpu().numpy() for t in w._swr_sparse_grad)
+            got = np.zeros_like(want)
+            got[urow[urow >= 0]] = ugrad[urow >= 0]
+        else:
+            got = w.grad.cpu().numpy()
+        # exact integer sums: the result is the fp32 rounding of the true sum (+ B * 2^-60 of truncation)
+        np.testing.assert_allclose(got, want, rtol=1.2e-7, atol=B * 2.0 ** -60)
+
+
+def test_embedding_backward_flags_out_of_range_gradient():
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    feats = [SparseFeature("a", 5, 8)]
+    layer = EmbeddingLayer(feats).to("cuda")
+    g = torch.zeros(64, 8, device="cuda")
+    g[3, 2] = 3e6                                      # >= 2^20
+    layer({"a": torch.arange(64, device="cuda") % 5}, feats, squeeze_dim=True).backward(g)
+    with pytest.raises(H.SwrError):
+        H.check_errors()
 
 
 def test_embedding_backward_is_deterministic():
