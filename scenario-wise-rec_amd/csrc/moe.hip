@@ -71,6 +71,30 @@ __global__ __launch_bounds__(MIX_WAVES * 64) void mix_fwd_kernel(const MixK k, c
     }
 }
 
+// ---- 16-byte fast path (H, x_col, row strides multiples of 4 floats): thread = 4 pooled outputs of one row; the expert
+// and gate rows are read straight from global memory (a row is 0.6 KB: the re-reads by the other outputs of the row
+// hit the CU's L1), no LDS, no barriers -> every load of a workgroup is in flight at once.
+__global__ __launch_bounds__(256) void mix_fwd_v4_kernel(const MixK k, const float* __restrict__ Y, int64_t ldy,
+                                                         float* __restrict__ P, int64_t ldp, int64_t M) {
+    const swr_mix_desc& d = k.d;
+    const int h4n = d.H >> 2, per_row = d.n_out * h4n;
+    const int64_t item = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t m = item / per_row;
+    if (m >= M) return;
+    const int q = static_cast<int>(item - m * per_row);
+    const int o = q / h4n, h = (q - o * h4n) * 4;
+    const float* __restrict__ y = Y + m * ldy;
+    const float* __restrict__ g = y + d.g_col + o * d.g_stride;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < d.n_sel; ++j) {
+        const float gj = g[j];
+        const float4 x = *reinterpret_cast<const float4*>(y + d.x_col + d.sel[o][j] * d.H + h);
+        acc.x = fmaf(gj, x.x, acc.x); acc.y = fmaf(gj, x.y, acc.y);
+        acc.z = fmaf(gj, x.z, acc.z); acc.w = fmaf(gj, x.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(P + m * ldp + o * d.H + h) = acc;
+}
+
 extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t ldy, float* P, int64_t ldp, int64_t M,
                                void* stream) {
     SWR_REQUIRE(desc && Y && P && M >= 0, SWR_ERR_ARG);
@@ -78,6 +102,12 @@ extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t
     const int rc = make_mix(desc, k);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
+    if (desc->H % 4 == 0 && desc->x_col % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0 && swr_aligned16(Y) && swr_aligned16(P)) {
+        const int64_t items = M * desc->n_out * (desc->H / 4);
+        hipLaunchKernelGGL(mix_fwd_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, 256))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
+        return swr_launch_status();
+    }
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 8192 ? swr_ceil_div(M, MIX_WAVES) : 8192);
     hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), MIX_WAVES * k.row_floats * sizeof(float),
                        static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
@@ -135,6 +165,114 @@ __global__ __launch_bounds__(MIX_WAVES * 64) void mix_bwd_kernel(const MixK k, c
     }
 }
 
+// 16-byte fast path of the backward: a workgroup takes MIXB_ROWS rows; phase 1: thread = 4 expert-gradient columns of
+// one row (sum over the outputs that select the expert), phase 2: thread = one gate gradient (dot product over H).
+// Everything is read from global memory / L1; no LDS, no barriers.
+#define MIXB_ROWS 32
+__global__ __launch_bounds__(256) void mix_bwd_v4_kernel(const MixK k, const float* __restrict__ dP, int64_t lddp,
+                                                         const float* __restrict__ Y, int64_t ldy,
+                                                         float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M) {
+    const swr_mix_desc& d = k.d;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * MIXB_ROWS;
+    const int rows = static_cast<int>(min<int64_t>(MIXB_ROWS, M - m0));
+    const int h4n = d.H >> 2;
+    const int xper = k.n_expert * h4n;                       // expert-gradient items per row
+    for (int it = threadIdx.x; it < rows * xper; it += 256) {
+        const int r = it / xper, q = it - r * xper;
+        const int e = q / h4n, h = (q - e * h4n) * 4;
+        const int64_t m = m0 + r;
+        const float* __restrict__ g = Y + m * ldy + d.g_col;
+        const float* __restrict__ dp = dP + m * lddp + h;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < k.inv_cnt[e]; ++c) {
+            const int o = k.inv[e][c] >> 4, j = k.inv[e][c] & 15;
+            const float gj = g[o * d.g_stride + j];
+            const float4 v = *reinterpret_cast<const float4*>(dp + o * d.H);
+            acc.x = fmaf(gj, v.x, acc.x); acc.y = fmaf(gj, v.y, acc.y);
+            acc.z = fmaf(gj, v.z, acc.z); acc.w = fmaf(gj, v.w, acc.w);
+        }
+        float4* dst = reinterpret_cast<float4*>(dY + m * lddy + d.x_col + e * d.H + h);
+        if (accumulate) {
+            const float4 old = *dst;
+            acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+        }
+        *dst = acc;
+    }
+    const int ng = d.n_out * d.n_sel;
+    for (int it = threadIdx.x; it < rows * ng; it += 256) {
+        const int r = it / ng, q = it - r * ng;
+        const int o = q / d.n_sel, j = q - o * d.n_sel;
+        const int64_t m = m0 + r;
+        const float* __restrict__ x = Y + m * ldy + d.x_col + d.sel[o][j] * d.H;
+        const float* __restrict__ dp = dP + m * lddp + o * d.H;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four interleaved chains, combined in a fixed order
+        for (int h = 0; h < d.H; h += 4) {
+            const float4 u = *reinterpret_cast<const float4*>(dp + h);
+            const float4 v = *reinterpret_cast<const float4*>(x + h);
+            a0 = fmaf(u.x, v.x, a0); a1 = fmaf(u.y, v.y, a1);
+            a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
+        }
+        const float acc = (a0 + a1) + (a2 + a3);
+        float* dst = dY + m * lddy + d.g_col + o * d.g_stride + j;
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}
+
+// Identity selection (every output mixes experts 0..n_sel-1 in order: MMoE) with H <= 256: thread = 4 columns h of one
+// row for ALL outputs and experts.  The expert rows stay in registers, each dP row is read once, the expert gradients
+// are complete in-thread, and the gate gradients are finished by a fixed butterfly over the H/4 lanes of the row.
+// Every byte of Y and dP is read exactly once.
+template <int NS>
+__global__ __launch_bounds__(256) void mix_bwd_ident_kernel(const MixK k, const float* __restrict__ dP, int64_t lddp,
+                                                            const float* __restrict__ Y, int64_t ldy,
+                                                            float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M) {
+    const swr_mix_desc& d = k.d;
+    const int h4n = d.H >> 2;                                // lanes per row: a power of two <= 64
+    const int64_t item = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t m = min(item / h4n, M - 1);                // surplus lanes redo the last row (shuffles need them)
+    const bool live = item / h4n < M;
+    const int h = static_cast<int>(item % h4n) * 4;
+    const float* __restrict__ y = Y + m * ldy;
+    float4 x[NS], dx[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        x[j] = j < d.n_sel ? *reinterpret_cast<const float4*>(y + d.x_col + j * d.H + h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* __restrict__ out = dY + m * lddy;
+    for (int o = 0; o < d.n_out; ++o) {
+        const float4 v = *reinterpret_cast<const float4*>(dP + m * lddp + o * d.H + h);
+        const float* __restrict__ g = y + d.g_col + o * d.g_stride;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (j < d.n_sel) {
+                const float gj = g[j];
+                dx[j].x = fmaf(gj, v.x, dx[j].x); dx[j].y = fmaf(gj, v.y, dx[j].y);
+                dx[j].z = fmaf(gj, v.z, dx[j].z); dx[j].w = fmaf(gj, v.w, dx[j].w);
+                float pd = (v.x * x[j].x + v.y * x[j].y) + (v.z * x[j].z + v.w * x[j].w);
+                for (int off = 1; off < h4n; off <<= 1) pd += __shfl_xor(pd, off);
+                if (live && h == 0) {
+                    float* dst = out + d.g_col + o * d.g_stride + j;
+                    *dst = accumulate ? *dst + pd : pd;
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if (j < d.n_sel) {
+            float4* dst = reinterpret_cast<float4*>(out + d.x_col + j * d.H + h);
+            float4 a = dx[j];
+            if (accumulate) {
+                const float4 old = *dst;
+                a.x += old.x; a.y += old.y; a.z += old.z; a.w += old.w;
+            }
+            *dst = a;
+        }
+    }
+}
+
 extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_t lddp, const float* Y, int64_t ldy,
                                float* dY, int64_t lddy, int accumulate, int64_t M, void* stream) {
     SWR_REQUIRE(desc && dP && Y && dY && M >= 0, SWR_ERR_ARG);
@@ -142,6 +280,26 @@ extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_
     const int rc = make_mix(desc, k);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
+    if (desc->H % 4 == 0 && desc->x_col % 4 == 0 && ldy % 4 == 0 && lddp % 4 == 0 && lddy % 4 == 0 && swr_aligned16(Y) &&
+        swr_aligned16(dP) && swr_aligned16(dY)) {
+        bool ident = desc->n_sel <= 8 && (desc->H & (desc->H - 1)) == 0 && desc->H <= 256 && k.n_expert == desc->n_sel;
+        for (int o = 0; o < desc->n_out && ident; ++o)
+            for (int j = 0; j < desc->n_sel; ++j) ident = ident && desc->sel[o][j] == j;
+        if (ident) {
+            const int64_t items = M * (desc->H / 4);
+            const dim3 grid(static_cast<unsigned>(swr_ceil_div(items, 256)));
+            if (desc->n_sel <= 4)
+                hipLaunchKernelGGL(mix_bwd_ident_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), k, dP, lddp,
+                                   Y, ldy, dY, lddy, accumulate, M);
+            else
+                hipLaunchKernelGGL(mix_bwd_ident_kernel<8>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), k, dP, lddp,
+                                   Y, ldy, dY, lddy, accumulate, M);
+            return swr_launch_status();
+        }
+        hipLaunchKernelGGL(mix_bwd_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, MIXB_ROWS))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy, dY, lddy, accumulate, M);
+        return swr_launch_status();
+    }
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 8192 ? swr_ceil_div(M, MIX_WAVES) : 8192);
     hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), MIX_WAVES * k.row_floats * sizeof(float),
                        static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy, dY, lddy, accumulate, M);

@@ -468,6 +468,11 @@ def make_mix_desc(n_out, n_sel, H_, x_col, g_col, g_stride, sel):
     for o in range(n_out):
         for j in range(n_sel):
             d.sel[o][j] = sel[o][j]
+    # columns of Y whose gradient swr_moe_mix_bwd writes: experts 0..max(sel) and the n_sel gates of every output
+    n_expert = max(max(row[:n_sel]) for row in sel[:n_out]) + 1
+    d._written = set(range(x_col, x_col + n_expert * H_))
+    for o in range(n_out):
+        d._written.update(range(g_col + o * g_stride, g_col + o * g_stride + n_sel))
     return d
 
 
@@ -493,7 +498,9 @@ class MoeMix(Function):
         (Y,) = ctx.saved_tensors
         dP = H.f32c(dP)
         M = Y.shape[0]
-        dY = torch.zeros((M, ctx.width_in), dtype=torch.float32, device=Y.device)
+        # the kernel writes every expert and gate column: a zero fill is only needed when Y has other columns
+        full = len(ctx.desc._written) == ctx.width_in
+        dY = (torch.empty if full else torch.zeros)((M, ctx.width_in), dtype=torch.float32, device=Y.device)
         H.check(lib.swr_moe_mix_bwd(C.byref(ctx.desc), H.ptr(dP), dP.stride(0) if M > 1 else dP.shape[1], H.ptr(Y),
                                     Y.stride(0) if M > 1 else Y.shape[1], H.ptr(dY), ctx.width_in, 0, M, H.stream()),
                 "swr_moe_mix_bwd")

@@ -278,3 +278,41 @@ def test_fused_adam_matches_oracle():
         ref.step(state, {i: g.astype(np.float64) for i, g in enumerate(gs)})
     for i, p in enumerate(params):
         np.testing.assert_allclose(p.detach().cpu().numpy(), state[i], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("M,H_,n_expert,sel,pad", [
+    (1000, 32, 4, [[0, 1, 2, 3]] * 5, 0),                    # MMoE: every domain gate mixes every expert (16-byte path)
+    (333, 16, 5, [[0, 1, 4], [2, 3, 4], [0, 1, 2]], 4),      # PLE-like subsets, spare columns in Y (stay zero)
+    (257, 6, 3, [[0, 2], [1, 2]], 0),                        # H not a multiple of 4: row-staged kernel
+    (1, 8, 2, [[0, 1]], 0),
+    (131, 8, 3, [[0, 1, 2]] * 2, 4),                         # identity selection, rows not filling the last wave
+    (77, 64, 6, [[0, 1, 2, 3, 4, 5]] * 3, 0)])
+def test_moe_mix_forward_backward(M, H_, n_expert, sel, pad):
+    """pooled_o = sum_j gate[o][j] * expert[sel[o][j]] and its gradients against numpy fp64 (mmoe.py:48-49)."""
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(M + H_)
+    n_out, n_sel = len(sel), len(sel[0])
+    x_col, g_col = 0, n_expert * H_ + pad
+    width = g_col + n_out * n_sel
+    Y = rng.standard_normal((M, width)).astype(np.float32)
+    desc = ops.make_mix_desc(n_out, n_sel, H_, x_col, g_col, n_sel, sel)
+    Yd = _dev(Y).requires_grad_(True)
+    P = ops.MoeMix.apply(Yd, desc, width)
+    X = Y[:, :n_expert * H_].reshape(M, n_expert, H_).astype(np.float64)
+    G = Y[:, g_col:].reshape(M, n_out, n_sel).astype(np.float64)
+    want = np.stack([sum(G[:, o, j, None] * X[:, sel[o][j]] for j in range(n_sel)) for o in range(n_out)], axis=1)
+    np.testing.assert_allclose(P.detach().cpu().numpy().reshape(M, n_out, H_), want, rtol=0, atol=4e-6)
+    dP = rng.standard_normal((M, n_out * H_)).astype(np.float32)
+    P.backward(_dev(dP))
+    got = Yd.grad.cpu().numpy()
+    dPn = dP.reshape(M, n_out, H_).astype(np.float64)
+    dX = np.zeros((M, n_expert, H_))
+    dG = np.zeros((M, n_out, n_sel))
+    for o in range(n_out):
+        for j in range(n_sel):
+            dX[:, sel[o][j]] += G[:, o, j, None] * dPn[:, o]
+            dG[:, o, j] = (dPn[:, o] * X[:, sel[o][j]]).sum(axis=1)
+    np.testing.assert_allclose(got[:, :n_expert * H_].reshape(M, n_expert, H_), dX, rtol=0, atol=8e-6)
+    np.testing.assert_allclose(got[:, g_col:].reshape(M, n_out, n_sel), dG, rtol=0, atol=3e-5)
+    if pad:
+        assert not np.any(got[:, n_expert * H_:g_col])
