@@ -123,6 +123,18 @@ int swr_embed_bwd(const swr_embed_grad_slot* slots_host, int n_slots,
                   const uint32_t* keys /* [n_slots * B] from the forward */,
                   const float* dE, int64_t ld, int64_t B,
                   void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream);
+/* The same work in two halves, so that the half that needs only the lookup keys (grouping the entries of the large
+ * tables by row: build keys + segmented radix sort) can run on another stream while the rest of the forward and
+ * backward pass executes, and only the reduction waits for dE:
+ *   swr_embed_bwd_sort   : output pointers of the slots may be null; leaves the sorted entries in `workspace`;
+ *   swr_embed_bwd_reduce : same arguments as swr_embed_bwd, same `workspace` (ordered after the sort by the caller).
+ * swr_embed_bwd == sort followed by reduce on one stream.  Small dense tables never enter the sort (they are summed
+ * in LDS per workgroup), whichever entry point is used. */
+int swr_embed_bwd_sort(const swr_embed_grad_slot* slots_host, int n_slots, const uint32_t* keys, int64_t B,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int swr_embed_bwd_reduce(const swr_embed_grad_slot* slots_host, int n_slots, const uint32_t* keys,
+                         const float* dE, int64_t ld, int64_t B,
+                         void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream);
 
 /* ------------------------------------------------------------------ K2 ----
  * fp32 matrix products on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact

@@ -117,7 +117,7 @@ static int bits_for(uint64_t max_value) {   // bits needed to represent values 0
 }
 static size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, HostPlan& p) {
+static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, HostPlan& p, bool need_outputs = true) {
     SWR_REQUIRE(slots && n_slots > 0 && n_slots <= MAX_SLOTS && B > 0, SWR_ERR_ARG);
     SWR_REQUIRE(B <= (1 << 24), SWR_ERR_UNSUPPORTED);
     BwdMeta& m = p.m;
@@ -145,7 +145,8 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
             t.urow = sl.urow;
             t.ugrad = sl.ugrad;
             SWR_REQUIRE(sl.mode >= 0 && sl.mode <= 2, SWR_ERR_ARG);
-            SWR_REQUIRE(sl.mode != 1 ? sl.grad_dense != nullptr : (sl.urow != nullptr && sl.ugrad != nullptr), SWR_ERR_ARG);
+            if (need_outputs)
+                SWR_REQUIRE(sl.mode != 1 ? sl.grad_dense != nullptr : (sl.urow != nullptr && sl.ugrad != nullptr), SWR_ERR_ARG);
         } else {
             SWR_REQUIRE(t.vocab == sl.vocab && t.dim == sl.dim && t.mode == sl.mode, SWR_ERR_ARG);
         }
@@ -813,17 +814,18 @@ __global__ __launch_bounds__(RB_THREADS) void finalize_sparse_kernel(const BwdMe
 
 extern "C" size_t swr_embed_bwd_workspace_bytes(const swr_embed_grad_slot* slots, int n_slots, int64_t B) {
     HostPlan p;
-    if (make_plan(slots, n_slots, B, p) != SWR_OK) return 0;
+    if (make_plan(slots, n_slots, B, p, false) != SWR_OK) return 0;
     return p.total;
 }
 
-extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
-                             int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag,
-                             void* stream) {
-    SWR_REQUIRE(keys && dE && workspace && ld > 0, SWR_ERR_ARG);
+// phases: 1 = build keys + sort (needs only the lookup keys), 2 = direct + reduce + finalise (needs dE), 3 = both
+static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
+                         int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream) {
+    SWR_REQUIRE(keys && workspace, SWR_ERR_ARG);
+    SWR_REQUIRE(!(phases & 2) || (dE && ld > 0), SWR_ERR_ARG);
     if (B == 0) return SWR_OK;
     HostPlan p;
-    int rc = make_plan(slots, n_slots, B, p);
+    int rc = make_plan(slots, n_slots, B, p, (phases & 2) != 0);
     if (rc != SWR_OK) return rc;
     SWR_REQUIRE(workspace_bytes >= p.total, SWR_ERR_WORKSPACE);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -835,6 +837,22 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
     unsigned long long* acc_lo = reinterpret_cast<unsigned long long*>(ws + p.off_acc_lo);
     const BwdMeta& m = p.m;
     const int64_t n = m.n;
+
+    if ((phases & 1) && n > 0) {
+        hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
+                           st, m, keys, kbuf[0], vbuf[0]);
+        int cur = 0;
+        for (int pass = 0; pass < p.n_passes; ++pass) {
+            hipLaunchKernelGGL(sort_hist_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], hist);
+            hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(SCAN_THREADS), 0, st, p.sm, pass, hist);
+            hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur],
+                               vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
+            cur ^= 1;
+        }
+    }
+    if (!(phases & 2)) return swr_launch_status();
+    const uint32_t* ck = kbuf[p.n_passes & 1];               // where the last pass left the sorted entries
+    const uint32_t* sv = vbuf[p.n_passes & 1];
 
     // both accumulator limbs are contiguous: one zero-fill (a kernel, not a memset node)
     rc = swr_zero_async(acc_hi, (p.off_acc_lo - p.off_acc_hi) * 2, st);
@@ -854,39 +872,22 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
             hipLaunchKernelGGL(direct_kernel<1>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
                                p.dm, keys, dE, ld, acc_hi, acc_lo, p.dense_acc_elems, err_flag);
     }
-    const uint32_t* ck = kbuf[0];
-    const uint32_t* sv = vbuf[0];
     if (n > 0) {
-        hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
-                           st, m, keys, kbuf[0], vbuf[0]);
-        int cur = 0;
-        for (int pass = 0; pass < p.n_passes; ++pass) {
-            hipLaunchKernelGGL(sort_hist_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur], hist);
-            hipLaunchKernelGGL(sort_scan_kernel, dim3(p.sm.n_tables), dim3(SCAN_THREADS), 0, st, p.sm, pass, hist);
-            hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.sm.n_tiles), dim3(SORT_THREADS), 0, st, p.sm, pass, kbuf[cur],
-                               vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
-            cur ^= 1;
-        }
-        ck = kbuf[cur];
-        sv = vbuf[cur];
-    }
-
-    if (n > 0) {
-    int lpe = 1;
-    while (lpe < m.dim_max && lpe < 64) lpe <<= 1;
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(p.n_chunks), RB_THREADS / lpe)));
+        int lpe = 1;
+        while (lpe < m.dim_max && lpe < 64) lpe <<= 1;
+        const dim3 grid(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(p.n_chunks), RB_THREADS / lpe)));
 #define LAUNCH_REDUCE(L)                                                                                              \
     hipLaunchKernelGGL(reduce_kernel<L>, grid, dim3(RB_THREADS), 0, st, m, p.n_chunks, ck, sv, dE, ld, acc_hi, acc_lo,   \
                        p.dense_acc_elems, err_flag)
-    switch (lpe) {
-        case 1: LAUNCH_REDUCE(1); break;
-        case 2: LAUNCH_REDUCE(2); break;
-        case 4: LAUNCH_REDUCE(4); break;
-        case 8: LAUNCH_REDUCE(8); break;
-        case 16: LAUNCH_REDUCE(16); break;
-        case 32: LAUNCH_REDUCE(32); break;
-        default: LAUNCH_REDUCE(64); break;
-    }
+        switch (lpe) {
+            case 1: LAUNCH_REDUCE(1); break;
+            case 2: LAUNCH_REDUCE(2); break;
+            case 4: LAUNCH_REDUCE(4); break;
+            case 8: LAUNCH_REDUCE(8); break;
+            case 16: LAUNCH_REDUCE(16); break;
+            case 32: LAUNCH_REDUCE(32); break;
+            default: LAUNCH_REDUCE(64); break;
+        }
 #undef LAUNCH_REDUCE
     }
     if (p.dense_acc_elems > 0) {
@@ -905,4 +906,21 @@ extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, cons
                            reinterpret_cast<const long long*>(acc_lo), p.dense_acc_elems);
     }
     return swr_launch_status();
+}
+
+extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
+                             int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag,
+                             void* stream) {
+    return run_embed_bwd(3, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
+}
+
+extern "C" int swr_embed_bwd_sort(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, int64_t B,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return run_embed_bwd(1, slots, n_slots, keys, nullptr, 0, B, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int swr_embed_bwd_reduce(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
+                                    int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag,
+                                    void* stream) {
+    return run_embed_bwd(2, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
 }

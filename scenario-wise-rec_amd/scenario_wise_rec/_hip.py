@@ -108,6 +108,8 @@ _SIGS = {
     "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
     "swr_embed_bwd_workspace_bytes": (_Z, [_P, _I, _L]),
     "swr_embed_bwd": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
+    "swr_embed_bwd_sort": (C.c_int, [_P, _I, _P, _L, _P, _Z, _P]),
+    "swr_embed_bwd_reduce": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
     "swr_gemm_nt": (C.c_int, [_P, _P]),
     "swr_gemm_nn": (C.c_int, [_P, _P]),
     "swr_gemm_tn_workspace_bytes": (_Z, [_P]),

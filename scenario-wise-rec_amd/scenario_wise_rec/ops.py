@@ -130,6 +130,47 @@ def _mark_touched(params):
         p._swr_touched = True
 
 
+# ------------------------------------------------------------------ work off the critical path (second HIP stream)
+# 1. Embedding backward, sort half: grouping the large tables' entries by row needs only the lookup keys, so
+#    EmbedGather.forward forks it onto a side stream and the backward joins before its reduction.  A chain of a dozen
+#    latency-bound launches (~75 us) disappears behind the dense forward / backward.
+# 2. (SWR_SIDE_DW=1, off) weight gradients: nothing in the backward pass reads them, so the dW products that write
+#    straight into the gradient arena can be forked after dX is enqueued and joined when the autograd engine finishes
+#    (queue_callback).  Measured on config 2: the dW product fills the chip and only slows whatever it overlaps.
+# Under hipGraph capture the forks / joins become parallel branches of the graph.
+SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"
+SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measured: the chip-filling dW product only slows
+                                                                        # whatever it is overlapped with; off by default
+_side = {"streams": {}, "keep": [], "queued": False}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _side["streams"]:
+        _side["streams"][key] = torch.cuda.Stream(device=dev)
+    return _side["streams"][key]
+
+
+def _join_side():
+    _side["queued"] = False
+    for st in _side["streams"].values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+    _side["keep"].clear()          # operands were kept alive until the join is enqueued on the main stream
+
+
+def _on_side_stream(dev, fn, keep):
+    """Run `fn()` (kernel launches only) on the side stream after everything enqueued so far; `keep`: tensors the
+    side work reads, held until the join so that their memory is not recycled by the main stream meanwhile."""
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+    _side["keep"].append(keep)
+    if not _side["queued"]:
+        _side["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+
+
 def _split_like(flat, tensors):
     """Slices of `flat` (first-dim concatenation) shaped like each of `tensors`."""
     out, off = [], 0
@@ -144,6 +185,22 @@ def _split_like(flat, tensors):
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
     __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy")
+
+
+def _grad_slot_layout(plan, weights, n_grad_slots):
+    """(live slots, uses per table, table ids): dense-gradient tables first, row-sparse (large) tables last."""
+    live = plan.sparse[:n_grad_slots]
+    uses = {}
+    for s, (wpos, *_rest) in enumerate(live):
+        uses.setdefault(wpos, []).append(s)
+    order = sorted(uses, key=lambda w: (weights[w].numel() * 4 > plan.dense_limit_bytes, w))
+    return live, uses, {w: i for i, w in enumerate(order)}
+
+
+def join_side_streams():
+    """Make the current stream wait for work forked onto the side stream (end of a captured step, tests)."""
+    for st in _side["streams"].values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
 
 
 class EmbedGather(Function):
@@ -181,6 +238,24 @@ class EmbedGather(Function):
                 "swr_embed_gather_fwd")
         ctx.plan, ctx.keys, ctx.B = plan, keys, B
         ctx.weights = weights            # identity / shapes only
+        ctx.presorted = None
+        if need_keys and ns and B > 0 and SIDE_STREAM and any(ctx.needs_input_grad):   # i.e. a backward may follow
+            # the grouping of the large tables' entries by row needs only the keys: run it NOW on the side stream,
+            # hidden behind the rest of the forward and backward pass; the backward joins before it reduces
+            live, _uses, table_id = _grad_slot_layout(plan, weights, ctx.n_grad_slots)
+            proto = (H.EmbedGradSlot * len(live))()
+            for s, (wpos, idx, vocab, dim, col, seed) in enumerate(live):
+                mode = 1 if weights[wpos].numel() * 4 > plan.dense_limit_bytes else 0
+                proto[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], mode, None, None, None)
+            nbytes = lib.swr_embed_bwd_workspace_bytes(proto, len(live), B)
+            if nbytes:
+                side = _side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    H.check(lib.swr_embed_bwd_sort(proto, len(live), H.ptr(keys), B, H.ptr(ws), nbytes, H.stream()),
+                            "swr_embed_bwd_sort")
+                ctx.presorted = (ws, nbytes, side)
         return out[:, :plan.width] if plan.width != plan.ld else out
 
     @staticmethod
@@ -192,12 +267,7 @@ class EmbedGather(Function):
         dE = H.f32c(dE)
         dev = dE.device
         # tables: dense gradient when small, row-sparse entries when large; sparse tables take the largest ids
-        live = plan.sparse[:ctx.n_grad_slots]
-        uses = {}
-        for s, (wpos, *_rest) in enumerate(live):
-            uses.setdefault(wpos, []).append(s)
-        order = sorted(uses, key=lambda w: (weights[w].numel() * 4 > plan.dense_limit_bytes, w))
-        table_id = {w: i for i, w in enumerate(order)}
+        live, uses, table_id = _grad_slot_layout(plan, weights, ctx.n_grad_slots)
         grads = [None] * len(weights)
         sparse_out = {}
         slots = (H.EmbedGradSlot * len(live))()
@@ -226,9 +296,15 @@ class EmbedGather(Function):
         nbytes = lib.swr_embed_bwd_workspace_bytes(slots, ns, B)
         if nbytes == 0:
             raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 40 lookup slots)")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        H.check(lib.swr_embed_bwd(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
-                                  H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd")
+        if ctx.presorted is not None and ctx.presorted[1] == nbytes:
+            ws, _n, side = ctx.presorted
+            torch.cuda.current_stream(dev).wait_stream(side)          # the sort forked in forward()
+            H.check(lib.swr_embed_bwd_reduce(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
+                                             H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce")
+        else:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            H.check(lib.swr_embed_bwd(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
+                                      H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd")
         for wpos, (urow, ugrad) in sparse_out.items():
             # row-sparse gradient of a large table: consumed by FusedAdam (optim.py); `.grad` stays None
             weights[wpos]._swr_sparse_grad = (urow, ugrad)
@@ -369,8 +445,12 @@ class LinearBNAct(Function):
         if not direct_w:
             dW = torch.empty((Ntot, K), dtype=torch.float32, device=dev)
             db = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
-        gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
-                gsC=N * K, gsColsum=N, ldc=K)
+        def launch_dw():
+            gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
+                    gsC=N * K, gsColsum=N, ldc=K)
+        side_dw = direct_w and SIDE_DW
+        if not side_dw:
+            launch_dw()
         dx = None
         if ctx.needs_input_grad[1]:
             if G > 1:
@@ -386,6 +466,10 @@ class LinearBNAct(Function):
                     gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:
                     dx = dx[:, :K]
+        if side_dw:
+            # forked AFTER the dX product is enqueued: dX is on the critical path and must not share the MFMA pipes
+            # with dW; dW then overlaps whatever the main stream does next (the embedding backward, lower layers)
+            _on_side_stream(dev, launch_dw, (dZ, x, dW, db))
         if direct_w:
             _mark_touched(p_W + tuple(p_b))
             grads = [None] * (nw * (2 if cfg["has_bias"] else 1))
