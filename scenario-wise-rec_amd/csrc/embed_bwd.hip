@@ -838,6 +838,11 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
     const BwdMeta& m = p.m;
     const int64_t n = m.n;
 
+    if (phases & 1) {
+        // both accumulator limbs are contiguous: one zero-fill (a kernel, not a memset node); part of the keys-only half
+        rc = swr_zero_async(acc_hi, (p.off_acc_lo - p.off_acc_hi) * 2, st);
+        if (rc != SWR_OK) return rc;
+    }
     if ((phases & 1) && n > 0) {
         hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
                            st, m, keys, kbuf[0], vbuf[0]);
@@ -854,9 +859,6 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
     const uint32_t* ck = kbuf[p.n_passes & 1];               // where the last pass left the sorted entries
     const uint32_t* sv = vbuf[p.n_passes & 1];
 
-    // both accumulator limbs are contiguous: one zero-fill (a kernel, not a memset node)
-    rc = swr_zero_async(acc_hi, (p.off_acc_lo - p.off_acc_hi) * 2, st);
-    if (rc != SWR_OK) return rc;
     if (p.dm.n_blocks > 0) {
         // LDS sized by the largest group (small groups -> more workgroups per CU); 16-byte loads when every lookup
         // column span is 4-float aligned

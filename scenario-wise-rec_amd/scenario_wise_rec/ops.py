@@ -141,6 +141,8 @@ def _mark_touched(params):
 SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"
 SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measured: the chip-filling dW product only slows
                                                                         # whatever it is overlapped with; off by default
+SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "0"))    # measured: forking the small (tower) products costs more
+                                                                        # in cross-stream edges than the overlap returns
 _side = {"streams": {}, "keep": [], "queued": False}
 
 
@@ -448,7 +450,7 @@ class LinearBNAct(Function):
         def launch_dw():
             gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
                     gsC=N * K, gsColsum=N, ldc=K)
-        side_dw = direct_w and SIDE_DW
+        side_dw = direct_w and SIDE_STREAM and (SIDE_DW or 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP)
         if not side_dw:
             launch_dw()
         dx = None
