@@ -283,6 +283,16 @@ int swr_bce_fwd(const float* p, const void* y, int y_dtype, int64_t M, float* lo
                 void* workspace, size_t workspace_bytes, void* stream);
 int swr_bce_bwd(const float* p, const void* y, int y_dtype, int64_t M, const float* dloss,
                 float* dp, void* stream);
+/* swr_select_fwd(apply_sigmoid = 1, no extra) + swr_bce_fwd in ONE launch, and their two backward kernels in one:
+ * the model's final domain select (mmoe.py:51-55) feeding the trainer's criterion (ctr_trainer.py:70) directly.
+ * Same arithmetic and the same summation trees as the separate entry points (bit-identical p, loss and dV).
+ * `workspace`: swr_bce_workspace_bytes(M).  `ticket`: one device word owned by the caller, zero before the first
+ * call; the kernel leaves it zero (the workgroup that finishes last does the final sum; nothing spins). */
+int swr_select_bce_fwd(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype,
+                       const void* y, int y_dtype, int64_t M, float* p, float* loss,
+                       void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream);
+int swr_select_bce_bwd(const float* p, const void* y, int y_dtype, int D, const void* domain,
+                       int dom_dtype, int64_t M, const float* dloss, float* dV, int64_t lddv, void* stream);
 
 /* -------------------------------------------------------- elementwise -----
  * small helpers of STAR / PPNet / HAMUR middles */

@@ -773,35 +773,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) 
     }
 }
 
-// fixed-order sum of the per-workgroup partial tiles: 4 lanes share one output element (each takes every 4th partial,
-// in order) and are combined with a fixed shuffle tree -> deterministic, 4x the loads in flight of a 1-thread loop
+// fixed-order sum of the per-workgroup partial tiles: L lanes share one output element (lane l takes partials l, l+L,
+// ... in order, UNROLL loads in flight) and are combined with a fixed butterfly -> deterministic; L grows with the
+// number of partials so that the per-lane chain stays a few loads long (tower layers have hundreds of partials)
+template <int L>
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
     const swr_gemm_tn_args& a = kk.a;
     const int g = blockIdx.y;
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
     const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t j = tid >> 2;
-    const int sub = static_cast<int>(tid & 3);
+    const int64_t j = tid / L;
+    const int sub = static_cast<int>(tid % L);
     const int nparts = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
+    auto lane_sum = [&](const float* __restrict__ p, int64_t stride) {
+        float sum = 0.f;
+        int sp = sub;
+        for (; sp + 3 * L < nparts; sp += 4 * L) {
+            const float v0 = p[sp * stride], v1 = p[(sp + L) * stride], v2 = p[(sp + 2 * L) * stride],
+                        v3 = p[(sp + 3 * L) * stride];
+            sum += v0; sum += v1; sum += v2; sum += v3;
+        }
+        for (; sp < nparts; sp += L) sum += p[sp * stride];
+        return sum;
+    };
     float sum = 0.f;
-    if (j < n) {
-        const float* p = kk.part + static_cast<int64_t>(g) * nparts * n + j;
-        for (int sp = sub; sp < nparts; sp += 4) sum += p[sp * n];
-    }
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
+    if (j < n) sum = lane_sum(kk.part + static_cast<int64_t>(g) * nparts * n + j, n);
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off);
     if (j < n && sub == 0) {
         const int64_t r = j / a.K2, c = j - r * a.K2;
         float* dst = a.C + g * a.gsC + r * a.ldc + c;
         *dst = a.accumulate ? *dst + sum : sum;
     }
     float cs = 0.f;
-    if (kk.part_cs && j < a.K1) {
-        const float* p = kk.part_cs + static_cast<int64_t>(g) * nparts * a.K1 + j;
-        for (int sp = sub; sp < nparts; sp += 4) cs += p[sp * a.K1];
-    }
-    cs += __shfl_xor(cs, 1);
-    cs += __shfl_xor(cs, 2);
+    if (kk.part_cs && j < a.K1) cs = lane_sum(kk.part_cs + static_cast<int64_t>(g) * nparts * a.K1 + j, a.K1);
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) cs += __shfl_xor(cs, off);
     if (kk.part_cs && j < a.K1 && sub == 0) {
         float* dst = a.colsum + g * a.gsColsum + j;
         *dst = a.accumulate ? *dst + cs : cs;
@@ -871,7 +878,13 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
     }
 #undef TN_LDS
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n * 4, 256)), static_cast<unsigned>(a.groups)),
-                       dim3(256), 0, st, kk);
+    const dim3 rblock(256);
+#define TN_RED(LV)                                                                                                      \
+    hipLaunchKernelGGL(tn_reduce_kernel<LV>, dim3(static_cast<unsigned>(swr_ceil_div(n * LV, 256)), static_cast<unsigned>(a.groups)), \
+                       rblock, 0, st, kk)
+    if (zsplit > 64) TN_RED(32);
+    else if (zsplit > 16) TN_RED(8);
+    else TN_RED(4);
+#undef TN_RED
     return swr_launch_status();
 }

@@ -379,7 +379,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return r;   // valid in thread 0
 }
 
-#define BCE_PER_BLOCK 4096
+#define BCE_PER_BLOCK 512     // 2 rows per thread: enough workgroups to cover the latency of a 65 536-row batch
 __global__ __launch_bounds__(EW_THREADS) void bce_partial_kernel(const float* __restrict__ p, const void* __restrict__ y,
                                                                  int y_dtype, int64_t M, float* __restrict__ part) {
     __shared__ float sm[EW_THREADS / 64];
@@ -439,6 +439,99 @@ extern "C" int swr_bce_bwd(const float* p, const void* y, int y_dtype, int64_t M
     SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, EW_THREADS))), dim3(EW_THREADS), 0,
                        static_cast<hipStream_t>(stream), p, y, y_dtype, M, dloss, dp);
+    return swr_launch_status();
+}
+
+// ------------------------------------------------------------------- select + BCE in one launch each way
+// The model's last op (domain select of the tower sigmoids, mmoe.py:51-55) and the trainer's criterion
+// (BCELoss, ctr_trainer.py:56,70) back to back: p and the per-workgroup loss partials in one pass, the final fp64 tree
+// by whichever workgroup draws the last ticket (same partials, same tree as swr_bce_fwd -> same bits; no spinning:
+// a workgroup either is last or leaves).  The ticket word must be zero on entry and is zero again on exit.
+__global__ __launch_bounds__(EW_THREADS) void select_bce_fwd_kernel(const float* __restrict__ V, int64_t ldv, int D,
+                                                                    const void* __restrict__ domain, int dom_dtype,
+                                                                    const void* __restrict__ y, int y_dtype, int64_t M,
+                                                                    float* __restrict__ p_out, float* part, int n_part,
+                                                                    uint32_t* ticket, float* __restrict__ loss) {
+    __shared__ float sm[EW_THREADS / 64];
+    __shared__ double smd[EW_THREADS];
+    __shared__ bool is_last;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * BCE_PER_BLOCK;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < BCE_PER_BLOCK; k += EW_THREADS) {
+        const int64_t m = base + k;
+        if (m < M) {
+            const int64_t dom = swr_load_index(domain, dom_dtype, m);
+            float pi = 0.f;
+            if (dom >= 0 && dom < D) pi = swr_sigmoid(V[m * ldv + dom]);
+            p_out[m] = pi;
+            const float yi = swr_load_value(y, y_dtype, m);
+            const float lp = fmaxf(logf(pi), -100.f), l1 = fmaxf(logf(1.f - pi), -100.f);   // torch clamps the logs
+            acc -= yi * lp + (1.f - yi) * l1;
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = tot;
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double a = 0.0;
+    const int per = (n_part + EW_THREADS - 1) / EW_THREADS;
+    for (int t = threadIdx.x * per; t < min((threadIdx.x + 1) * per, n_part); ++t)
+        a += __hip_atomic_load(part + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    smd[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 1; st < EW_THREADS; st <<= 1) {
+        if ((threadIdx.x & (2 * st - 1)) == 0) smd[threadIdx.x] += smd[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = static_cast<float>(smd[0] / static_cast<double>(M));
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+extern "C" int swr_select_bce_fwd(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype, const void* y,
+                                  int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
+                                  uint32_t* ticket, void* stream) {
+    SWR_REQUIRE(V && domain && y && p && loss && workspace && ticket && D > 0 && M > 0 && ldv >= D, SWR_ERR_ARG);
+    SWR_REQUIRE(swr_is_index_dtype(dom_dtype), SWR_ERR_DTYPE);
+    SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
+    SWR_REQUIRE(workspace_bytes >= swr_bce_workspace_bytes(M), SWR_ERR_WORKSPACE);
+    const int nb = static_cast<int>(swr_ceil_div(M, BCE_PER_BLOCK));
+    hipLaunchKernelGGL(select_bce_fwd_kernel, dim3(nb), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), V, ldv, D, domain,
+                       dom_dtype, y, y_dtype, M, p, static_cast<float*>(workspace), nb, ticket, loss);
+    return swr_launch_status();
+}
+
+// dV[m, d] = (d == dom[m]) ? dBCE/dp * p (1 - p) : 0, the two factors rounded exactly as swr_bce_bwd and
+// swr_select_bwd round them
+__global__ __launch_bounds__(EW_THREADS) void select_bce_bwd_kernel(const float* __restrict__ p, const void* __restrict__ y,
+                                                                    int y_dtype, int D, const void* __restrict__ domain,
+                                                                    int dom_dtype, int64_t M, const float* __restrict__ dloss,
+                                                                    float* __restrict__ dV, int64_t lddv) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
+    const int64_t m = idx / D;
+    if (m >= M) return;
+    const int d = static_cast<int>(idx - m * D);
+    float r = 0.f;
+    if (swr_load_index(domain, dom_dtype, m) == d) {
+        const float pi = p[m], yi = swr_load_value(y, y_dtype, m);
+        const float g = dloss[0] * (pi - yi) / fmaxf(pi * (1.f - pi), 1e-12f) / static_cast<float>(M);
+        r = g * pi * (1.f - pi);
+    }
+    dV[m * lddv + d] = r;
+}
+
+extern "C" int swr_select_bce_bwd(const float* p, const void* y, int y_dtype, int D, const void* domain, int dom_dtype,
+                                  int64_t M, const float* dloss, float* dV, int64_t lddv, void* stream) {
+    SWR_REQUIRE(p && y && domain && dloss && dV && D > 0 && M > 0 && lddv >= D, SWR_ERR_ARG);
+    SWR_REQUIRE(swr_is_index_dtype(dom_dtype), SWR_ERR_DTYPE);
+    SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
+    hipLaunchKernelGGL(select_bce_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M * D, EW_THREADS))), dim3(EW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), p, y, y_dtype, D, domain, dom_dtype, M, dloss, dV, lddv);
     return swr_launch_status();
 }
 

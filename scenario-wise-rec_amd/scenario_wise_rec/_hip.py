@@ -127,6 +127,8 @@ _SIGS = {
     "swr_bce_workspace_bytes": (_Z, [_L]),
     "swr_bce_fwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _Z, _P]),
     "swr_bce_bwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _P]),
+    "swr_select_bce_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
+    "swr_select_bce_bwd": (C.c_int, [_P, _P, _I, _I, _P, _I, _L, _P, _P, _L, _P]),
     "swr_mul_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "swr_colsum_workspace_bytes": (_Z, [_L, _I]),
     "swr_colsum": (C.c_int, [_P, _L, _L, _I, _P, _I, _P, _Z, _P]),
@@ -184,6 +186,18 @@ def err_flag(device):
     if key not in _err_flags:
         _err_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _err_flags[key]
+
+
+_tickets = {}
+
+
+def ticket(device):
+    """A zeroed device word per device for kernels that elect their last workgroup (they leave it zero).  Users are
+    serialised on one stream (the loss of a step); allocate before any graph capture (the warm-up steps do)."""
+    key = torch.device(device).index or 0
+    if key not in _tickets:
+        _tickets[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return _tickets[key]
 
 
 def check_errors(device=None):

@@ -41,6 +41,8 @@ def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_re
     a.groups, a.gsA, a.gsB, a.gsC, a.gsBias, a.gsScale = groups, gsA, gsB, gsC, gsBias, gsScale
     fn = lib.swr_gemm_nt if kind == "nt" else lib.swr_gemm_nn
     H.check(fn(C.byref(a), H.stream()), f"swr_gemm_{kind}")
+    if _side["deferred"]:
+        _flush_deferred()          # side-stream work parked until the main stream had its next kernel enqueued
 
 
 def gemm_tn(A, B, C_out, M, K1, K2, colsum=None, accumulate=False, groups=1, gsA=0, gsB=0, gsC=0, gsColsum=0,
@@ -141,9 +143,10 @@ def _mark_touched(params):
 SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"
 SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measured: the chip-filling dW product only slows
                                                                         # whatever it is overlapped with; off by default
+SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "1"))   # measured: 1 (fork at once) 0.862 ms, 3 0.866, 2 0.94 (event nodes stall the branch)
 SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "0"))    # measured: forking the small (tower) products costs more
                                                                         # in cross-stream edges than the overlap returns
-_side = {"streams": {}, "keep": [], "queued": False}
+_side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0}
 
 
 def _side_stream(dev):
@@ -153,20 +156,62 @@ def _side_stream(dev):
     return _side["streams"][key]
 
 
+def join_side_streams():
+    """Make the current stream wait for everything forked onto the side stream so far.  Cheap when nothing is
+    pending.  A cross-stream edge costs ~10 us of latency when the waiting stream is otherwise ready, so callers
+    join where the main stream still has work queued behind it (the trainer joins before `loss.backward()`)."""
+    _flush_deferred()
+    if _side["pending"]:
+        for st in _side["streams"].values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        _side["pending"] = 0
+    _side["keep"].clear()
+
+
 def _join_side():
     _side["queued"] = False
-    for st in _side["streams"].values():
-        torch.cuda.current_stream(st.device).wait_stream(st)
-    _side["keep"].clear()          # operands were kept alive until the join is enqueued on the main stream
+    join_side_streams()
+
+
+def _fork_side(dev, fn, after_event=None):
+    """Run `fn()` (kernel launches / allocations) on the side stream, ordered after `after_event` (or after
+    everything enqueued so far on the current stream)."""
+    side = _side_stream(dev)
+    if after_event is not None:
+        side.wait_event(after_event)
+    else:
+        side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+    _side["pending"] += 1
+
+
+def _defer_side(dev, fn):
+    """Fork `fn` onto the side stream, but only AFTER the next kernel of the main stream has been enqueued
+    (`_flush_deferred()` is called by the GEMM launcher): launched immediately, the side kernels are dispatched
+    ahead of the main stream's next kernel and delay it by their launch latency.  The side work is ordered after
+    the point where `_defer_side` was called (an event recorded now)."""
+    if SIDE_MODE == 1:                 # immediate fork
+        _fork_side(dev, fn)
+        return
+    ev = None
+    if SIDE_MODE == 2:                 # deferred, ordered after an event recorded here
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+    _side["deferred"].append((dev, fn, ev))       # mode 3: deferred, ordered after the main stream's next kernel
+
+
+def _flush_deferred():
+    if _side["deferred"]:
+        todo, _side["deferred"] = _side["deferred"], []
+        for dev, fn, ev in todo:
+            _fork_side(dev, fn, ev)
 
 
 def _on_side_stream(dev, fn, keep):
-    """Run `fn()` (kernel launches only) on the side stream after everything enqueued so far; `keep`: tensors the
-    side work reads, held until the join so that their memory is not recycled by the main stream meanwhile."""
-    side = _side_stream(dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        fn()
+    """Backward-pass helper: run `fn()` on the side stream after everything enqueued so far; `keep`: tensors the
+    side work reads, held until the join (queued for the end of the autograd pass)."""
+    _fork_side(dev, fn)
     _side["keep"].append(keep)
     if not _side["queued"]:
         _side["queued"] = True
@@ -197,12 +242,6 @@ def _grad_slot_layout(plan, weights, n_grad_slots):
         uses.setdefault(wpos, []).append(s)
     order = sorted(uses, key=lambda w: (weights[w].numel() * 4 > plan.dense_limit_bytes, w))
     return live, uses, {w: i for i, w in enumerate(order)}
-
-
-def join_side_streams():
-    """Make the current stream wait for work forked onto the side stream (end of a captured step, tests)."""
-    for st in _side["streams"].values():
-        torch.cuda.current_stream(st.device).wait_stream(st)
 
 
 class EmbedGather(Function):
@@ -251,13 +290,14 @@ class EmbedGather(Function):
                 proto[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], mode, None, None, None)
             nbytes = lib.swr_embed_bwd_workspace_bytes(proto, len(live), B)
             if nbytes:
-                side = _side_stream(dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                    H.check(lib.swr_embed_bwd_sort(proto, len(live), H.ptr(keys), B, H.ptr(ws), nbytes, H.stream()),
+                box = {"nbytes": nbytes}
+
+                def sort_now(box=box, proto=proto, n=len(live), keys=keys, B=B, dev=dev):
+                    box["ws"] = torch.empty(box["nbytes"], dtype=torch.uint8, device=dev)
+                    H.check(lib.swr_embed_bwd_sort(proto, n, H.ptr(keys), B, H.ptr(box["ws"]), box["nbytes"], H.stream()),
                             "swr_embed_bwd_sort")
-                ctx.presorted = (ws, nbytes, side)
+                _defer_side(dev, sort_now)
+                ctx.presorted = box
         return out[:, :plan.width] if plan.width != plan.ld else out
 
     @staticmethod
@@ -298,9 +338,9 @@ class EmbedGather(Function):
         nbytes = lib.swr_embed_bwd_workspace_bytes(slots, ns, B)
         if nbytes == 0:
             raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 40 lookup slots)")
-        if ctx.presorted is not None and ctx.presorted[1] == nbytes:
-            ws, _n, side = ctx.presorted
-            torch.cuda.current_stream(dev).wait_stream(side)          # the sort forked in forward()
+        if ctx.presorted is not None and ctx.presorted["nbytes"] == nbytes:
+            join_side_streams()                                       # the sort forked in forward() (no-op if joined)
+            ws = ctx.presorted["ws"]
             H.check(lib.swr_embed_bwd_reduce(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
                                              H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce")
         else:
@@ -463,6 +503,8 @@ class LinearBNAct(Function):
                 if Ntot % 4 == 0 and K >= 32:
                     # dX = dZ @ W as an "nt" product against the transposed weights (a small copy): the [N, K]
                     # layout is the one the bf16-split MFMA kernel stages into LDS
+                    # (forking this 5 us copy onto the side stream at forward time was measured: the extra
+                    # cross-stream edge costs ~12 us of main-stream latency, more than the copy)
                     gemm("nt", dZ, W.t().contiguous(), dx, M, K, Ntot)
                 else:
                     gemm("nn", dZ, W, dx, M, K, Ntot)
@@ -657,7 +699,78 @@ def bce_mean(p, y):
     return BCEMean.apply(p, y)
 
 
+class SelectBCE(Function):
+    """(p, loss) = (domain_select(sigmoid(V)), BCELoss(p, y)) in one launch each way: the model's last op feeding the
+    trainer's criterion directly (mmoe.py:51-55 + ctr_trainer.py:70).  p stays a differentiable output: a gradient
+    arriving on p (someone used the probabilities as well) is added through the plain select backward."""
+
+    @staticmethod
+    def forward(ctx, V, domain, y):
+        H.require_device(V, domain, y)
+        V = H.f32c(V)
+        M, D = V.shape
+        domain, y = domain.contiguous(), y.contiguous()
+        dev = V.device
+        p = torch.empty(M, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        nbytes = lib.swr_bce_workspace_bytes(M)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        H.check(lib.swr_select_bce_fwd(H.ptr(V), V.stride(0) if M > 1 else D, D, H.ptr(domain), H.dtype_code(domain),
+                                       H.ptr(y), H.dtype_code(y), M, H.ptr(p), H.ptr(loss), H.ptr(ws), nbytes,
+                                       H.ptr(H.ticket(dev)), H.stream()), "swr_select_bce_fwd")
+        ctx.save_for_backward(p, domain, y)
+        ctx.D = D
+        ctx.set_materialize_grads(False)
+        return p, loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp, dloss):
+        p, domain, y = ctx.saved_tensors
+        M, D = p.numel(), ctx.D
+        dV = None
+        if dloss is not None:
+            dV = torch.empty((M, D), dtype=torch.float32, device=p.device)
+            dloss = dloss.float().contiguous()
+            H.check(lib.swr_select_bce_bwd(H.ptr(p), H.ptr(y), H.dtype_code(y), D, H.ptr(domain), H.dtype_code(domain), M,
+                                           H.ptr(dloss), H.ptr(dV), D, H.stream()), "swr_select_bce_bwd")
+        if dp is not None:
+            extra = torch.empty((M, D), dtype=torch.float32, device=p.device)
+            dp = H.f32c(dp).contiguous()
+            H.check(lib.swr_select_bwd(H.ptr(dp), H.ptr(p), D, H.ptr(domain), H.dtype_code(domain), 1, 0, H.ptr(extra), D,
+                                       None, M, H.stream()), "swr_select_bwd")
+            dV = extra if dV is None else dV + extra
+        return dV, None, None
+
+
+class fused_bce(object):
+    """`with fused_bce(y) as f: y_pred = model(x)`: while active, the model's final `domain_select(V, domain)` (tower
+    sigmoids, no extra term) also produces the mean BCE against `y` in the same launch.  Afterwards
+    `f.loss_for(y_pred)` is that loss if `y_pred` IS the selected tensor (nothing was applied on top), else None --
+    the caller then evaluates its criterion the ordinary way."""
+    _active = None
+
+    def __init__(self, y):
+        self.y, self.p, self.loss = y, None, None
+
+    def __enter__(self):
+        self._prev, fused_bce._active = fused_bce._active, self
+        return self
+
+    def __exit__(self, *exc):
+        fused_bce._active = self._prev
+        return False
+
+    def loss_for(self, y_pred):
+        return self.loss if (self.p is not None and y_pred is self.p) else None
+
+
 def domain_select(V, domain, apply_sigmoid=True, extra=None):
+    req = fused_bce._active
+    if (req is not None and req.p is None and apply_sigmoid and extra is None and V.dim() == 2 and
+            req.y.numel() == V.shape[0] and V.shape[0] > 0):
+        req.p, req.loss = SelectBCE.apply(V, domain, req.y.reshape(-1))
+        return req.p
     return DomainSelect.apply(V, domain, apply_sigmoid, extra)
 
 

@@ -101,12 +101,7 @@ class DataParallelStep(object):
 
     # ---- pieces ---------------------------------------------------------------------------------------
     def _forward_backward(self, x_dict, y):
-        tr = self.trainer
-        y_pred = tr.model(x_dict)
-        loss = tr.criterion(y_pred, y)
-        tr.model.zero_grad()
-        loss.backward()
-        return loss.detach()
+        return self.trainer.forward_backward(x_dict, y).detach()
 
     def _sparse(self):
         arena = self.trainer.model.arena()

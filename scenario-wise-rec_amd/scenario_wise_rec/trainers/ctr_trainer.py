@@ -56,13 +56,35 @@ class CTRTrainer(object):
         self.model_path = model_path
 
     # ---- one optimisation step (`ctr_trainer.py:67-73`) ---------------------------------------------
-    def train_step(self, x_dict, y):
-        y_pred = self.model(x_dict)
-        loss = self.criterion(y_pred, y)
+    def forward_backward(self, x_dict, y):
+        """forward -> criterion -> zero_grad -> backward (`ctr_trainer.py:69-72`); returns the loss tensor."""
+        if isinstance(self.criterion, BCELoss):
+            # the model's final domain select and the criterion in one launch when the model output IS the selected
+            # probabilities (every multi-domain model here); otherwise the criterion runs the ordinary way
+            with ops.fused_bce(y) as f:
+                y_pred = self.model(x_dict)
+            loss = f.loss_for(y_pred)
+            if loss is None:
+                loss = self.criterion(y_pred, y)
+        else:
+            y_pred = self.model(x_dict)
+            loss = self.criterion(y_pred, y)
         self.model.zero_grad()
-        loss.backward()
+        ops.join_side_streams()      # work forked during the forward pass (embedding sort, W^T copies): joined here,
+        loss.backward(gradient=self._one(loss))     # where the main stream still has the whole backward queued behind
+        return loss
+
+    def train_step(self, x_dict, y):
+        loss = self.forward_backward(x_dict, y)
         self.optimizer.step()
         return loss
+
+    def _one(self, loss):
+        # d(loss)/d(loss): autograd would fill a fresh ones tensor every step (one more launch on a launch-bound path)
+        one = getattr(self, "_grad_one", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+            one = self._grad_one = torch.ones_like(loss)
+        return one
 
     def train_one_epoch(self, data_loader, log_interval=10):
         self.model.train()

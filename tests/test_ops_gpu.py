@@ -316,3 +316,38 @@ def test_moe_mix_forward_backward(M, H_, n_expert, sel, pad):
     np.testing.assert_allclose(got[:, g_col:].reshape(M, n_out, n_sel), dG, rtol=0, atol=3e-5)
     if pad:
         assert not np.any(got[:, n_expert * H_:g_col])
+
+
+@pytest.mark.parametrize("M,D,ydt", [(5000, 5, torch.float32), (1, 3, torch.float32), (4097, 2, torch.int64)])
+def test_fused_select_bce_is_bitwise_the_two_step_path(M, D, ydt):
+    """swr_select_bce_fwd / _bwd against swr_select_fwd -> swr_bce_fwd and their backward kernels: identical bits for
+    p, the loss and dV (same arithmetic, same summation trees); out-of-range domain ids give p = 0 exactly."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(M)
+    V0 = torch.randn(M, D, device="cuda", generator=g) * 3
+    dom = torch.randint(0, D + 1, (M,), device="cuda", generator=g)           # D itself: no tower -> p = 0
+    y = (torch.rand(M, device="cuda", generator=g) < 0.3).to(ydt)
+    Va = V0.clone().requires_grad_(True)
+    pa = ops.domain_select(Va, dom)
+    la = ops.bce_mean(pa, y)
+    la.backward()
+    Vb = V0.clone().requires_grad_(True)
+    with ops.fused_bce(y) as f:
+        pb = ops.domain_select(Vb, dom)
+    lb = f.loss_for(pb)
+    assert lb is not None and f.loss_for(pb * 1.0) is None
+    lb.backward()
+    assert torch.equal(pa, pb) and torch.equal(la, lb) and torch.equal(Va.grad, Vb.grad)
+    for _ in range(3):                                                         # the ticket word is left clean
+        with ops.fused_bce(y) as f2:
+            p2 = ops.domain_select(V0, dom)
+        assert torch.equal(f2.loss_for(p2), la)
+    # a gradient arriving on p as well is added through the plain select backward
+    Vc = V0.clone().requires_grad_(True)
+    with ops.fused_bce(y) as f3:
+        pc = ops.domain_select(Vc, dom)
+    (f3.loss_for(pc) + pc.sum() * 0.5).backward()
+    Vd = V0.clone().requires_grad_(True)
+    pd_ = ops.domain_select(Vd, dom)
+    (ops.bce_mean(pd_, y) + pd_.sum() * 0.5).backward()
+    torch.testing.assert_close(Vc.grad, Vd.grad, rtol=1e-6, atol=1e-9)
