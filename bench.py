@@ -283,9 +283,22 @@ def measure_roofline(cfg, model, trainer, x, dev, iters):
     flops = 2.0 * B * n1 * k0
     achieved = flops / (ms * 1e-3) / 1e12
     return {"kernel": "gemm_tn_kernel (+tn_reduce_kernel)", "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("void gemm_tn_kernel<5>"),
+            "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)",
+            "algorithmic_bytes_per_launch": 4.0 * B * (n1 + k0),
             "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms,
             "also": {"embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters)}}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (tools/prof_round.sh ->
+    tools/pmc_to_json.py), or None: counters cannot be collected from inside the bench process."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def gather_roofline(cfg, model, x, dev, iters):
@@ -318,7 +331,7 @@ def gather_roofline(cfg, model, x, dev, iters):
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-            "kernel": "embed_gather_kernel"}
+            "traffic": pmc_traffic("void embed_gather_kernel<4>"), "kernel": "embed_gather_kernel"}
 
 
 if __name__ == "__main__":

@@ -93,6 +93,7 @@ def _plan_part(plan, weights, wpos, layer, x, sparse, dense):
 
 def _run_plan(plan, weights):
     plan.ld = (plan.width + 3) // 4 * 4
+    plan.want_grad = torch.is_grad_enabled()       # Function.forward itself always runs with grad mode off
     return ops.EmbedGather.apply(plan, *weights)
 
 

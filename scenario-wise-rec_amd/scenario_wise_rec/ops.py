@@ -231,7 +231,7 @@ def _split_like(flat, tensors):
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad")
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -280,7 +280,7 @@ class EmbedGather(Function):
         ctx.plan, ctx.keys, ctx.B = plan, keys, B
         ctx.weights = weights            # identity / shapes only
         ctx.presorted = None
-        if need_keys and ns and B > 0 and SIDE_STREAM and any(ctx.needs_input_grad):   # i.e. a backward may follow
+        if need_keys and ns and B > 0 and SIDE_STREAM and getattr(plan, "want_grad", False):   # a backward may follow
             # the grouping of the large tables' entries by row needs only the keys: run it NOW on the side stream,
             # hidden behind the rest of the forward and backward pass; the backward joins before it reduces
             live, _uses, table_id = _grad_slot_layout(plan, weights, ctx.n_grad_slots)

@@ -20,6 +20,8 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def hip_merge_rows(urow, ugrad, vocab):
     """Deterministic merge of gathered row entries on the device: (row id or -1, gradient) x n ->
@@ -142,6 +144,7 @@ class DataParallelStep(object):
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             loss = self._forward_backward(self.x, self.y)
+            ops.join_side_streams()
         arena, big, sparse = self._sparse()
         buffers = [(torch.empty(self.world_size * r.numel(), dtype=r.dtype, device=r.device),
                     torch.empty((self.world_size * g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device))

@@ -12,6 +12,8 @@ Capture rules learnt the hard way on ROCm 7.2 / torch 2.10 (see DESIGN.md "hipGr
 """
 import torch
 
+from .. import ops
+
 
 class GraphedStep(object):
     def __init__(self, trainer, x_dict, y, warmup=2, step_fn=None):
@@ -29,6 +31,7 @@ class GraphedStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             loss = fn(self.x, self.y)
+            ops.join_side_streams()        # nothing forked may outlive the capture (no-op after a full step)
         self.loss = loss.detach()
         del loss
 
