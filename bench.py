@@ -192,7 +192,7 @@ def main():
 
     # ---- warm-up (eager), then capture the step into hipGraph(s) ------------------------------------------
     # 1 GPU: the whole step is ONE graph.  N GPUs: forward+backward and merge+optimizer are two graphs with the
-    # RCCL collectives (one all-reduce + two all-gathers) issued eagerly in between (parallel.DataParallelStep).
+    # one RCCL all-gather issued eagerly in between (parallel.DataParallelStep).
     graph = None
     if not args.no_graph:
         try:

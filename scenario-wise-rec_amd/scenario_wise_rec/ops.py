@@ -319,8 +319,12 @@ class EmbedGather(Function):
             if sparse_mode:
                 if wpos not in sparse_out:
                     cnt = len(uses[wpos]) * B
-                    sparse_out[wpos] = (torch.empty(cnt, dtype=torch.int32, device=dev),
-                                        torch.empty((cnt, dim), dtype=torch.float32, device=dev))
+                    pre = getattr(w, "_swr_sparse_out", None)      # caller-owned outputs (the data-parallel send buffer)
+                    if pre is not None and tuple(pre[0].shape) == (cnt,) and tuple(pre[1].shape) == (cnt, dim):
+                        sparse_out[wpos] = pre
+                    else:
+                        sparse_out[wpos] = (torch.empty(cnt, dtype=torch.int32, device=dev),
+                                            torch.empty((cnt, dim), dtype=torch.float32, device=dev))
                 urow, ugrad = sparse_out[wpos]
                 slots[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], 1, None, urow.data_ptr(), ugrad.data_ptr())
             else:

@@ -43,34 +43,55 @@ def hip_merge_rows(urow, ugrad, vocab):
     return out_row, out_grad
 
 
-def communicate(dense_grad, sparse_grads, world_size, group=None, buffers=None):
-    """The collectives of the exchange step, nothing else: one all-reduce of the flat gradient arena and, per large
-    table, all-gathers of the per-rank (row id, gradient) entries.  Returns the gathered (rows, grads, vocab) list.
-    `buffers` (optional) are preallocated gather targets [(rows, grads), ...] -- static addresses for hipGraph use."""
-    if dense_grad is not None and dense_grad.numel():
-        dist.all_reduce(dense_grad, op=dist.ReduceOp.SUM, group=group)
-    gathered = []
-    for t, (urow, ugrad, vocab) in enumerate(sparse_grads):
+def exchange_layout(dense_grad, sparse_grads):
+    """Layout of one rank's message, in fp32 words: [gradient arena | per large table: row ids (int32 bits), gradients]."""
+    A = dense_grad.numel() if dense_grad is not None else 0
+    offs, pos = [], A
+    for urow, ugrad, vocab in sparse_grads:
         n, dim = ugrad.shape
-        if buffers is not None:
-            rows, grads = buffers[t]
-        else:
-            rows = torch.empty(world_size * n, dtype=urow.dtype, device=urow.device)
-            grads = torch.empty((world_size * n, dim), dtype=ugrad.dtype, device=ugrad.device)
-        dist.all_gather_into_tensor(rows, urow.contiguous(), group=group)
-        dist.all_gather_into_tensor(grads, ugrad.contiguous(), group=group)
-        gathered.append((rows, grads, vocab))
-    return gathered
+        offs.append((pos, pos + n, n, dim, vocab))
+        pos += n + n * dim
+    return A, offs, pos
+
+
+def communicate(dense_grad, sparse_grads, world_size, group=None, buffers=None):
+    """The collective of the exchange step, nothing else: ONE all-gather of every rank's packed message (the flat
+    gradient arena, and per large table the row ids + row gradients of its reduced entries).  xGMI is point-to-point
+    and a step has no other exchange, so one large collective beats an all-reduce plus two all-gathers per table.
+    `buffers` = (send, recv) preallocated (static addresses for hipGraph use); tensors that already live inside
+    `send` (DataParallelStep points the backward's outputs there) are not copied."""
+    A, offs, total = exchange_layout(dense_grad, sparse_grads)
+    ref = dense_grad if A else sparse_grads[0][1]
+    if buffers is None:
+        send = torch.empty(total, dtype=torch.float32, device=ref.device)
+        recv = torch.empty(world_size * total, dtype=torch.float32, device=ref.device)
+    else:
+        send, recv = buffers
+    base = send.data_ptr()
+    if A and dense_grad.data_ptr() != base:
+        send[:A].copy_(dense_grad.reshape(-1))
+    for (r0, r1, n, dim, _v), (urow, ugrad, _vocab) in zip(offs, sparse_grads):
+        if urow.data_ptr() != base + 4 * r0:
+            send[r0:r1].copy_(urow.contiguous().view(torch.float32))        # bit copy of the int32 ids
+        if ugrad.data_ptr() != base + 4 * r1:
+            send[r1:r1 + n * dim].copy_(ugrad.reshape(-1))
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv, A, offs, total
 
 
 def finish(dense_grad, gathered, world_size, merge_rows=hip_merge_rows):
-    """Device-side remainder of the exchange: gradient averaging and the deterministic merge of the gathered row
-    entries (every rank computes bit-identical results)."""
-    if dense_grad is not None and dense_grad.numel():
+    """Device-side remainder of the exchange: the arenas of all ranks are summed in rank order and averaged, the
+    gathered row entries are merged deterministically (every rank computes bit-identical results)."""
+    recv, A, offs, total = gathered
+    R = recv.view(world_size, total)
+    if A:
+        dense_grad.reshape(-1).copy_(R[:, :A].sum(dim=0))
         dense_grad.mul_(1.0 / world_size)
     merged = []
-    for rows, grads, vocab in gathered:
-        r, g = merge_rows(rows, grads, vocab)
+    for r0, r1, n, dim, vocab in offs:
+        rows = R[:, r0:r1].contiguous().view(torch.int32).reshape(-1)
+        grads = R[:, r1:r1 + n * dim].reshape(world_size * n, dim)
+        r, g = merge_rows(rows, grads.contiguous(), vocab)
         merged.append((r, g.mul_(1.0 / world_size)))
     return merged
 
@@ -123,11 +144,27 @@ class DataParallelStep(object):
                     p.grad.mul_(1.0 / self.world_size)
         else:
             arena, big, sparse = self._sparse()
-            merged = exchange_gradients(arena["g"], sparse, self.world_size, self.group)
+            bufs = self._exchange_buffers(arena["g"], big, sparse)
+            merged = finish(arena["g"], communicate(arena["g"], sparse, self.world_size, self.group, bufs), self.world_size)
             for p, rg in zip(big, merged):
                 p._swr_sparse_grad = rg
         tr.optimizer.step()
         return loss
+
+    def _exchange_buffers(self, dense, big, sparse):
+        """(send, recv) for the current message layout; the large tables' backward is pointed at its slots of `send`
+        (`_swr_sparse_out`, read by ops.EmbedGather.backward) so that from the next step on nothing is copied but the
+        0.5 MB gradient arena."""
+        A, offs, total = exchange_layout(dense, sparse)
+        key = (A, tuple(offs))
+        if getattr(self, "_xb_key", None) != key:
+            self._xb_key = key
+            self._xb = (torch.empty(total, dtype=torch.float32, device=dense.device),
+                        torch.empty(self.world_size * total, dtype=torch.float32, device=dense.device))
+            send = self._xb[0]
+            for p, (r0, r1, n, dim, _v) in zip(big, offs):
+                p._swr_sparse_out = (send[r0:r1].view(torch.int32), send[r1:r1 + n * dim].view(n, dim))
+        return self._xb
 
     # ---- captured variant -----------------------------------------------------------------------------
     def capture(self, x_dict, y, warmup=2):
@@ -145,18 +182,21 @@ class DataParallelStep(object):
         with torch.cuda.graph(g1):
             loss = self._forward_backward(self.x, self.y)
             ops.join_side_streams()
-        arena, big, sparse = self._sparse()
-        buffers = [(torch.empty(self.world_size * r.numel(), dtype=r.dtype, device=r.device),
-                    torch.empty((self.world_size * g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device))
-                   for r, g, _ in sparse]
-        gathered = [(rows, grads, v) for (rows, grads), (_, _, v) in zip(buffers, sparse)]
+            arena, big, sparse = self._sparse()
+            buffers = self._exchange_buffers(arena["g"], big, sparse)          # established by the warm-up steps
+            A, offs, total = exchange_layout(arena["g"], sparse)
+            if A:
+                buffers[0][:A].copy_(arena["g"].reshape(-1))                   # the only packing copy, inside graph 1
+        for (urow, ugrad, _v), (r0, r1, n, dim, _v2) in zip(sparse, offs):
+            assert urow.data_ptr() == buffers[0].data_ptr() + 4 * r0 and ugrad.data_ptr() == buffers[0].data_ptr() + 4 * r1
+        gathered = (buffers[1], A, offs, total)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool()):
             merged = finish(arena["g"], gathered, self.world_size)
             for p, rg in zip(big, merged):
                 p._swr_sparse_grad = rg
             self.trainer.optimizer.step()
-        self._graphs = (g1, g2, arena["g"], sparse, buffers)
+        self._graphs = (g1, g2, buffers)
         self.loss = loss
         return self
 
@@ -166,8 +206,8 @@ class DataParallelStep(object):
         self.y.copy_(y, non_blocking=True)
 
     def replay(self):
-        g1, g2, dense, sparse, buffers = self._graphs
+        g1, g2, (send, recv) = self._graphs
         g1.replay()
-        communicate(dense, sparse, self.world_size, self.group, buffers)
+        dist.all_gather_into_tensor(recv, send, group=self.group)       # the step's one collective
         g2.replay()
         return self.loss
