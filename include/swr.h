@@ -264,6 +264,41 @@ int swr_moe_mix_bwd(const swr_mix_desc* desc_host, const float* dP, int64_t lddp
                     const float* Y, int64_t ldy, float* dY, int64_t lddy, int accumulate,
                     int64_t M, void* stream);
 
+/* ------------------------------------------------------ tower heads -------
+ * G independent [Linear(K, H) -> BatchNorm1d(H) (batch statistics) -> ReLU -> Linear(H, 1)] evaluated together: the
+ * per-domain `towers` of mmoe.py:38-41,50-51 (ple.py, sharebottom.py alike) with tower_params = {"dims": [H]}, each
+ * reading its own K columns of X (column block g).  One kernel per pass over the batch, thread = (row, tower); the
+ * post-activation values are never stored (the backward recomputes them from Z1).  K in {8,16,32}, H in
+ * {4,8,16,32} (swr_tower_supported); other shapes go through swr_gemm_* + swr_bn_* + swr_affine_act_*.
+ *   swr_tower_fwd_linear : Z1[M, G*H] = X_g W1_g^T + b1 (+ stat_partials [ceil(M/32)][G*H][2] for swr_bn_finalize)
+ *   swr_tower_fwd_head   : V[M, G]    = relu(scale * Z1 + shift)_g . w2_g + b2_g
+ *   swr_tower_bwd        : from dV[M, G]: dgamma, dbeta, dw2[G*H], db2[G] (written, or added when `accumulate`),
+ *                          dZ1[M, G*H] (feed swr_gemm_tn for dW1 / db1) and dX[M, G*K] (skipped when null).
+ *                          ca / cb / cc: [G*H] scratch for the BatchNorm backward coefficients. */
+typedef struct {
+    int64_t M;
+    int32_t G, K, H, accumulate;
+    const float* X;  int64_t ldx;                 /* [M, >= G*K] */
+    const float* W1; const float* b1;             /* [G][H][K], [G][H] (b1 nullable) */
+    float* Z1;       int64_t ldz;                 /* [M, >= G*H], ldz % 4 == 0 */
+    float* stat_partials;                         /* fwd_linear: nullable */
+    const float* scale; const float* shift;       /* [G*H] BatchNorm as an affine map (swr_bn_finalize) */
+    const float* mean;  const float* rstd; const float* gamma;   /* backward */
+    const float* w2; const float* b2;             /* [G][H], [G] (b2 nullable) */
+    float* V;        int64_t ldv;                 /* fwd_head: [M, >= G] */
+    const float* dV; int64_t lddv;                /* bwd */
+    float* ca; float* cb; float* cc;              /* [G*H] each */
+    float* dgamma; float* dbeta; float* dw2; float* db2;        /* nullable */
+    float* dZ1;      int64_t lddz;
+    float* dX;       int64_t lddx;                /* nullable */
+} swr_tower_args;
+
+int swr_tower_supported(int K, int H);
+int swr_tower_fwd_linear(const swr_tower_args* args_host, void* stream);
+int swr_tower_fwd_head(const swr_tower_args* args_host, void* stream);
+size_t swr_tower_bwd_workspace_bytes(int64_t M, int G, int H);
+int swr_tower_bwd(const swr_tower_args* args_host, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------- domain select + loss ------
  * final = 0; for d: final = where(domain_id == d, y_d, final)
  * (mmoe.py:53-55, base_example.py:72-74): integer equality on the raw id, ids

@@ -1,0 +1,409 @@
+// Per-domain tower heads: G independent [Linear(K, H) -> BatchNorm1d(H) -> ReLU -> Linear(H, 1)] evaluated together
+// (the `towers` of mmoe.py:38-41,50-51 / ple.py / sharebottom.py with tower_params = {"dims": [H]}).
+//
+// The products are tiny (K = 32, H = 16 at the KuaiRand config: 0.3 GFLOP per pass) but the activations are not
+// ([B, G*K] and [B, G*H] fp32 = 42 + 21 MB at B = 65 536), so the generic GEMM + BN + activation launches (nine in the
+// backward pass) are bound by HBM passes and launch latency.  Here every pass over the batch is ONE kernel whose
+// thread owns one (row, tower) pair, keeps the H hidden values in registers and reads the weights as wave-uniform
+// scalars:
+//
+//   forward  : tower_linear_fwd  Z1 = X_g W1_g^T + b1, with the per-32-row (mean, M2) tiles of the BatchNorm statistics
+//              (swr_bn_finalize)
+//              tower_head_fwd    V[:, g] = relu(scale * Z1 + shift)_g . w2_g + b2_g          (A1 is never stored)
+//   backward : tower_bwd_stats   per-64-row tiles of (sum dY, sum dY * xhat) and of dW2, db2, A1 recomputed from Z1
+//              tower_bwd_finalize   fixed-order fp64 sums -> dgamma, dbeta, dW2, db2 and the BN backward coefficients
+//              tower_bwd_apply   dZ1 = ca dY + cb (Z1 - mean) + cc  and  dX_g = dZ1_g W1_g
+//              (dW1, db1 = the ordinary grouped weight-gradient product swr_gemm_tn on dZ1, X)
+//
+// All reductions are per-tile partials summed in a fixed order: deterministic.
+#include "common.h"
+
+#define TW_THREADS 256
+
+struct TowerK {
+    swr_tower_args a;
+    float* bn_partials;     // [tiles of 64 rows][G*H][2]   (sum dY, sum dY * xhat)
+    float* head_partials;   // [tiles][G*H + G]             (dW2 columns, then db2 per tower)
+};
+
+__device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes of a half-wave (one 32-row tile)
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int N4>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&v)[4 * N4]) {
+#pragma unroll
+    for (int q = 0; q < N4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
+// Tiles of TW_THREADS rows x W columns cross HBM with consecutive lanes on consecutive 16-byte pieces of a row
+// (coalesced) and live in LDS with a row pitch of W + 4 floats (the per-thread 16-byte row accesses are then
+// conflict-free).  A thread owns one row of the tile.
+template <int W>
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t ld, int rows, float* lds) {
+    constexpr int P = W + 4, Q = W / 4;
+    for (int idx = threadIdx.x; idx < rows * Q; idx += TW_THREADS) {
+        const int r = idx / Q, c = idx - r * Q;
+        *reinterpret_cast<float4*>(lds + r * P + 4 * c) = *reinterpret_cast<const float4*>(src + r * ld + 4 * c);
+    }
+}
+template <int W>
+__device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t ld, int rows, const float* lds) {
+    constexpr int P = W + 4, Q = W / 4;
+    for (int idx = threadIdx.x; idx < rows * Q; idx += TW_THREADS) {
+        const int r = idx / Q, c = idx - r * Q;
+        *reinterpret_cast<float4*>(dst + r * ld + 4 * c) = *reinterpret_cast<const float4*>(lds + r * P + 4 * c);
+    }
+}
+
+// The hidden index j is a REAL loop (one weight row = K wave-uniform scalars per trip) and the H values of a row live
+// in the LDS tile, not in a register array: fully unrolled, hipcc hoists all H*K scalar weight loads to the top of
+// the kernel and spills ~450 SGPRs through v_writelane / v_readlane (measured: 3x slower).
+
+// ---------------------------------------------------------------------------------- forward, first layer
+template <int K, int H>
+__global__ __launch_bounds__(TW_THREADS) void tower_linear_fwd_kernel(const TowerK kk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PX = K + 4, PZ = H + 4;
+    float* lx = lds;                                          // [TW_THREADS][PX]
+    float* lz = lds;                                          // [TW_THREADS][PZ], reuses the X tile once it is in registers
+    const swr_tower_args& a = kk.a;
+    const int g = blockIdx.y;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
+    const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
+    const bool valid = static_cast<int>(threadIdx.x) < rows;
+    tile_load<K>(a.X + m0 * a.ldx + static_cast<int64_t>(g) * K, a.ldx, rows, lx);
+    __syncthreads();
+    float x[K];
+    load_row<K / 4>(lx + threadIdx.x * PX, x);
+    __syncthreads();
+    const float* __restrict__ w = a.W1 + static_cast<int64_t>(g) * H * K;      // wave-uniform: scalar loads
+#pragma unroll 1
+    for (int j = 0; j < H; ++j) {
+        float acc = a.b1 ? a.b1[g * H + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[j * K + k], acc);
+        lz[threadIdx.x * PZ + j] = valid ? acc : 0.f;
+    }
+    __syncthreads();
+    tile_store<H>(a.Z1 + m0 * a.ldz + g * H, a.ldz, rows, lz);
+    if (!a.stat_partials) return;
+    // (mean, M2) per 32-row tile and column, the layout swr_bn_finalize merges: TPP threads share one (tile, column),
+    // each over H of its rows (two passes over LDS), combined with a fixed butterfly
+    constexpr int TPP = 32 / H > 0 ? 32 / H : 1;              // H <= 32
+    constexpr int RPT = 32 / TPP;
+    const int pair = threadIdx.x / TPP, part = threadIdx.x % TPP;
+    const int t8 = pair / H, j = pair % H;
+    const int64_t tile = (m0 >> 5) + t8;
+    const int tile_rows = static_cast<int>(min<int64_t>(32, a.M - tile * 32));
+    const float* col = lz + (t8 * 32) * PZ + j;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) sum += col[(i * TPP + part) * PZ];           // rows past the end hold 0
+#pragma unroll
+    for (int off = 1; off < TPP; off <<= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / static_cast<float>(tile_rows > 0 ? tile_rows : 1);
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = i * TPP + part;
+        const float d = r < tile_rows ? col[r * PZ] - mean : 0.f;
+        m2 = fmaf(d, d, m2);
+    }
+#pragma unroll
+    for (int off = 1; off < TPP; off <<= 1) m2 += __shfl_xor(m2, off);
+    if (part == 0 && tile_rows > 0) {
+        float* p = a.stat_partials + (tile * (a.G * H) + g * H + j) * 2;
+        p[0] = mean;
+        p[1] = m2;
+    }
+}
+
+// --------------------------------------------------------------------------- forward, BN + ReLU + output layer
+template <int H>
+__global__ __launch_bounds__(TW_THREADS) void tower_head_fwd_kernel(const TowerK kk) {
+    const swr_tower_args& a = kk.a;
+    const int64_t m = static_cast<int64_t>(blockIdx.x) * TW_THREADS + threadIdx.x;
+    if (m >= a.M) return;
+    for (int g = 0; g < a.G; ++g) {
+        float z[H];
+        load_row<H / 4>(a.Z1 + m * a.ldz + g * H, z);
+        float v = a.b2 ? a.b2[g] : 0.f;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const float act = fmaxf(fmaf(z[j], a.scale[g * H + j], a.shift[g * H + j]), 0.f);
+            v = fmaf(act, a.w2[g * H + j], v);
+        }
+        a.V[m * a.ldv + g] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------- backward, statistics
+// Z1 tile and dV column staged in LDS; TPP threads share one (64-row tile, column) and walk H of its rows each with the
+// column's coefficients in registers: no per-element shuffles.
+template <int H>
+__global__ __launch_bounds__(TW_THREADS) void tower_bwd_stats_kernel(const TowerK kk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PZ = H + 4;
+    float* lz = lds;                                          // [TW_THREADS][PZ]
+    float* ldv = lds + TW_THREADS * PZ;                       // [TW_THREADS]
+    const swr_tower_args& a = kk.a;
+    const int g = blockIdx.y;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
+    const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
+    tile_load<H>(a.Z1 + m0 * a.ldz + g * H, a.ldz, rows, lz);
+    ldv[threadIdx.x] = static_cast<int>(threadIdx.x) < rows ? a.dV[(m0 + threadIdx.x) * a.lddv + g] : 0.f;
+    __syncthreads();
+    constexpr int TPP = 64 / H;                               // H <= 32 -> >= 2
+    constexpr int RPT = 64 / TPP;
+    const int pair = threadIdx.x / TPP, part = threadIdx.x % TPP;
+    const int t4 = pair / H, j = pair % H;
+    const int n = g * H + j, N = a.G * H;
+    const float sc = a.scale[n], sh = a.shift[n], mu = a.mean[n], rs = a.rstd[n], w2 = a.w2[n];
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = t4 * 64 + i * TPP + part;
+        const float dv = ldv[r];                              // 0 on rows past the end: they add nothing
+        const float zj = r < rows ? lz[r * PZ + j] : 0.f;    // (their LDS rows were never written: could hold NaN bits)
+        const float pre = fmaf(zj, sc, sh);
+        const bool on = pre > 0.f;
+        const float dy = on ? dv * w2 : 0.f;
+        s1 += dy;
+        s2 = fmaf(dy, (zj - mu) * rs, s2);
+        s3 = fmaf(on ? dv : 0.f, pre, s3);
+        s4 += dv;
+    }
+#pragma unroll
+    for (int off = 1; off < TPP; off <<= 1) {
+        s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off); s4 += __shfl_xor(s4, off);
+    }
+    const int64_t tile = (m0 >> 6) + t4;
+    if (part == 0 && tile * 64 < a.M) {
+        float* p = kk.bn_partials + (tile * N + n) * 2;
+        p[0] = s1;
+        p[1] = s2;
+        kk.head_partials[tile * (N + a.G) + n] = s3;
+        if (j == 0) kk.head_partials[tile * (N + a.G) + N + g] = s4;
+    }
+}
+
+// fixed-order fp64 sums over the 64-row tiles; one workgroup per hidden column (+ one per tower for db2)
+__global__ __launch_bounds__(TW_THREADS) void tower_bwd_finalize_kernel(const TowerK kk, int n_tiles) {
+    const swr_tower_args& a = kk.a;
+    __shared__ double t1[TW_THREADS], t2[TW_THREADS], t3[TW_THREADS];
+    const int N = a.G * (a.H);
+    const int n = blockIdx.x;                                                  // < N: hidden column, >= N: tower
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int per = (n_tiles + TW_THREADS - 1) / TW_THREADS;
+    const int t0 = threadIdx.x * per;
+    for (int t = t0; t < min(t0 + per, n_tiles); ++t) {
+        if (n < N) {
+            const float* p = kk.bn_partials + (static_cast<int64_t>(t) * N + n) * 2;
+            a1 += p[0];
+            a2 += p[1];
+        }
+        a3 += kk.head_partials[static_cast<int64_t>(t) * (N + a.G) + n];
+    }
+    t1[threadIdx.x] = a1; t2[threadIdx.x] = a2; t3[threadIdx.x] = a3;
+    __syncthreads();
+    for (int st = 1; st < TW_THREADS; st <<= 1) {
+        if ((threadIdx.x & (2 * st - 1)) == 0) {
+            t1[threadIdx.x] += t1[threadIdx.x + st];
+            t2[threadIdx.x] += t2[threadIdx.x + st];
+            t3[threadIdx.x] += t3[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const float s3 = static_cast<float>(t3[0]);
+    if (n >= N) {
+        if (a.db2) a.db2[n - N] = (a.accumulate ? a.db2[n - N] : 0.f) + s3;
+        return;
+    }
+    if (a.dw2) a.dw2[n] = (a.accumulate ? a.dw2[n] : 0.f) + s3;
+    const double S1 = t1[0], S2 = t2[0];
+    const double gm = a.gamma ? a.gamma[n] : 1.0, rs = a.rstd[n];
+    if (a.dgamma) a.dgamma[n] = (a.accumulate ? a.dgamma[n] : 0.f) + static_cast<float>(S2);
+    if (a.dbeta) a.dbeta[n] = (a.accumulate ? a.dbeta[n] : 0.f) + static_cast<float>(S1);
+    // dZ = g rs dY - g rs^2 (S2 / M) (Z - mean) - g rs (S1 / M)      (same coefficients as swr_bn_bwd_finalize)
+    a.ca[n] = static_cast<float>(gm * rs);
+    a.cb[n] = static_cast<float>(-gm * rs * rs * S2 / static_cast<double>(a.M));
+    a.cc[n] = static_cast<float>(-gm * rs * S1 / static_cast<double>(a.M));
+}
+
+// --------------------------------------------------------------------------------------- backward, apply
+template <int K, int H>
+__global__ __launch_bounds__(TW_THREADS) void tower_bwd_apply_kernel(const TowerK kk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PX = K + 4, PZ = H + 4;
+    float* lz = lds;                                          // [TW_THREADS][PZ]: Z1 in, dZ1 out (in place)
+    float* lx = lds;                                          // [TW_THREADS][PX]: dX out, after dZ1 has left
+    const swr_tower_args& a = kk.a;
+    const int g = blockIdx.y;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
+    const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
+    const bool valid = static_cast<int>(threadIdx.x) < rows;
+    tile_load<H>(a.Z1 + m0 * a.ldz + g * H, a.ldz, rows, lz);
+    const float dv = valid ? a.dV[(m0 + threadIdx.x) * a.lddv + g] : 0.f;
+    __syncthreads();
+    const float* __restrict__ w = a.W1 + static_cast<int64_t>(g) * H * K;
+    float dx[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) dx[k] = 0.f;
+    float* zrow = lz + threadIdx.x * PZ;
+#pragma unroll 1
+    for (int j = 0; j < H; ++j) {
+        const int n = g * H + j;
+        const float zj = valid ? zrow[j] : 0.f;
+        const float pre = fmaf(zj, a.scale[n], a.shift[n]);
+        const float dy = pre > 0.f ? dv * a.w2[n] : 0.f;
+        const float dz = fmaf(a.cb[n], zj - a.mean[n], dy * a.ca[n]) + a.cc[n];
+        zrow[j] = dz;
+        if (a.dX) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) dx[k] = fmaf(dz, w[j * K + k], dx[k]);
+        }
+    }
+    __syncthreads();
+    tile_store<H>(a.dZ1 + m0 * a.lddz + g * H, a.lddz, rows, lz);
+    if (!a.dX) return;
+    __syncthreads();
+    float* xrow = lx + threadIdx.x * PX;
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q)
+        *reinterpret_cast<float4*>(xrow + 4 * q) = make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+    __syncthreads();
+    tile_store<K>(a.dX + m0 * a.lddx + static_cast<int64_t>(g) * K, a.lddx, rows, lx);
+}
+
+// ------------------------------------------------------------------------------------------- dispatch
+static bool tower_shape_ok(int K, int H) {
+    return (K == 8 || K == 16 || K == 32) && (H == 4 || H == 8 || H == 16 || H == 32);   // K = 64 would need > 64 KB of LDS
+}
+
+extern "C" int swr_tower_supported(int K, int H) { return tower_shape_ok(K, H) ? 1 : 0; }
+
+#define TW_DISPATCH_KH(FN, K, H, ...)                                   \
+    do {                                                                \
+        switch ((K) * 100 + (H)) {                                      \
+            case 804: FN<8, 4> __VA_ARGS__; break;                      \
+            case 808: FN<8, 8> __VA_ARGS__; break;                      \
+            case 816: FN<8, 16> __VA_ARGS__; break;                     \
+            case 832: FN<8, 32> __VA_ARGS__; break;                     \
+            case 1604: FN<16, 4> __VA_ARGS__; break;                    \
+            case 1608: FN<16, 8> __VA_ARGS__; break;                    \
+            case 1616: FN<16, 16> __VA_ARGS__; break;                   \
+            case 1632: FN<16, 32> __VA_ARGS__; break;                   \
+            case 3204: FN<32, 4> __VA_ARGS__; break;                    \
+            case 3208: FN<32, 8> __VA_ARGS__; break;                    \
+            case 3216: FN<32, 16> __VA_ARGS__; break;                   \
+            case 3232: FN<32, 32> __VA_ARGS__; break;                   \
+            case 6404: FN<64, 4> __VA_ARGS__; break;                    \
+            case 6408: FN<64, 8> __VA_ARGS__; break;                    \
+            case 6416: FN<64, 16> __VA_ARGS__; break;                   \
+            default: FN<64, 32> __VA_ARGS__; break;                     \
+        }                                                               \
+    } while (0)
+
+#define TW_DISPATCH_H(FN, H, ...)                                       \
+    do {                                                                \
+        switch (H) {                                                    \
+            case 4: FN<4> __VA_ARGS__; break;                           \
+            case 8: FN<8> __VA_ARGS__; break;                           \
+            case 16: FN<16> __VA_ARGS__; break;                         \
+            default: FN<32> __VA_ARGS__; break;                         \
+        }                                                               \
+    } while (0)
+
+template <int K, int H>
+static void launch_linear_fwd(const TowerK& kk, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((tower_linear_fwd_kernel<K, H>), grid, dim3(TW_THREADS), TW_THREADS * ((K > H ? K : H) + 4) * sizeof(float), st, kk);
+}
+template <int H>
+static void launch_head_fwd(const TowerK& kk, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((tower_head_fwd_kernel<H>), grid, dim3(TW_THREADS), 0, st, kk);
+}
+template <int H>
+static void launch_bwd_stats(const TowerK& kk, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((tower_bwd_stats_kernel<H>), grid, dim3(TW_THREADS), TW_THREADS * (H + 5) * sizeof(float), st, kk);
+}
+template <int K, int H>
+static void launch_bwd_apply(const TowerK& kk, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((tower_bwd_apply_kernel<K, H>), grid, dim3(TW_THREADS), TW_THREADS * ((K > H ? K : H) + 4) * sizeof(float), st, kk);
+}
+
+static int tower_common(const swr_tower_args* args) {
+    SWR_REQUIRE(args != nullptr, SWR_ERR_ARG);
+    const swr_tower_args& a = *args;
+    SWR_REQUIRE(a.M > 0 && a.G > 0 && a.G <= 65535, SWR_ERR_ARG);
+    SWR_REQUIRE(tower_shape_ok(a.K, a.H), SWR_ERR_UNSUPPORTED);
+    SWR_REQUIRE(a.Z1 && a.ldz >= a.G * a.H && a.ldz % 4 == 0 && swr_aligned16(a.Z1), SWR_ERR_ARG);
+    return SWR_OK;
+}
+
+extern "C" int swr_tower_fwd_linear(const swr_tower_args* args, void* stream) {
+    int rc = tower_common(args);
+    if (rc != SWR_OK) return rc;
+    const swr_tower_args& a = *args;
+    SWR_REQUIRE(a.X && a.W1 && a.ldx >= static_cast<int64_t>(a.G) * a.K, SWR_ERR_ARG);
+    SWR_REQUIRE(a.ldx % 4 == 0 && swr_aligned16(a.X), SWR_ERR_ALIGN);
+    TowerK kk;
+    kk.a = a;
+    kk.bn_partials = kk.head_partials = nullptr;
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)), static_cast<unsigned>(a.G));
+    TW_DISPATCH_KH(launch_linear_fwd, a.K, a.H, (kk, grid, static_cast<hipStream_t>(stream)));
+    return swr_launch_status();
+}
+
+extern "C" int swr_tower_fwd_head(const swr_tower_args* args, void* stream) {
+    int rc = tower_common(args);
+    if (rc != SWR_OK) return rc;
+    const swr_tower_args& a = *args;
+    SWR_REQUIRE(a.scale && a.shift && a.w2 && a.V && a.ldv >= a.G, SWR_ERR_ARG);
+    TowerK kk;
+    kk.a = a;
+    kk.bn_partials = kk.head_partials = nullptr;
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)));
+    TW_DISPATCH_H(launch_head_fwd, a.H, (kk, grid, static_cast<hipStream_t>(stream)));
+    return swr_launch_status();
+}
+
+extern "C" size_t swr_tower_bwd_workspace_bytes(int64_t M, int G, int H) {
+    if (M <= 0 || G <= 0 || H <= 0) return 0;
+    const size_t tiles = static_cast<size_t>(swr_ceil_div(M, 64));
+    return tiles * (static_cast<size_t>(G) * H * 3 + G) * sizeof(float) + 256;
+}
+
+extern "C" int swr_tower_bwd(const swr_tower_args* args, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = tower_common(args);
+    if (rc != SWR_OK) return rc;
+    swr_tower_args a = *args;
+    SWR_REQUIRE(a.dV && a.lddv >= a.G && a.scale && a.shift && a.mean && a.rstd && a.w2 && a.W1, SWR_ERR_ARG);
+    SWR_REQUIRE(a.ca && a.cb && a.cc && a.dZ1 && a.lddz >= a.G * a.H, SWR_ERR_ARG);
+    SWR_REQUIRE(a.lddz % 4 == 0 && swr_aligned16(a.dZ1), SWR_ERR_ALIGN);
+    SWR_REQUIRE(!a.dX || (a.lddx >= static_cast<int64_t>(a.G) * a.K && a.lddx % 4 == 0 && swr_aligned16(a.dX)), SWR_ERR_ALIGN);
+    SWR_REQUIRE(workspace && workspace_bytes >= swr_tower_bwd_workspace_bytes(a.M, a.G, a.H), SWR_ERR_WORKSPACE);
+    const int n_tiles = static_cast<int>(swr_ceil_div(a.M, 64));
+    const int N = a.G * a.H;
+    TowerK kk;
+    kk.a = a;
+    kk.bn_partials = static_cast<float*>(workspace);
+    kk.head_partials = kk.bn_partials + static_cast<size_t>(n_tiles) * N * 2;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)), static_cast<unsigned>(a.G));
+    TW_DISPATCH_H(launch_bwd_stats, a.H, (kk, grid, st));
+    hipLaunchKernelGGL(tower_bwd_finalize_kernel, dim3(static_cast<unsigned>(N + a.G)), dim3(TW_THREADS), 0, st, kk, n_tiles);
+    TW_DISPATCH_KH(launch_bwd_apply, a.K, a.H, (kk, grid, st));
+    return swr_launch_status();
+}

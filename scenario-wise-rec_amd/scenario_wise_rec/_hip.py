@@ -92,6 +92,17 @@ class MixDesc(C.Structure):
                 ("g_col", C.c_int32), ("g_stride", C.c_int32), ("sel", (C.c_uint8 * MIX_MAX_SEL) * MIX_MAX_OUT)]
 
 
+class TowerArgs(C.Structure):
+    _fields_ = [("M", C.c_int64), ("G", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("accumulate", C.c_int32),
+                ("X", C.c_void_p), ("ldx", C.c_int64), ("W1", C.c_void_p), ("b1", C.c_void_p),
+                ("Z1", C.c_void_p), ("ldz", C.c_int64), ("stat_partials", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("gamma", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("V", C.c_void_p), ("ldv", C.c_int64),
+                ("dV", C.c_void_p), ("lddv", C.c_int64), ("ca", C.c_void_p), ("cb", C.c_void_p), ("cc", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
+                ("dZ1", C.c_void_p), ("lddz", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64)]
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("step", C.c_int64), ("step_size", C.c_float),
@@ -129,6 +140,11 @@ _SIGS = {
     "swr_bce_bwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _P]),
     "swr_select_bce_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
     "swr_select_bce_bwd": (C.c_int, [_P, _P, _I, _I, _P, _I, _L, _P, _P, _L, _P]),
+    "swr_tower_supported": (C.c_int, [_I, _I]),
+    "swr_tower_fwd_linear": (C.c_int, [_P, _P]),
+    "swr_tower_fwd_head": (C.c_int, [_P, _P]),
+    "swr_tower_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
+    "swr_tower_bwd": (C.c_int, [_P, _P, _Z, _P]),
     "swr_mul_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "swr_colsum_workspace_bytes": (_Z, [_L, _I]),
     "swr_colsum": (C.c_int, [_P, _L, _L, _I, _P, _I, _P, _Z, _P]),

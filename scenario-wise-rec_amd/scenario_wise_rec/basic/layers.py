@@ -5,6 +5,8 @@ nn.BatchNorm1d / nn.Embedding objects are kept as PARAMETER HOLDERS, created in 
 a given torch seed yields the same initial weights); `forward` never calls them -- it launches the fused
 HIP ops of `scenario_wise_rec.ops`.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -229,12 +231,32 @@ def mlp_bank_groups(mlps):
     return g
 
 
+def _tower_head_ok(mlps, x, shared_input, first_block):
+    m0 = mlps[0]
+    if (shared_input or not m0.training or m0.n_blocks - first_block != 1 or not m0.has_output_layer or m0.act != "relu"
+            or m0.dropout_p > 0 or not x.is_cuda or os.environ.get("SWR_TOWER_HEAD", "1") == "0"):
+        return False
+    lin, out = m0.block(first_block)[0], m0.output_linear()
+    if lin.bias is None or out.bias is None or out.out_features != 1:
+        return False
+    if x.dim() != 2 or x.shape[1] != len(mlps) * lin.in_features or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        return False
+    return ops.tower_head_supported(lin.in_features, lin.out_features)
+
+
 def mlp_bank_forward(mlps, x, shared_input, first_block=0):
     """Evaluate structurally identical MLPs together: block `first_block` reads a shared x (stacked
     outputs) or per-member column slices of x; later blocks and the output layer are grouped launches.
     Returns [M, n_mlps * out_dim]."""
     m0 = mlps[0]
     training = m0.training
+    if _tower_head_ok(mlps, x, shared_input, first_block):
+        # per-domain tower heads [Linear -> BN -> ReLU -> Linear(., 1)] in training mode: the fused kernels of
+        # csrc/tower.hip (three launches forward instead of five, half the HBM passes of the backward)
+        blocks = [m.block(first_block) for m in mlps]
+        outs = [m.output_linear() for m in mlps]
+        return ops.tower_head(x, [b[0].weight for b in blocks], [b[0].bias for b in blocks], _bn_dict([b[1] for b in blocks]),
+                              [o.weight for o in outs], [o.bias for o in outs])
     for i in range(first_block, m0.n_blocks):
         act = (m0.act, m0.block(i)[0].out_features) if m0.act == "softmax" else m0.act
         bank = LayerBank([m.block(i)[0] for m in mlps], [m.block(i)[1] for m in mlps], [act] * len(mlps),

@@ -362,6 +362,28 @@ class EmbedGather(Function):
 
 
 # =========================================================================== Linear (+BN) (+act)
+def _bn_train_finalize(bn, gamma, beta, partials, n_tiles, M, Ntot, dev):
+    """Merge the per-tile (mean, M2) pairs into batch statistics, update the running statistics in place and return
+    (mean, rstd, scale, shift) with BN(z) = scale * z + shift."""
+    mean = torch.empty(Ntot, dtype=torch.float32, device=dev)
+    rstd = torch.empty(Ntot, dtype=torch.float32, device=dev)
+    scale = torch.empty(Ntot, dtype=torch.float32, device=dev)
+    shift = torch.empty(Ntot, dtype=torch.float32, device=dev)
+    rm, rv, nbt = _cat_params(bn["running_mean"]), _cat_params(bn["running_var"]), _cat_params(bn["nbt"])
+    copy_back = rm.data_ptr() != bn["running_mean"][0].data_ptr()
+    H.check(lib.swr_bn_finalize(H.ptr(partials), n_tiles, M, Ntot, H.ptr(gamma), H.ptr(beta), bn["eps"],
+                                bn["momentum"], H.ptr(rm), H.ptr(rv), H.ptr(nbt), nbt.numel(), H.ptr(mean),
+                                H.ptr(rstd), H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_finalize")
+    if copy_back:      # buffers were not adjacent: scatter the updated copies back
+        for dst, src in zip(bn["running_mean"], _split_like(rm, bn["running_mean"])):
+            dst.copy_(src)
+        for dst, src in zip(bn["running_var"], _split_like(rv, bn["running_var"])):
+            dst.copy_(src)
+        for dst, src in zip(bn["nbt"], _split_like(nbt, bn["nbt"])):
+            dst.copy_(src)
+    return mean, rstd, scale, shift
+
+
 class LinearBNAct(Function):
     """[Linear -> BatchNorm1d -> activation] of an MLP block (basic/layers.py:253-258) for one or more
     independent layers at once:
@@ -407,20 +429,7 @@ class LinearBNAct(Function):
             if training:
                 if M < 2:
                     raise ValueError("Expected more than 1 value per channel when training")   # torch's message
-                mean = torch.empty(Ntot, dtype=torch.float32, device=dev)
-                rstd = torch.empty(Ntot, dtype=torch.float32, device=dev)
-                rm, rv, nbt = _cat_params(bn["running_mean"]), _cat_params(bn["running_var"]), _cat_params(bn["nbt"])
-                copy_back = rm.data_ptr() != bn["running_mean"][0].data_ptr()
-                H.check(lib.swr_bn_finalize(H.ptr(partials), n_tiles, M, Ntot, H.ptr(gamma), H.ptr(beta), bn["eps"],
-                                            bn["momentum"], H.ptr(rm), H.ptr(rv), H.ptr(nbt), nbt.numel(), H.ptr(mean),
-                                            H.ptr(rstd), H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_finalize")
-                if copy_back:      # buffers were not adjacent: scatter the updated copies back
-                    for dst, src in zip(bn["running_mean"], _split_like(rm, bn["running_mean"])):
-                        dst.copy_(src)
-                    for dst, src in zip(bn["running_var"], _split_like(rv, bn["running_var"])):
-                        dst.copy_(src)
-                    for dst, src in zip(bn["nbt"], _split_like(nbt, bn["nbt"])):
-                        dst.copy_(src)
+                mean, rstd, scale, shift = _bn_train_finalize(bn, gamma, beta, partials, n_tiles, M, Ntot, dev)
             else:
                 rm, rv = _cat_params(bn["running_mean"]), _cat_params(bn["running_var"])
                 H.check(lib.swr_bn_eval_coeffs(H.ptr(gamma), H.ptr(beta), H.ptr(rm), H.ptr(rv), bn["eps"], Ntot,
@@ -559,6 +568,115 @@ def linear_bn_act(x, weights, biases, bn=None, acts=None, groups=1, training=Tru
         cfg["n_bn"] = len(bn["gamma"])
         params += list(bn["gamma"]) + list(bn["beta"])
     return LinearBNAct.apply(cfg, x, *params)
+
+
+class TowerHead(Function):
+    """G per-domain towers [Linear(K, H) -> BatchNorm1d(H) -> ReLU -> Linear(H, 1)] on their own K-column blocks of x, in
+    training mode (batch statistics): mmoe.py:38-41,50-51 with tower_params = {"dims": [H]}.  Three launches forward,
+    three + the grouped weight-gradient product backward (csrc/tower.hip); A1 = relu(bn(Z1)) is never stored.
+
+    params = G first-layer weights [H, K] + G biases + G gammas + G betas + G output weights [1, H] + G output biases."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        G = cfg["groups"]
+        W1s, b1s, gammas, betas, w2s, b2s = (params[i * G:(i + 1) * G] for i in range(6))
+        H.require_device(x, W1s[0])
+        x = H.f32c(x)
+        M = x.shape[0]
+        Hd, K = W1s[0].shape
+        N = G * Hd
+        dev = x.device
+        if M < 2:
+            raise ValueError("Expected more than 1 value per channel when training")   # torch's message
+        W1, b1 = _cat_params(W1s), _cat_params(b1s)
+        gamma, beta = _cat_params(gammas), _cat_params(betas)
+        w2, b2 = _cat_params([w.reshape(-1) for w in w2s]), _cat_params(b2s)
+        Z1 = torch.empty((M, N), dtype=torch.float32, device=dev)
+        n_tiles = (M + 31) // 32
+        partials = torch.empty((n_tiles, N, 2), dtype=torch.float32, device=dev)
+        a = H.TowerArgs()
+        a.M, a.G, a.K, a.H = M, G, K, Hd
+        a.X, a.ldx = x.data_ptr(), x.stride(0)
+        a.W1, a.b1 = W1.data_ptr(), b1.data_ptr()
+        a.Z1, a.ldz = Z1.data_ptr(), N
+        a.stat_partials = partials.data_ptr()
+        H.check(lib.swr_tower_fwd_linear(C.byref(a), H.stream()), "swr_tower_fwd_linear")
+        mean, rstd, scale, shift = _bn_train_finalize(cfg["bn"], gamma, beta, partials, n_tiles, M, N, dev)
+        V = torch.empty((M, G), dtype=torch.float32, device=dev)
+        a.scale, a.shift = scale.data_ptr(), shift.data_ptr()
+        a.w2, a.b2 = w2.data_ptr(), b2.data_ptr()
+        a.V, a.ldv = V.data_ptr(), G
+        H.check(lib.swr_tower_fwd_head(C.byref(a), H.stream()), "swr_tower_fwd_head")
+        ctx.cfg, ctx.dims, ctx.params = cfg, (M, G, K, Hd), params
+        ctx.save_for_backward(x, W1, Z1, mean, rstd, scale, shift, gamma, w2)
+        return V
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dV):
+        x, W1, Z1, mean, rstd, scale, shift, gamma, w2 = ctx.saved_tensors
+        M, G, K, Hd = ctx.dims
+        N = G * Hd
+        dev = x.device
+        p_W1, p_b1, p_g, p_be, p_w2, p_b2 = (ctx.params[i * G:(i + 1) * G] for i in range(6))
+        dV = H.f32c(dV).contiguous()
+        dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_be, 2)
+        dw2, db2 = _grad_alias(p_w2), _grad_alias(p_b2)
+        direct = all(t is not None for t in (dgamma, dbeta, dw2, db2))
+        if not direct:
+            dgamma, dbeta, dw2 = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+            db2 = torch.empty(G, dtype=torch.float32, device=dev)
+        ca, cb, cc = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+        dZ1 = torch.empty((M, N), dtype=torch.float32, device=dev)
+        need_dx = ctx.needs_input_grad[1]
+        dx = torch.empty((M, G * K), dtype=torch.float32, device=dev) if need_dx else None
+        a = H.TowerArgs()
+        a.M, a.G, a.K, a.H, a.accumulate = M, G, K, Hd, int(direct)
+        a.W1 = W1.data_ptr()
+        a.Z1, a.ldz = Z1.data_ptr(), N
+        a.scale, a.shift, a.mean, a.rstd, a.gamma = (t.data_ptr() for t in (scale, shift, mean, rstd, gamma))
+        a.w2 = w2.data_ptr()
+        a.dV, a.lddv = dV.data_ptr(), G
+        a.ca, a.cb, a.cc = ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
+        a.dgamma, a.dbeta, a.dw2, a.db2 = dgamma.data_ptr(), dbeta.data_ptr(), dw2.data_ptr(), db2.data_ptr()
+        a.dZ1, a.lddz = dZ1.data_ptr(), N
+        a.dX, a.lddx = (dx.data_ptr(), G * K) if need_dx else (None, 0)
+        nbytes = lib.swr_tower_bwd_workspace_bytes(M, G, Hd)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        H.check(lib.swr_tower_bwd(C.byref(a), H.ptr(ws), nbytes, H.stream()), "swr_tower_bwd")
+        # first-layer weights: the ordinary grouped weight-gradient product on dZ1, x
+        dW1, db1 = _grad_alias(p_W1), _grad_alias(p_b1)
+        direct_w = dW1 is not None and db1 is not None
+        if not direct_w:
+            dW1 = torch.empty((N, K), dtype=torch.float32, device=dev)
+            db1 = torch.empty(N, dtype=torch.float32, device=dev)
+        gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
+                ldc=K)
+        grads = []
+        if direct_w:
+            _mark_touched(p_W1 + p_b1)
+            grads += [None] * (2 * G)
+        else:
+            grads += list(_split_like(dW1, p_W1)) + list(_split_like(db1, p_b1))
+        if direct:
+            _mark_touched(p_g + p_be + p_w2 + p_b2)
+            grads += [None] * (4 * G)
+        else:
+            grads += list(_split_like(dgamma, p_g)) + list(_split_like(dbeta, p_be))
+            grads += [t.reshape(p.shape) for t, p in zip(_split_like(dw2, [w.reshape(-1) for w in p_w2]), p_w2)]
+            grads += list(_split_like(db2, p_b2))
+        return (None, dx) + tuple(grads)
+
+
+def tower_head_supported(K, Hd):
+    return bool(lib.swr_tower_supported(int(K), int(Hd)))
+
+
+def tower_head(x, W1s, b1s, bn, w2s, b2s):
+    """Functional front-end of TowerHead; `bn` as in linear_bn_act."""
+    cfg = {"groups": len(W1s), "bn": {k: bn[k] for k in ("running_mean", "running_var", "nbt", "eps", "momentum")}}
+    return TowerHead.apply(cfg, x, *W1s, *b1s, *bn["gamma"], *bn["beta"], *w2s, *b2s)
 
 
 class MatmulIO(Function):

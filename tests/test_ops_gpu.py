@@ -351,3 +351,66 @@ def test_fused_select_bce_is_bitwise_the_two_step_path(M, D, ydt):
     pd_ = ops.domain_select(Vd, dom)
     (ops.bce_mean(pd_, y) + pd_.sum() * 0.5).backward()
     torch.testing.assert_close(Vc.grad, Vd.grad, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("M,G,K,Hd", [(1000, 5, 32, 16), (257, 3, 8, 4), (64, 2, 16, 32), (4099, 1, 16, 8)])
+def test_tower_head_matches_the_layerwise_path(M, G, K, Hd):
+    """The fused per-domain tower kernels (csrc/tower.hip) against the same towers evaluated layer by layer
+    (grouped GEMM + BatchNorm + ReLU + GEMM, SWR_TOWER_HEAD=0): outputs, input gradient, every parameter gradient and
+    the BatchNorm running statistics, plus an fp64 numpy check of the forward."""
+    import os
+    from scenario_wise_rec.basic.layers import MLP, mlp_bank_forward
+    from scenario_wise_rec.basic.module import SwrModule
+
+    class Towers(SwrModule):
+        def __init__(self):
+            super().__init__()
+            self.towers = torch.nn.ModuleList(MLP(K, True, [Hd]) for _ in range(G))
+
+        def forward(self, x):
+            return mlp_bank_forward(list(self.towers), x, shared_input=False)
+
+    torch.manual_seed(M + G)
+    ref, fused = Towers(), Towers()
+    fused.load_state_dict(ref.state_dict())
+    for mod in (ref, fused):
+        mod.to("cuda").train()
+        for p in mod.parameters():                      # away from the degenerate init (beta = 0, gamma = 1)
+            p.data.add_(0.1 * torch.randn_like(p))
+    fused.load_state_dict(ref.state_dict())
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x0 = torch.randn(M, G * K, device="cuda", generator=g)
+    dV = torch.randn(M, G, device="cuda", generator=g)
+    res = []
+    for mod, flag in ((ref, "0"), (fused, "1")):
+        os.environ["SWR_TOWER_HEAD"] = flag
+        try:
+            x = x0.clone().requires_grad_(True)
+            V = mod(x)
+            V.backward(dV)
+        finally:
+            os.environ.pop("SWR_TOWER_HEAD", None)
+        res.append((V.detach(), x.grad, {n: p.grad.clone() for n, p in mod.named_parameters()},
+                    {n: b.clone() for n, b in mod.named_buffers()}))
+    (Va, dxa, ga, ba), (Vb, dxb, gb, bb) = res
+    torch.testing.assert_close(Vb, Va, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(dxb, dxa, rtol=1e-4, atol=1e-5 * float(dxa.abs().max()) + 1e-7)
+    for n in ga:
+        atol = 2e-5 * float(ga[n].abs().max()) + 1e-6
+        if n.endswith("mlp.0.bias"):          # a bias in front of BatchNorm: zero in exact arithmetic, rounding noise here
+            atol = 1e-3 * float(ga[n.replace("bias", "weight")].abs().max())
+        torch.testing.assert_close(gb[n], ga[n], rtol=1e-4, atol=atol, msg=n)
+    for n in ba:
+        torch.testing.assert_close(bb[n].float(), ba[n].float(), rtol=1e-5, atol=1e-6, msg=n)
+    # forward against numpy fp64
+    sd = {k: v.detach().cpu().double().numpy() for k, v in ref.state_dict().items()}
+    xs = x0.cpu().double().numpy()
+    cols = []
+    for t in range(G):
+        W1, b1 = sd[f"towers.{t}.mlp.0.weight"], sd[f"towers.{t}.mlp.0.bias"]
+        gm, be = sd[f"towers.{t}.mlp.1.weight"], sd[f"towers.{t}.mlp.1.bias"]
+        w2, b2 = sd[f"towers.{t}.mlp.4.weight"], sd[f"towers.{t}.mlp.4.bias"]
+        z = xs[:, t * K:(t + 1) * K] @ W1.T + b1
+        a1 = np.maximum((z - z.mean(0)) / np.sqrt(z.var(0) + 1e-5) * gm + be, 0)
+        cols.append(a1 @ w2.T + b2)
+    np.testing.assert_allclose(Vb.cpu().numpy(), np.concatenate(cols, axis=1), rtol=0, atol=3e-5)
