@@ -66,9 +66,9 @@ __device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t ld, 
     }
 }
 
-// The hidden index j is a REAL loop (one weight row = K wave-uniform scalars per trip) and the H values of a row live
-// in the LDS tile, not in a register array: fully unrolled, hipcc hoists all H*K scalar weight loads to the top of
-// the kernel and spills ~450 SGPRs through v_writelane / v_readlane (measured: 3x slower).
+// The hidden index j is a REAL loop (one weight row per trip) and the H values of a row live in the LDS tile, not in a
+// register array: fully unrolled with the weights read through the (wave-uniform) argument pointers, hipcc hoists all
+// H*K scalar loads to the top of the kernel and spills ~450 SGPRs through v_writelane / v_readlane (3x slower).
 
 // ---------------------------------------------------------------------------------- forward, first layer
 template <int K, int H>
@@ -82,17 +82,21 @@ __global__ __launch_bounds__(TW_THREADS) void tower_linear_fwd_kernel(const Towe
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
     const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
     const bool valid = static_cast<int>(threadIdx.x) < rows;
+    float* lw = lds + TW_THREADS * (PX > PZ ? PX : PZ);       // [H][K] weights of this tower (+ [H] biases)
     tile_load<K>(a.X + m0 * a.ldx + static_cast<int64_t>(g) * K, a.ldx, rows, lx);
+    for (int i = threadIdx.x; i < H * K; i += TW_THREADS) lw[i] = a.W1[static_cast<int64_t>(g) * H * K + i];
+    if (static_cast<int>(threadIdx.x) < H) lw[H * K + threadIdx.x] = a.b1 ? a.b1[g * H + threadIdx.x] : 0.f;
     __syncthreads();
     float x[K];
     load_row<K / 4>(lx + threadIdx.x * PX, x);
     __syncthreads();
-    const float* __restrict__ w = a.W1 + static_cast<int64_t>(g) * H * K;      // wave-uniform: scalar loads
-#pragma unroll 1
+    // weights as LDS broadcasts (one 16-byte read feeds 4 FMAs of the whole wave): scalar loads from the kernel
+    // argument pointers cost ~0.4 us of latency per weight row and a wave has nothing else to do meanwhile
+#pragma unroll 2
     for (int j = 0; j < H; ++j) {
-        float acc = a.b1 ? a.b1[g * H + j] : 0.f;
+        float acc = lw[H * K + j];
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[j * K + k], acc);
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], lw[j * K + k], acc);
         lz[threadIdx.x * PZ + j] = valid ? acc : 0.f;
     }
     __syncthreads();
@@ -254,25 +258,32 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_apply_kernel(const Tower
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
     const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
     const bool valid = static_cast<int>(threadIdx.x) < rows;
+    float* lw = lds + TW_THREADS * (PX > PZ ? PX : PZ);       // [H][K] weights, then 7 x [H] per-column coefficients
+    float* lc = lw + H * K;
     tile_load<H>(a.Z1 + m0 * a.ldz + g * H, a.ldz, rows, lz);
+    for (int i = threadIdx.x; i < H * K; i += TW_THREADS) lw[i] = a.W1[static_cast<int64_t>(g) * H * K + i];
+    if (static_cast<int>(threadIdx.x) < H) {
+        const int n = g * H + threadIdx.x;
+        lc[threadIdx.x] = a.scale[n];         lc[H + threadIdx.x] = a.shift[n];     lc[2 * H + threadIdx.x] = a.w2[n];
+        lc[3 * H + threadIdx.x] = a.cb[n];    lc[4 * H + threadIdx.x] = a.mean[n];  lc[5 * H + threadIdx.x] = a.ca[n];
+        lc[6 * H + threadIdx.x] = a.cc[n];
+    }
     const float dv = valid ? a.dV[(m0 + threadIdx.x) * a.lddv + g] : 0.f;
     __syncthreads();
-    const float* __restrict__ w = a.W1 + static_cast<int64_t>(g) * H * K;
     float dx[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) dx[k] = 0.f;
     float* zrow = lz + threadIdx.x * PZ;
-#pragma unroll 1
+#pragma unroll 2
     for (int j = 0; j < H; ++j) {
-        const int n = g * H + j;
         const float zj = valid ? zrow[j] : 0.f;
-        const float pre = fmaf(zj, a.scale[n], a.shift[n]);
-        const float dy = pre > 0.f ? dv * a.w2[n] : 0.f;
-        const float dz = fmaf(a.cb[n], zj - a.mean[n], dy * a.ca[n]) + a.cc[n];
+        const float pre = fmaf(zj, lc[j], lc[H + j]);
+        const float dy = pre > 0.f ? dv * lc[2 * H + j] : 0.f;
+        const float dz = fmaf(lc[3 * H + j], zj - lc[4 * H + j], dy * lc[5 * H + j]) + lc[6 * H + j];
         zrow[j] = dz;
         if (a.dX) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) dx[k] = fmaf(dz, w[j * K + k], dx[k]);
+            for (int k = 0; k < K; ++k) dx[k] = fmaf(dz, lw[j * K + k], dx[k]);
         }
     }
     __syncthreads();
@@ -328,7 +339,7 @@ extern "C" int swr_tower_supported(int K, int H) { return tower_shape_ok(K, H) ?
 
 template <int K, int H>
 static void launch_linear_fwd(const TowerK& kk, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((tower_linear_fwd_kernel<K, H>), grid, dim3(TW_THREADS), TW_THREADS * ((K > H ? K : H) + 4) * sizeof(float), st, kk);
+    hipLaunchKernelGGL((tower_linear_fwd_kernel<K, H>), grid, dim3(TW_THREADS), (TW_THREADS * ((K > H ? K : H) + 4) + H * K + H) * sizeof(float), st, kk);
 }
 template <int H>
 static void launch_head_fwd(const TowerK& kk, dim3 grid, hipStream_t st) {
@@ -340,7 +351,7 @@ static void launch_bwd_stats(const TowerK& kk, dim3 grid, hipStream_t st) {
 }
 template <int K, int H>
 static void launch_bwd_apply(const TowerK& kk, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((tower_bwd_apply_kernel<K, H>), grid, dim3(TW_THREADS), TW_THREADS * ((K > H ? K : H) + 4) * sizeof(float), st, kk);
+    hipLaunchKernelGGL((tower_bwd_apply_kernel<K, H>), grid, dim3(TW_THREADS), (TW_THREADS * ((K > H ? K : H) + 4) + H * K + 7 * H) * sizeof(float), st, kk);
 }
 
 static int tower_common(const swr_tower_args* args) {
