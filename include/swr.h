@@ -264,6 +264,32 @@ int swr_moe_mix_bwd(const swr_mix_desc* desc_host, const float* dP, int64_t lddp
                     const float* Y, int64_t ldy, float* dY, int64_t lddy, int accumulate,
                     int64_t M, void* stream);
 
+/* --------------------------------------- BatchNorm + activation + gate mix -----
+ * One MMoE level (mmoe.py:44-49) without materialising the activated experts / gate probabilities:
+ *   Z[:, 0 : ne*H] experts (BN -> ReLU), Z[:, ne*H : ne*H + D*ne] gates (BN -> softmax over ne),
+ *   P[:, o*H:(o+1)*H] = sum_j gate_o[j] * expert_j          (identity selection: every output mixes every expert)
+ * swr_bnmix_fwd: Z, scale, shift -> P.   swr_bnmix_bwd: dP, Z, scale, shift, mean, rstd -> dY = dL/d(BN output)
+ * [M, ne*H + D*ne] and bn_partials [ceil(M/64)][ne*H + D*ne][2] for swr_bn_bwd_finalize; swr_act_bwd_apply without
+ * activations then gives dZ.  ne <= 8, D <= 8, H in {16, 32} (swr_bnmix_supported); other shapes:
+ * swr_affine_act_fwd + swr_moe_mix_* + swr_bn_act_bwd_stats. */
+typedef struct {
+    int64_t M;
+    int32_t ne, H, D, pad;
+    const float* Z;  int64_t ldz;
+    const float* scale; const float* shift;       /* [ne*H + D*ne], 16-byte aligned */
+    float* P;        int64_t ldp;                 /* forward out [M, >= D*H] */
+    const float* dP; int64_t lddp;                /* backward in */
+    const float* mean; const float* rstd;         /* backward */
+    float* dY;       int64_t lddy;                /* backward out */
+    float* bn_partials;                           /* backward out */
+    float* G;                                     /* [M, D*ne] gate probabilities: written by fwd, read by bwd (nullable:
+                                                     the backward then recomputes them) */
+} swr_bnmix_args;
+
+int swr_bnmix_supported(int ne, int H, int D);
+int swr_bnmix_fwd(const swr_bnmix_args* args_host, void* stream);
+int swr_bnmix_bwd(const swr_bnmix_args* args_host, void* stream);
+
 /* ------------------------------------------------------ tower heads -------
  * G independent [Linear(K, H) -> BatchNorm1d(H) (batch statistics) -> ReLU -> Linear(H, 1)] evaluated together: the
  * per-domain `towers` of mmoe.py:38-41,50-51 (ple.py, sharebottom.py alike) with tower_params = {"dims": [H]}, each

@@ -12,7 +12,7 @@
 //   3. reduce     : each group of LPE lanes walks a fixed chunk of 8-32 sorted entries of one table, sums
 //                   runs of equal rows in registers and flushes each run (plain stores for runs that lie
 //                   inside the chunk, two 64-bit integer atomics for runs cut by a chunk boundary)
-//   4. finalise   : integer accumulators -> fp32 gradients (dense tables) or per-row entries (sparse)
+//   4. finalise   : integer accumulators -> fp32 gradients (dense tables) or per-row entries (sparse), one launch
 //
 // Accumulation is dual-limb fixed point: x * 2^60 (truncated) = hi * 2^40 + lo, hi in 2^-20 units, lo in 2^-60
 // units.  Both limbs are integers, so the sum is exact (to 2^-60) and independent of the order in which
@@ -772,31 +772,31 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
     if (bad && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
 }
 
-__global__ __launch_bounds__(RB_THREADS) void finalize_dense_kernel(const BwdMeta m, const long long* __restrict__ acc_hi,
-                                                                    const long long* __restrict__ acc_lo,
-                                                                    int64_t dense_acc_elems) {
-    const TableMeta& t = m.tab[blockIdx.y];
-    if (t.mode == 1) return;
-    const int64_t n = t.vocab * t.dim;
-    for (int64_t j = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x; j < n;
-         j += static_cast<int64_t>(gridDim.x) * RB_THREADS) {
-        long long hi = 0, lo = 0;                                     // integer sums: order-free, exact
+// integer accumulators -> fp32 gradients, ONE launch: workgroups [0, dense_blocks) sweep the dense tables
+// (blockIdx.x = table * gx + slice; sums the ACC_STRIPES copies), the rest emit the per-entry rows of the sparse tables
+__global__ __launch_bounds__(RB_THREADS) void finalize_kernel(const BwdMeta m, const uint32_t* __restrict__ ck,
+                                                              const long long* __restrict__ acc_hi,
+                                                              const long long* __restrict__ acc_lo, int64_t dense_acc_elems,
+                                                              int gx, int dense_blocks) {
+    if (static_cast<int>(blockIdx.x) < dense_blocks) {
+        const TableMeta& t = m.tab[blockIdx.x / gx];
+        if (t.mode == 1) return;
+        const int64_t n = t.vocab * t.dim;
+        for (int64_t j = static_cast<int64_t>(blockIdx.x % gx) * RB_THREADS + threadIdx.x; j < n;
+             j += static_cast<int64_t>(gx) * RB_THREADS) {
+            long long hi = 0, lo = 0;                                     // integer sums: order-free, exact
 #pragma unroll
-        for (int st = 0; st < ACC_STRIPES; ++st) {
-            hi += acc_hi[st * dense_acc_elems + t.acc_off + j];
-            lo += acc_lo[st * dense_acc_elems + t.acc_off + j];
+            for (int st = 0; st < ACC_STRIPES; ++st) {
+                hi += acc_hi[st * dense_acc_elems + t.acc_off + j];
+                lo += acc_lo[st * dense_acc_elems + t.acc_off + j];
+            }
+            const float g = from_fixed(hi, lo);
+            t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;     // mode 2: add to the caller's gradient arena
         }
-        const float g = from_fixed(hi, lo);
-        t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;     // mode 2: add to the caller's gradient arena
+        return;
     }
-}
-
-__global__ __launch_bounds__(RB_THREADS) void finalize_sparse_kernel(const BwdMeta m, const uint32_t* __restrict__ ck,
-                                                                     const long long* __restrict__ acc_hi,
-                                                                     const long long* __restrict__ acc_lo,
-                                                                     int64_t dense_acc_elems) {
     // one thread per (sorted entry of the sparse region, column)
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x - dense_blocks) * RB_THREADS + threadIdx.x;
     const int64_t i = m.sparse_start + idx / m.dim_max;
     const int e = static_cast<int>(idx % m.dim_max);
     if (i >= m.n) return;
@@ -892,21 +892,20 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         }
 #undef LAUNCH_REDUCE
     }
+    int gx = 0, dense_blocks = 0;
     if (p.dense_acc_elems > 0) {
         int64_t biggest = 1;
         for (int t = 0; t < m.n_tables; ++t)
             if (m.tab[t].mode != 1 && m.tab[t].vocab * m.tab[t].dim > biggest) biggest = m.tab[t].vocab * m.tab[t].dim;
-        const unsigned gx = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(biggest, RB_THREADS), 1024));
-        hipLaunchKernelGGL(finalize_dense_kernel, dim3(gx, static_cast<unsigned>(m.n_tables)), dim3(RB_THREADS), 0, st, m,
-                           reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo),
-                           p.dense_acc_elems);
+        gx = static_cast<int>(std::min<int64_t>(swr_ceil_div(biggest, RB_THREADS), 1024));
+        dense_blocks = gx * m.n_tables;
     }
-    if (m.sparse_start < n) {
-        const int64_t work = (n - m.sparse_start) * m.dim_max;
-        hipLaunchKernelGGL(finalize_sparse_kernel, dim3(static_cast<unsigned>(swr_ceil_div(work, RB_THREADS))),
-                           dim3(RB_THREADS), 0, st, m, ck, reinterpret_cast<const long long*>(acc_hi),
-                           reinterpret_cast<const long long*>(acc_lo), p.dense_acc_elems);
-    }
+    int64_t sparse_blocks = 0;
+    if (m.sparse_start < n) sparse_blocks = swr_ceil_div((n - m.sparse_start) * m.dim_max, RB_THREADS);
+    if (dense_blocks + sparse_blocks > 0)
+        hipLaunchKernelGGL(finalize_kernel, dim3(static_cast<unsigned>(dense_blocks + sparse_blocks)), dim3(RB_THREADS), 0, st,
+                           m, ck, reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo),
+                           p.dense_acc_elems, gx > 0 ? gx : 1, dense_blocks);
     return swr_launch_status();
 }
 

@@ -92,6 +92,14 @@ class MixDesc(C.Structure):
                 ("g_col", C.c_int32), ("g_stride", C.c_int32), ("sel", (C.c_uint8 * MIX_MAX_SEL) * MIX_MAX_OUT)]
 
 
+class BnMixArgs(C.Structure):
+    _fields_ = [("M", C.c_int64), ("ne", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("pad", C.c_int32),
+                ("Z", C.c_void_p), ("ldz", C.c_int64), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("P", C.c_void_p), ("ldp", C.c_int64), ("dP", C.c_void_p), ("lddp", C.c_int64),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dY", C.c_void_p), ("lddy", C.c_int64),
+                ("bn_partials", C.c_void_p), ("G", C.c_void_p)]
+
+
 class TowerArgs(C.Structure):
     _fields_ = [("M", C.c_int64), ("G", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("accumulate", C.c_int32),
                 ("X", C.c_void_p), ("ldx", C.c_int64), ("W1", C.c_void_p), ("b1", C.c_void_p),
@@ -140,6 +148,9 @@ _SIGS = {
     "swr_bce_bwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _P]),
     "swr_select_bce_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
     "swr_select_bce_bwd": (C.c_int, [_P, _P, _I, _I, _P, _I, _L, _P, _P, _L, _P]),
+    "swr_bnmix_supported": (C.c_int, [_I, _I, _I]),
+    "swr_bnmix_fwd": (C.c_int, [_P, _P]),
+    "swr_bnmix_bwd": (C.c_int, [_P, _P]),
     "swr_tower_supported": (C.c_int, [_I, _I]),
     "swr_tower_fwd_linear": (C.c_int, [_P, _P]),
     "swr_tower_fwd_head": (C.c_int, [_P, _P]),

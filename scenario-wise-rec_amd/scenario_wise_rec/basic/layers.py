@@ -165,11 +165,13 @@ class LayerBank(object):
                   [b.running_var for b in self.bns], [b.num_batches_tracked for b in self.bns]]
         return g
 
-    def __call__(self, x, training):
+    def __call__(self, x, training, mix=None):
+        """`mix` = (n_expert, H, n_out): the members are n_expert ReLU experts of width H followed by n_out softmax
+        gates over them, and the caller wants the gate-mixed outputs [M, n_out * H] (training mode only)."""
         biases = [l.bias for l in self.linears] if self.linears[0].bias is not None else None
         return ops.linear_bn_act(x, [l.weight for l in self.linears], biases,
                                  bn=_bn_dict(self.bns) if self.bns is not None else None, acts=self.acts,
-                                 groups=len(self.linears) if self.grouped else 1, training=training)
+                                 groups=len(self.linears) if self.grouped else 1, training=training, mix=mix)
 
 
 class MLP(SwrModule):

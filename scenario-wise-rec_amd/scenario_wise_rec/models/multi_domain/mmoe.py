@@ -1,4 +1,6 @@
 """Multi-gate Mixture-of-Experts (reference: `models/multi_domain/mmoe.py:6-56`)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -58,8 +60,15 @@ class MMOE(SwrModule):
         ne, D = self.n_expert, self.domain_num
         experts, gates = list(self.experts), list(self.gates)
         if self._fusable():
-            y = self._first_bank()(embed_x, self.training)                       # [B, ne*H0 + D*ne]
             h0 = experts[0].block(0)[0].out_features
+            if (self.training and experts[0].n_blocks == 1 and experts[0].act == "relu" and embed_x.is_cuda
+                    and os.environ.get("SWR_BNMIX", "1") != "0" and (ne * h0 + D * ne) % 4 == 0
+                    and ops.bnmix_supported(ne, h0, D)):
+                # single-layer ReLU experts: BatchNorm + ReLU / softmax + gate mix in one pass, no [B, 148] activations
+                pooled = self._first_bank()(embed_x, True, mix=(ne, h0, D))      # [B, D*H]
+                logits = mlp_bank_forward(list(self.towers), pooled, shared_input=False)
+                return ops.domain_select(logits, domain_id, apply_sigmoid=True)
+            y = self._first_bank()(embed_x, self.training)                       # [B, ne*H0 + D*ne]
             if experts[0].n_blocks > 1:
                 ex = mlp_bank_forward(experts, y[:, :ne * h0], shared_input=False, first_block=1)
                 y = torch.cat([ex, y[:, ne * h0:]], dim=1)

@@ -435,24 +435,39 @@ class LinearBNAct(Function):
                 H.check(lib.swr_bn_eval_coeffs(H.ptr(gamma), H.ptr(beta), H.ptr(rm), H.ptr(rv), bn["eps"], Ntot,
                                                H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_eval_coeffs")
         identity = cfg["bn"] is None and all(a[2] in (None, "none") for a in _norm_acts(cfg["acts"], Ntot))
-        if identity:
-            Y = Z
+        mix = cfg.get("mix") if training else None
+        if mix is not None:
+            # BN + ReLU / softmax + gate mix in one pass (csrc/bnmix.hip): the activations Y are never materialised
+            ne, Hm, D = mix
+            Y = None
+            out = torch.empty((M, D * Hm), dtype=torch.float32, device=dev)
+            a = H.BnMixArgs()
+            a.M, a.ne, a.H, a.D = M, ne, Hm, D
+            a.Z, a.ldz, a.scale, a.shift = Z.data_ptr(), Ntot, scale.data_ptr(), shift.data_ptr()
+            a.P, a.ldp = out.data_ptr(), D * Hm
+            gate_p = torch.empty((M, D * ne), dtype=torch.float32, device=dev)     # kept for the backward (tiny)
+            a.G = gate_p.data_ptr()
+            H.check(lib.swr_bnmix_fwd(C.byref(a), H.stream()), "swr_bnmix_fwd")
+        elif identity:
+            out = Y = Z
         else:
-            Y = torch.empty_like(Z)
+            out = Y = torch.empty_like(Z)
             H.check(lib.swr_affine_act_fwd(H.ptr(Z), Ntot, H.ptr(scale), H.ptr(shift), acts, n_acts, H.ptr(Y), Ntot, M,
                                            Ntot, H.stream()), "swr_affine_act_fwd")
         ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
         ctx.params = params
         ctx.training_bn = training
-        ctx.save_for_backward(x, W, Z, Y, mean, rstd, scale, _cat_params(gammas) if gammas else None)
-        return Y
+        ctx.mix = mix
+        ctx.save_for_backward(x, W, Z, Y, mean, rstd, scale, _cat_params(gammas) if gammas else None, shift if mix else None,
+                              gate_p if mix else None)
+        return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dY):
         cfg = ctx.cfg
         M, N, K, G, Ntot = ctx.dims
-        x, W, Z, Y, mean, rstd, scale, gamma = ctx.saved_tensors
+        x, W, Z, Y, mean, rstd, scale, gamma, shift, gate_p = ctx.saved_tensors
         dev = x.device
         dY = H.f32c(dY)
         acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
@@ -468,9 +483,25 @@ class LinearBNAct(Function):
         if ctx.training_bn:
             nt = (M + 63) // 64
             partials = torch.empty((nt, Ntot, 2), dtype=torch.float32, device=dev)
-            H.check(lib.swr_bn_act_bwd_stats(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(mean),
-                                             H.ptr(rstd), acts, n_acts, H.ptr(partials), M, Ntot, H.stream()),
-                    "swr_bn_act_bwd_stats")
+            if ctx.mix is not None:
+                # incoming gradient is dP (w.r.t. the pooled outputs): one pass gives dL/d(BN output) + the statistics
+                ne, Hm, D = ctx.mix
+                dP = dY if dY.stride(0) % 4 == 0 and dY.data_ptr() % 16 == 0 else dY.contiguous()
+                dY = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+                a = H.BnMixArgs()
+                a.M, a.ne, a.H, a.D = M, ne, Hm, D
+                a.Z, a.ldz, a.scale, a.shift = Z.data_ptr(), Ntot, scale.data_ptr(), shift.data_ptr()
+                a.dP, a.lddp = dP.data_ptr(), dP.stride(0)
+                a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+                a.dY, a.lddy, a.bn_partials = dY.data_ptr(), Ntot, partials.data_ptr()
+                a.G = gate_p.data_ptr()
+                H.check(lib.swr_bnmix_bwd(C.byref(a), H.stream()), "swr_bnmix_bwd")
+                acts, n_acts = H.act_ranges(None, Ntot)          # the activations are already differentiated
+                Y = Z                                            # placeholder operand (no activation reads it)
+            else:
+                H.check(lib.swr_bn_act_bwd_stats(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(mean),
+                                                 H.ptr(rstd), acts, n_acts, H.ptr(partials), M, Ntot, H.stream()),
+                        "swr_bn_act_bwd_stats")
             dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_be, 2)
             direct_bn = dgamma is not None and dbeta is not None
             if not direct_bn:
@@ -555,13 +586,17 @@ def _norm_acts(acts, n):
     return acts
 
 
-def linear_bn_act(x, weights, biases, bn=None, acts=None, groups=1, training=True):
+def bnmix_supported(ne, Hm, D):
+    return bool(lib.swr_bnmix_supported(int(ne), int(Hm), int(D)))
+
+
+def linear_bn_act(x, weights, biases, bn=None, acts=None, groups=1, training=True, mix=None):
     """Functional front-end of LinearBNAct.
 
     weights / biases: lists of Parameters stacked along the output dim (biases may be None);
     bn: None or dict(gamma=[...], beta=[...], running_mean=[...], running_var=[...], nbt=[...], eps, momentum)."""
     cfg = {"n_w": len(weights), "has_bias": biases is not None, "groups": groups, "acts": acts,
-           "training": training, "bn": None, "n_bn": 0}
+           "training": training, "bn": None, "n_bn": 0, "mix": mix}
     params = list(weights) + (list(biases) if biases is not None else [])
     if bn is not None:
         cfg["bn"] = {k: bn[k] for k in ("running_mean", "running_var", "nbt", "eps", "momentum")}

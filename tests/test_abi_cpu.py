@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
     """Compile a C program against include/swr.h and compare sizeof / offsetof with the ctypes mirrors."""
     from scenario_wise_rec import _hip as H
     structs = {"swr_sparse_slot": H.SparseSlot, "swr_dense_slot": H.DenseSlot, "swr_embed_grad_slot": H.EmbedGradSlot,
-               "swr_tower_args": H.TowerArgs,
+               "swr_tower_args": H.TowerArgs, "swr_bnmix_args": H.BnMixArgs,
                "swr_gemm_args": H.GemmArgs, "swr_gemm_tn_args": H.GemmTnArgs, "swr_act_range": H.ActRange,
                "swr_mix_desc": H.MixDesc, "swr_adam_hyper": H.AdamHyper}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "swr.h"', 'int main(void){']

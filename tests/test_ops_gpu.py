@@ -414,3 +414,62 @@ def test_tower_head_matches_the_layerwise_path(M, G, K, Hd):
         a1 = np.maximum((z - z.mean(0)) / np.sqrt(z.var(0) + 1e-5) * gm + be, 0)
         cols.append(a1 @ w2.T + b2)
     np.testing.assert_allclose(Vb.cpu().numpy(), np.concatenate(cols, axis=1), rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("B,ne,Hh,D", [(1000, 4, 32, 5), (130, 2, 16, 4), (257, 3, 32, 4), (64, 8, 16, 4), (100, 2, 16, 3)])   # last: width not 16-byte, layer-wise
+def test_bnmix_path_matches_the_layerwise_path(B, ne, Hh, D):
+    """MMOE with the fused BatchNorm + ReLU / softmax + gate-mix kernels (csrc/bnmix.hip) against the same model run
+    layer by layer (SWR_BNMIX=0): probabilities, every parameter gradient and the BatchNorm running statistics."""
+    import os
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.models.multi_domain import MMOE
+    feats = [SparseFeature("a", 50, 8), SparseFeature("b", 7, 8), DenseFeature("x0"), DenseFeature("x1")]
+    torch.manual_seed(B + ne)
+    mods = [MMOE(feats, D, ne, {"dims": [Hh]}, {"dims": [8]}) for _ in range(2)]
+    mods[1].load_state_dict(mods[0].state_dict())
+    g = torch.Generator().manual_seed(3)
+    x = {"a": torch.randint(0, 50, (B,), generator=g), "b": torch.randint(0, 7, (B,), generator=g),
+         "x0": torch.rand(B, generator=g), "x1": torch.rand(B, generator=g),
+         "domain_indicator": torch.randint(0, D, (B,), generator=g)}
+    x = {k: v.cuda() for k, v in x.items()}
+    y = (torch.rand(B, generator=g) < 0.3).float().cuda()
+    res = []
+    for mod, flag in zip(mods, ("0", "1")):
+        mod.cuda().train()
+        for p in mod.parameters():
+            if p.dim() == 1:
+                p.data.add_(0.1 * torch.randn(p.shape, generator=g).cuda())      # gamma / beta / biases off their init
+        os.environ["SWR_BNMIX"] = flag
+        try:
+            mod.zero_grad()
+            p_ = mod(x)
+            ops_loss = torch.nn.functional.binary_cross_entropy(p_, y)
+            ops_loss.backward()
+        finally:
+            os.environ.pop("SWR_BNMIX", None)
+        res.append((p_.detach(), {n: q.grad.clone() for n, q in mod.named_parameters() if q.grad is not None},
+                    {n: b.clone() for n, b in mod.named_buffers()}))
+    # the two models were perturbed with different draws: redo with identical parameters
+    mods[1].load_state_dict(mods[0].state_dict())
+    res = []
+    for mod, flag in zip(mods, ("0", "1")):
+        os.environ["SWR_BNMIX"] = flag
+        try:
+            mod.zero_grad()
+            p_ = mod(x)
+            torch.nn.functional.binary_cross_entropy(p_, y).backward()
+        finally:
+            os.environ.pop("SWR_BNMIX", None)
+        res.append((p_.detach(), {n: q.grad.clone() for n, q in mod.named_parameters() if q.grad is not None},
+                    {n: b.clone() for n, b in mod.named_buffers()}))
+    (pa, ga, ba), (pb, gb, bb) = res
+    torch.testing.assert_close(pb, pa, rtol=1e-5, atol=2e-6)
+    assert set(ga) == set(gb)
+    for n in ga:
+        scale = float(ga[n].abs().max())
+        atol = 3e-5 * scale + 1e-7
+        if n.endswith("mlp.0.bias"):              # bias in front of BatchNorm: zero in exact arithmetic
+            atol = 1e-3 * float(ga[n.replace("bias", "weight")].abs().max()) + 1e-7
+        torch.testing.assert_close(gb[n], ga[n], rtol=2e-4, atol=atol, msg=n)
+    for n in ba:
+        torch.testing.assert_close(bb[n].float(), ba[n].float(), rtol=1e-5, atol=1e-6, msg=n)
