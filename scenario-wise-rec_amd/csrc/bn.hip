@@ -190,34 +190,50 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_v4_kernel(
 
 
 // ---------------------------------------------------------------------------------- forward stats
+// Two fixed-order fp64 passes over the tiles of one column: mean = sum(n_t mean_t) / n, then
+// M2 = sum(M2_t + n_t (mean_t - mean)^2) -- the pairwise (Chan) combination written as two plain sums, so the
+// 256-thread trees are additions only (a tree of fp64 divisions made this small kernel take 10 us).
 __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
     const float* __restrict__ part, int n_tiles, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var,
     int64_t* nbt, int n_tracked, float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
-    __shared__ SwrMoments sm[BN_THREADS];
+    __shared__ double sm[BN_THREADS];
+    __shared__ double mean_s;
     const int n = blockIdx.x;
-    SwrMoments acc = {0.0, 0.0, 0.0};
-    // each thread merges a contiguous run of tiles in order, then a fixed binary tree over threads
     const int per = (n_tiles + BN_THREADS - 1) / BN_THREADS;
-    const int t0 = threadIdx.x * per;
-    for (int t = t0; t < min(t0 + per, n_tiles); ++t) {
-        const float* p = part + (static_cast<int64_t>(t) * N + n) * 2;
-        SwrMoments b;
-        b.n = static_cast<double>(min<int64_t>(32, M - static_cast<int64_t>(t) * 32));
-        b.mean = p[0];
-        b.m2 = p[1];
-        acc = swr_merge(acc, b);
-    }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (int st = 1; st < BN_THREADS; st <<= 1) {
-        if ((threadIdx.x & (2 * st - 1)) == 0) sm[threadIdx.x] = swr_merge(sm[threadIdx.x], sm[threadIdx.x + st]);
+    const int t0 = threadIdx.x * per, t1 = min(t0 + per, n_tiles);
+    auto tree = [&](double v) {
+        sm[threadIdx.x] = v;
         __syncthreads();
+        for (int st = 1; st < BN_THREADS; st <<= 1) {
+            if ((threadIdx.x & (2 * st - 1)) == 0) sm[threadIdx.x] += sm[threadIdx.x + st];
+            __syncthreads();
+        }
+        const double r = sm[0];
+        __syncthreads();
+        return r;
+    };
+    double acc = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const double nt = static_cast<double>(min<int64_t>(32, M - static_cast<int64_t>(t) * 32));
+        acc += nt * static_cast<double>(part[(static_cast<int64_t>(t) * N + n) * 2]);
     }
+    const double total = tree(acc);
+    if (threadIdx.x == 0) mean_s = total / static_cast<double>(M);
+    __syncthreads();
+    const double mu = mean_s;
+    acc = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const float* p = part + (static_cast<int64_t>(t) * N + n) * 2;
+        const double nt = static_cast<double>(min<int64_t>(32, M - static_cast<int64_t>(t) * 32));
+        const double d = static_cast<double>(p[0]) - mu;
+        acc += static_cast<double>(p[1]) + nt * d * d;
+    }
+    const double m2 = tree(acc);
     if (threadIdx.x == 0) {
-        const SwrMoments tot = sm[0];
-        const double var_b = tot.m2 / tot.n;
-        const float mean = static_cast<float>(tot.mean);
+        const double cnt = static_cast<double>(M);
+        const double var_b = m2 / cnt;
+        const float mean = static_cast<float>(mu);
         const float rstd = static_cast<float>(1.0 / sqrt(var_b + static_cast<double>(eps)));
         const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
         const float scale = g * rstd;
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
         if (shift_o) shift_o[n] = b - mean * scale;
         if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mean;
         if (running_var) {
-            const float var_u = static_cast<float>(tot.n > 1.0 ? tot.m2 / (tot.n - 1.0) : var_b);
+            const float var_u = static_cast<float>(cnt > 1.0 ? m2 / (cnt - 1.0) : var_b);
             running_var[n] = (1.f - momentum) * running_var[n] + momentum * var_u;
         }
         if (nbt && n < n_tracked) nbt[n] += 1;

@@ -354,6 +354,7 @@ class EmbedGather(Function):
         for wpos, (urow, ugrad) in sparse_out.items():
             # row-sparse gradient of a large table: consumed by FusedAdam (optim.py); `.grad` stays None
             weights[wpos]._swr_sparse_grad = (urow, ugrad)
+            weights[wpos]._swr_sparse_local = True     # every row listed was looked up (and caught up) by THIS forward
         for i, g in enumerate(grads):
             if isinstance(g, tuple):
                 weights[i]._swr_touched = True

@@ -134,7 +134,10 @@ class FusedAdam(torch.optim.Optimizer):
                 for p, (urow, ugrad) in sparse:
                     # rows that take a gradient must be current BEFORE the step advances: those looked up by this
                     # rank were caught up by the forward lookup, those that only other ranks touched are caught up here
-                    self._lazy_state(p, hist, hyper).catchup(urow)
+                    if not getattr(p, "_swr_sparse_local", False):
+                        self._lazy_state(p, hist, hyper).catchup(urow)
+                    else:
+                        self._lazy_state(p, hist, hyper)       # (state must exist before the row kernel)
                 if ent[3] + 2 >= HIST_CAP:
                     raise H.SwrError("FusedAdam: step history full; call materialize() and rebuild the optimizer")
             H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, stream),

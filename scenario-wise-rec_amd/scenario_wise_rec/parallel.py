@@ -148,6 +148,7 @@ class DataParallelStep(object):
             merged = finish(arena["g"], communicate(arena["g"], sparse, self.world_size, self.group, bufs), self.world_size)
             for p, rg in zip(big, merged):
                 p._swr_sparse_grad = rg
+                p._swr_sparse_local = False      # rows other ranks touched are in the list too
         tr.optimizer.step()
         return loss
 
@@ -195,6 +196,7 @@ class DataParallelStep(object):
             merged = finish(arena["g"], gathered, self.world_size)
             for p, rg in zip(big, merged):
                 p._swr_sparse_grad = rg
+                p._swr_sparse_local = False
             self.trainer.optimizer.step()
         self._graphs = (g1, g2, buffers)
         self.loss = loss
