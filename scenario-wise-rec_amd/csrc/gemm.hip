@@ -821,7 +821,9 @@ static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps
     ta = static_cast<int>(swr_ceil_div(tiles1, pblk));
     const int qblk = static_cast<int>(swr_ceil_div(a.K2, 32 * TN_TB));
     const int64_t tiles = static_cast<int64_t>(pblk) * qblk * a.groups;
-    int64_t want = std::max<int64_t>(1, 2048 / tiles);                 // ~2 waves per SIMD over the chip
+    static const int waves_target = getenv("SWR_TN_WAVES") ? atoi(getenv("SWR_TN_WAVES")) : 1024;
+    int64_t want = std::max<int64_t>(1, waves_target / tiles);         // one wave per SIMD over the chip: measured 145 us vs 157 (2 per SIMD) and
+                                                                       // 174 (4): more resident waves only thrash the dword-load path
     want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / 64));    // at least 64 rows per wave
     rps = swr_ceil_div(a.M, want);
     rps += rps & 1;
