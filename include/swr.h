@@ -173,10 +173,19 @@ typedef struct {
     float* stat_partials;
     int32_t groups;
     int64_t gsA, gsB, gsC, gsBias, gsScale;
+    const void* B_split;   /* nt only, nullable: B already split into three bf16 planes by swr_split_weights
+                              ([3][>= N rows][ld_split] bf16, zero-padded to a multiple of 32 columns); the bf16-split
+                              kernel then stages it with plain copies instead of re-splitting B in every workgroup */
+    int64_t ld_split, plane_stride;   /* in bf16 elements */
 } swr_gemm_args;
 
 int swr_gemm_nt(const swr_gemm_args* args_host, void* stream);
 int swr_gemm_nn(const swr_gemm_args* args_host, void* stream);
+/* W[N, K] fp32 -> the three bf16 planes of W (`planes`, rows = N, columns = K padded to ld = swr_split_ld(K)) and / or
+ * of W^T (`planes_t`, rows = K, columns = N padded to ld_t = swr_split_ld(N)); x = h + m + l with h = bf16(x),
+ * m = bf16(x - h), l = bf16(x - h - m).  Either output may be null.  Plane p starts at p * rows * ld. */
+int64_t swr_split_ld(int64_t cols);
+int swr_split_weights(const float* W, int64_t ldw, int N, int K, void* planes, void* planes_t, void* stream);
 
 typedef struct {
     int64_t M;

@@ -265,7 +265,7 @@ __device__ __forceinline__ Bf3 split3(float x) {
         L[idx] = s3_.l;                    \
     } while (0)
 
-template <int NT, bool PRO>
+template <int NT, bool PRO, bool PS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD
     constexpr int NCOL = NT * 32;
     constexpr int PLANE = NCOL * X6_PITCH;              // bf16 elements per plane
@@ -299,14 +299,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
         const bool ok = k < K;
         return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     };
-    // ---- B staging: fp32 global -> registers (a chunk ahead) -> split -> three bf16 planes in LDS
-    float4 stage[F4_PER_THREAD];
+    // ---- B staging: fp32 global -> registers (a chunk ahead) -> split -> three bf16 planes in LDS; or, when the
+    // caller pre-split B (swr_split_weights: once per step instead of once per workgroup), three plain 8-byte copies
+    constexpr bool presplit = PS;
+    const __bf16* __restrict__ Bs = static_cast<const __bf16*>(a.B_split);
+    float4 stage[PS ? 1 : F4_PER_THREAD];
+    bf16x4 stage_p[PS ? F4_PER_THREAD : 1][3];
     auto stage_load = [&](int kc) {
 #pragma unroll
         for (int u = 0; u < F4_PER_THREAD; ++u) {
             const int q = min(static_cast<int>(threadIdx.x) + u * GEMM_THREADS, F4 - 1);
             const int n = min(n0 + (q >> 3), N - 1);
-            stage[u] = ld4c(Bg + static_cast<int64_t>(n) * a.ldb, kc + 4 * (q & 7));
+            if (presplit) {
+                // planes are zero-padded to a multiple of X6_KC columns: no clamp; chunks past the end are never stored
+                const __bf16* src = Bs + static_cast<int64_t>(n) * a.ld_split + min(kc, K - 1) / X6_KC * X6_KC + 4 * (q & 7);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) stage_p[PS ? u : 0][p] = *reinterpret_cast<const bf16x4*>(src + p * a.plane_stride);
+            } else {
+                stage[PS ? 0 : u] = ld4c(Bg + static_cast<int64_t>(n) * a.ldb, kc + 4 * (q & 7));
+            }
         }
     };
     auto stage_store = [&]() {
@@ -316,10 +327,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             if (q < F4) {
                 const int n = q >> 3, kq = 4 * (q & 7);
                 bf16x4 h, m, l;
-                SPLIT3_INTO(stage[u].x, h, m, l, 0);
-                SPLIT3_INTO(stage[u].y, h, m, l, 1);
-                SPLIT3_INTO(stage[u].z, h, m, l, 2);
-                SPLIT3_INTO(stage[u].w, h, m, l, 3);
+                if (presplit) {
+                    h = stage_p[PS ? u : 0][0]; m = stage_p[PS ? u : 0][1]; l = stage_p[PS ? u : 0][2];
+                } else {
+                    SPLIT3_INTO(stage[PS ? 0 : u].x, h, m, l, 0);
+                    SPLIT3_INTO(stage[PS ? 0 : u].y, h, m, l, 1);
+                    SPLIT3_INTO(stage[PS ? 0 : u].z, h, m, l, 2);
+                    SPLIT3_INTO(stage[PS ? 0 : u].w, h, m, l, 3);
+                }
                 __bf16* d = Bx + n * X6_PITCH + kq;
                 *reinterpret_cast<bf16x4*>(d) = h;
                 *reinterpret_cast<bf16x4*>(d + PLANE) = m;
@@ -529,6 +544,56 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_kernel(const GemmK kk)
     rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
 }
 
+// ------------------------------------------------------------------------------------ weight pre-split
+// thread = 4 consecutive k of one row n of W: the three planes of W ([N][ld]) with 8-byte stores and, element by
+// element, of W^T ([K][ld_t]); pad columns are written as zeros (the GEMM stages whole 32-column chunks)
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, __bf16* P,
+                                                            int64_t ld, __bf16* Pt, int64_t ld_t) {
+    const int k4n = static_cast<int>(ld / 4);
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t rows = max<int64_t>(N, Pt ? ld_t : N);     // rows of the index space: also covers W^T's pad columns
+    if (idx >= rows * k4n) return;
+    const int n = static_cast<int>(idx / k4n), k = static_cast<int>(idx - static_cast<int64_t>(n) * k4n) * 4;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (n < N && k + c < K) ? W[static_cast<int64_t>(n) * ldw + k + c] : 0.f;
+    bf16x4 h, m, l;
+    SPLIT3_INTO(v[0], h, m, l, 0);
+    SPLIT3_INTO(v[1], h, m, l, 1);
+    SPLIT3_INTO(v[2], h, m, l, 2);
+    SPLIT3_INTO(v[3], h, m, l, 3);
+    if (P && n < N) {
+        __bf16* d = P + static_cast<int64_t>(n) * ld + k;
+        *reinterpret_cast<bf16x4*>(d) = h;
+        *reinterpret_cast<bf16x4*>(d + static_cast<int64_t>(N) * ld) = m;
+        *reinterpret_cast<bf16x4*>(d + 2 * static_cast<int64_t>(N) * ld) = l;
+    }
+    if (Pt && n < ld_t) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k + c < K) {
+                __bf16* d = Pt + static_cast<int64_t>(k + c) * ld_t + n;
+                d[0] = h[c];
+                d[static_cast<int64_t>(K) * ld_t] = m[c];
+                d[2 * static_cast<int64_t>(K) * ld_t] = l[c];
+            }
+        }
+    }
+}
+
+extern "C" int64_t swr_split_ld(int64_t cols) { return (cols + X6_KC - 1) / X6_KC * X6_KC; }
+
+extern "C" int swr_split_weights(const float* W, int64_t ldw, int N, int K, void* planes, void* planes_t, void* stream) {
+    SWR_REQUIRE(W && N > 0 && K > 0 && ldw >= K && (planes || planes_t), SWR_ERR_ARG);
+    const int64_t ld = swr_split_ld(K), ld_t = swr_split_ld(N);
+    const int64_t rows = std::max<int64_t>(N, planes_t ? ld_t : N);
+    const int64_t items = rows * (ld / 4);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, 256))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), W, ldw, N, K, static_cast<__bf16*>(planes), ld,
+                       static_cast<__bf16*>(planes_t), ld_t);
+    return swr_launch_status();
+}
+
 // SWR_GEMM=f32 forces the f32-MFMA kernels (default: bf16x3-split "x6" kernels where applicable)
 static bool use_x6() {
     static int v = -1;
@@ -550,25 +615,32 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     GemmK kk;
     kk.a = a;
     kk.n_tiles_m = static_cast<int>(swr_ceil_div(a.M, 32));
+    if (a.B_split) {
+        SWR_REQUIRE(BT && a.groups == 1 && a.ld_split >= swr_split_ld(a.K) && a.ld_split % 4 == 0 &&
+                        a.plane_stride >= static_cast<int64_t>(a.N) * a.ld_split && swr_aligned16(a.B_split), SWR_ERR_ARG);
+    }
     const bool pro = a.a_scale != nullptr;
     bool vec = swr_aligned16(a.A) && a.lda % 4 == 0 && a.gsA % 4 == 0;
     vec = vec && swr_aligned16(a.B) && a.ldb % 4 == 0 && a.gsB % 4 == 0;      // both layouts are staged with 16-byte loads
     if (pro) vec = vec && swr_aligned16(a.a_scale) && swr_aligned16(a.a_shift) && a.gsScale % 4 == 0;
     const bool lds_ok = vec && a.K % 4 == 0 && a.K >= 4 && (BT || (a.N % 4 == 0 && a.N >= 4));
     const int tiles = static_cast<int>(swr_ceil_div(a.N, 32));
-    // tiles per wave: the LDS kernel keeps two waves per SIMD up to 5 tiles (VGPR + AGPR <= 256)
-    const int nblk = static_cast<int>(swr_ceil_div(tiles, lds_ok ? 5 : 8));
+    const bool x6_ok = BT && lds_ok && use_x6();
+    // tiles per wave: the f32 LDS kernel keeps two waves per SIMD up to 5 tiles (VGPR + AGPR <= 256), the bf16-split
+    // kernel up to 7 (252 VGPRs).  Fewer, wider column groups = fewer re-reads / re-splits of A and less padding
+    // (N = 516: 3 groups of 6 tiles instead of 4 of 5).
+    const int nblk = static_cast<int>(swr_ceil_div(tiles, x6_ok ? (a.B_split ? 6 : 7) : (lds_ok ? 5 : 8)));   // pre-split: 6 (VGPRs)
     const int nt = static_cast<int>(swr_ceil_div(tiles, nblk));
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(kk.n_tiles_m, GEMM_WAVES)), static_cast<unsigned>(nblk),
                     static_cast<unsigned>(a.groups));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool x6_ok = BT && lds_ok && use_x6();
 #define X6_BYTES(NTV) static_cast<unsigned>(3 * (NTV) * 32 * X6_PITCH * 2)
 #define LDS_BYTES(NTV) static_cast<unsigned>(2 * LDS_KC * ((NTV) * 32 + 4) * sizeof(float))
 #define GO(NTV)                                                                                                   \
     do {                                                                                                          \
-        if (x6_ok && pro) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, true>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
-        else if (x6_ok) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, false>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
+        if (x6_ok && pro) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, true, false>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
+        else if (x6_ok && a.B_split) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, false, true>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
+        else if (x6_ok) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, false, false>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
         else if (lds_ok && pro) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, true>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk);   \
         else if (lds_ok) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, false>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk); \
         else if (vec && pro) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, true>), grid, dim3(GEMM_THREADS), 0, st, kk);   \

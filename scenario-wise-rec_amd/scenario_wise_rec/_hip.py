@@ -69,7 +69,7 @@ class GemmArgs(C.Structure):
                 ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int32),
                 ("accumulate", C.c_int32), ("stat_partials", C.c_void_p), ("groups", C.c_int32),
                 ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsBias", C.c_int64),
-                ("gsScale", C.c_int64)]
+                ("gsScale", C.c_int64), ("B_split", C.c_void_p), ("ld_split", C.c_int64), ("plane_stride", C.c_int64)]
 
 
 class GemmTnArgs(C.Structure):
@@ -131,6 +131,8 @@ _SIGS = {
     "swr_embed_bwd_reduce": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
     "swr_gemm_nt": (C.c_int, [_P, _P]),
     "swr_gemm_nn": (C.c_int, [_P, _P]),
+    "swr_split_ld": (C.c_int64, [_L]),
+    "swr_split_weights": (C.c_int, [_P, _L, _I, _I, _P, _P, _P]),
     "swr_gemm_tn_workspace_bytes": (_Z, [_P]),
     "swr_gemm_tn": (C.c_int, [_P, _P, _Z, _P]),
     "swr_bn_finalize": (C.c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P]),

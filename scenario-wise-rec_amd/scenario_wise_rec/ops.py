@@ -25,9 +25,13 @@ def _ld(t):
 
 
 def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_relu=False, accumulate=False,
-         stat_partials=None, groups=1, gsA=0, gsB=0, gsC=0, gsBias=0, gsScale=0, lda=None, ldb=None, ldc=None):
-    """kind 'nt': C[m,n] = sum_k A[m,k] B[n,k];  'nn': C[m,n] = sum_k A[m,k] B[k,n]."""
+         stat_partials=None, groups=1, gsA=0, gsB=0, gsC=0, gsBias=0, gsScale=0, lda=None, ldb=None, ldc=None,
+         B_split=None):
+    """kind 'nt': C[m,n] = sum_k A[m,k] B[n,k];  'nn': C[m,n] = sum_k A[m,k] B[k,n].
+    B_split: (planes, ld, plane_stride) from split_weights -- B already split into bf16 planes ('nt', one group)."""
     a = H.GemmArgs()
+    if B_split is not None:
+        a.B_split, a.ld_split, a.plane_stride = B_split[0].data_ptr(), B_split[1], B_split[2]
     a.M, a.N, a.K = M, N, K
     a.A, a.lda = A.data_ptr(), lda if lda is not None else _ld(A)
     a.B, a.ldb = B.data_ptr(), ldb if ldb is not None else _ld(B)
@@ -43,6 +47,18 @@ def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_re
     H.check(fn(C.byref(a), H.stream()), f"swr_gemm_{kind}")
     if _side["deferred"]:
         _flush_deferred()          # side-stream work parked until the main stream had its next kernel enqueued
+
+
+def split_weights(W, want_t):
+    """Three bf16 planes (x = h + m + l) of W [N, K] for the bf16-split GEMM, and of W^T when `want_t`: ONE small
+    launch per step instead of a split of the weight tile in every workgroup of the product (and, for dX, instead of
+    the fp32 transpose copy).  Returns ((planes, ld, plane_stride), (planes_t, ld_t, plane_stride_t) or None)."""
+    N, K = W.shape
+    ld, ld_t = int(lib.swr_split_ld(K)), int(lib.swr_split_ld(N))
+    P = torch.empty(3 * N * ld, dtype=torch.bfloat16, device=W.device)
+    Pt = torch.empty(3 * K * ld_t, dtype=torch.bfloat16, device=W.device) if want_t else None
+    H.check(lib.swr_split_weights(H.ptr(W), W.stride(0), N, K, H.ptr(P), H.ptr(Pt), H.stream()), "swr_split_weights")
+    return (P, ld, N * ld), ((Pt, ld_t, K * ld_t) if want_t else None)
 
 
 def gemm_tn(A, B, C_out, M, K1, K2, colsum=None, accumulate=False, groups=1, gsA=0, gsB=0, gsC=0, gsColsum=0,
@@ -141,6 +157,8 @@ def _mark_touched(params):
 #    (queue_callback).  Measured on config 2: the dW product fills the chip and only slows whatever it overlaps.
 # Under hipGraph capture the forks / joins become parallel branches of the graph.
 SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"
+PRESPLIT = os.environ.get("SWR_PRESPLIT", "0") == "1"      # weights pre-split into bf16 planes once per step: measured
+                                                             # 16 us SLOWER per step than splitting in every workgroup (opt-in)
 SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measured: the chip-filling dW product only slows
                                                                         # whatever it is overlapped with; off by default
 SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "1"))   # measured: 1 (fork at once) 0.862 ms, 3 0.866, 2 0.94 (event nodes stall the branch)
@@ -418,8 +436,14 @@ class LinearBNAct(Function):
         training = cfg["training"] and cfg["bn"] is not None
         n_tiles = (M + 31) // 32
         partials = torch.empty((n_tiles, Ntot, 2), dtype=torch.float32, device=dev) if training else None
+        planes = planes_t = None
+        if (PRESPLIT and G == 1 and M >= 4096 and K % 4 == 0 and K >= 32 and W.is_contiguous() and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0):
+            # weights split into bf16 planes once per step (and W^T's planes for the dX product of the backward)
+            planes, planes_t = split_weights(W, bool(ctx.needs_input_grad[1]) and Ntot % 4 == 0)
         gemm("nt", x, W, Z, M, N, K, bias=b, stat_partials=partials, groups=G,
-             gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N)
+             gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N, B_split=planes)
+        ctx.planes_t = planes_t
         acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
         mean = rstd = scale = shift = None
         if cfg["bn"] is not None:
@@ -550,7 +574,10 @@ class LinearBNAct(Function):
                     # layout is the one the bf16-split MFMA kernel stages into LDS
                     # (forking this 5 us copy onto the side stream at forward time was measured: the extra
                     # cross-stream edge costs ~12 us of main-stream latency, more than the copy)
-                    gemm("nt", dZ, W.t().contiguous(), dx, M, K, Ntot)
+                    if ctx.planes_t is not None:
+                        gemm("nt", dZ, W, dx, M, K, Ntot, ldb=Ntot, B_split=ctx.planes_t)    # W^T only through its planes
+                    else:
+                        gemm("nt", dZ, W.t().contiguous(), dx, M, K, Ntot)
                 else:
                     gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:
