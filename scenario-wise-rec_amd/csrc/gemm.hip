@@ -845,6 +845,179 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) 
     }
 }
 
+// ------------------------------------------------------------------------- tn on the bf16 MFMA (x6 split)
+// The weight-gradient product has its reduction index (the batch) as the row index of BOTH operands, so the 8
+// consecutive k a bf16 MFMA fragment needs are a column slice: nothing a lane can load directly.  A workgroup of 8
+// waves stages TX_ROWS batch rows of A[:, 0:K1] (all of it, <= 160 columns) and of its 128 columns of B with coalesced
+// loads (a thread = 8 rows x 2 columns, three stages in flight in registers), splits every value into three bf16
+// terms ONCE and writes them transposed into LDS planes [buffer][plane][column][row] with 16-byte stores; fragments
+// are then single conflict-free ds_read_b128.  Waves 0-3 / 4-7 own q-tile (w & 3) and the first / second half of the
+// p-tiles; the planes are double-buffered: one barrier per 16 batch rows.  Partial tiles per batch split go to the
+// workspace and are summed by tn_reduce_kernel in fixed order.
+#define TX_ROWS 16
+#define TX_PM 24                        // bf16 pitch along the batch rows: 16 + 8 pad (48 bytes: conflict-free b128 access)
+#define TX_QCOLS 128                    // B columns per workgroup (4 q-tiles)
+#define TX_THREADS 512
+#define TX_DEPTH 3                      // stages in flight in registers
+
+template <int PT>
+__global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
+    constexpr int ACOLS = PT * 32, COLS = ACOLS + TX_QCOLS;
+    constexpr int UNITS = 2 * (COLS / 2);                              // (row oct, column pair)
+    constexpr int PA = (PT + 1) / 2;                                   // p-tiles of the first wave group
+    constexpr int PLANE = COLS * TX_PM, BUF = 3 * PLANE;               // bf16 elements
+    extern __shared__ __attribute__((aligned(16))) __bf16 Lx[];        // [2][3][COLS][TX_PM]
+    const swr_gemm_tn_args& a = kk.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, s = lane >> 5;
+    const int qt = wave & 3, p_first = (wave >> 2) ? PA : 0;
+    const int p_count = (wave >> 2) ? PT - PA : PA;
+    const int q0 = blockIdx.x * TX_QCOLS;
+    const int split = blockIdx.y;
+    const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
+    const int64_t me = min(ms + kk.rows_per_split, a.M);
+
+    f32x16 acc[PA];
+#pragma unroll
+    for (int t = 0; t < PA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // this thread's staging unit: row oct `ro` (rows 8 ro .. 8 ro + 7 of the stage), column pair `cp` of the slab
+    // the staging units go to waves 4-7 first (they own the smaller half of the p-tiles: their split work overlaps the
+    // other wave group's MFMAs on the same SIMD), the rest to wave 0
+    const int uid = (threadIdx.x + TX_THREADS / 2) & (TX_THREADS - 1);
+    const bool unit_on = uid < UNITS;
+    const int ro = uid & 1, cp = unit_on ? (uid >> 1) : 0;
+    const int scol = 2 * cp;                                           // slab column (A columns, then the 128 B columns)
+    const bool isA = scol < ACOLS;
+    const int gcol = isA ? scol : q0 + (scol - ACOLS);
+    const bool col_ok = unit_on && (isA ? gcol < a.K1 : gcol < a.K2);  // K1, K2 even
+    const float* __restrict__ src = (isA ? a.A : a.B) + (col_ok ? gcol : 0);
+    const int64_t ld = isA ? a.lda : a.ldb;
+    float cs0 = 0.f, cs1 = 0.f;                                        // column sums of A (bias gradient)
+
+    float2 st[TX_DEPTH][8];
+    // raw loads only: any arithmetic on a loaded value here would make the compiler wait for it here, three stages
+    // before it is needed; rows past the end / invalid columns are zeroed when the stage is stored.  32-bit element
+    // offsets (checked by the launcher), advanced by a scalar per stage and clamped to the last row of the matrix.
+    const uint32_t ld32 = static_cast<uint32_t>(ld);
+    const uint32_t off_last = static_cast<uint32_t>((a.M - 1 - ms) * ld);                // row M - 1, relative to row ms
+    const float* __restrict__ base = src + ms * ld;
+    uint32_t roff[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) roff[r] = static_cast<uint32_t>(8 * ro + r) * ld32;
+    auto stage_load = [&](int stage, float2 (&dst)[8]) {
+        const uint32_t so = static_cast<uint32_t>(stage) * (TX_ROWS * ld32);             // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r] = *reinterpret_cast<const float2*>(base + min(so + roff[r], off_last));
+    };
+    const int rows_total = static_cast<int>(me - ms);
+    auto stage_store = [&](int stage, const float2 (&raw)[8], __bf16* buf) {
+        if (!unit_on) return;
+        const int left = rows_total - stage * TX_ROWS - 8 * ro;                          // valid rows of this unit
+        bf16x8 h0, m0_, l0, h1, m1, l1;
+        if (col_ok && left >= 8) {                                                       // (almost always)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                SPLIT3_INTO(raw[r].x, h0, m0_, l0, r);
+                SPLIT3_INTO(raw[r].y, h1, m1, l1, r);
+                cs0 += raw[r].x;
+                cs1 += raw[r].y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool ok = col_ok && r < left;
+                const float vx = ok ? raw[r].x : 0.f, vy = ok ? raw[r].y : 0.f;
+                SPLIT3_INTO(vx, h0, m0_, l0, r);
+                SPLIT3_INTO(vy, h1, m1, l1, r);
+                cs0 += vx;
+                cs1 += vy;
+            }
+        }
+        __bf16* d = buf + scol * TX_PM + 8 * ro;
+        *reinterpret_cast<bf16x8*>(d) = h0;
+        *reinterpret_cast<bf16x8*>(d + PLANE) = m0_;
+        *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l0;
+        *reinterpret_cast<bf16x8*>(d + TX_PM) = h1;
+        *reinterpret_cast<bf16x8*>(d + TX_PM + PLANE) = m1;
+        *reinterpret_cast<bf16x8*>(d + TX_PM + 2 * PLANE) = l1;
+    };
+    auto frag = [&](bf16x8 (&f)[3], const __bf16* buf, int col) {
+        const __bf16* p = buf + (col + i) * TX_PM + 8 * s;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
+    };
+
+    const int n_stages = static_cast<int>((me - ms + TX_ROWS - 1) / TX_ROWS);
+    // prologue: stages 0 .. DEPTH-1 in flight, stage 0 into buffer 0, then stage DEPTH takes its slot
+#pragma unroll
+    for (int d = 0; d < TX_DEPTH; ++d) stage_load(d, st[d]);           // beyond the end: zeros (never used)
+    stage_store(0, st[0], Lx);
+    stage_load(TX_DEPTH, st[0]);
+    __syncthreads();
+    // steady state, unrolled by DEPTH so that the register slots are static
+    auto step = [&](int sg, auto slot_c) {
+        constexpr int NEXT = (decltype(slot_c)::value + 1) % TX_DEPTH;  // slot holding stage sg + 1
+        const __bf16* buf = Lx + (sg & 1) * BUF;
+        bf16x8 b[3], a0[3], a1[3];
+        frag(b, buf, ACOLS + 32 * qt);
+        frag(a0, buf, 32 * p_first);
+#pragma unroll
+        for (int t = 0; t < PA; ++t) {
+            if (t < p_count) {
+                bf16x8 (&af)[3] = (t & 1) ? a1 : a0;
+                bf16x8 (&nx)[3] = (t & 1) ? a0 : a1;
+                if (t + 1 < PA && t + 1 < p_count) frag(nx, buf, 32 * (p_first + t + 1));
+                __builtin_amdgcn_sched_barrier(0);      // the next tile's LDS reads are issued before this tile's MFMAs
+                f32x16 c_ = acc[t];
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);     // small terms first
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
+                acc[t] = c_;
+            }
+        }
+        if (sg + 1 < n_stages) stage_store(sg + 1, st[NEXT], Lx + ((sg + 1) & 1) * BUF);
+        stage_load(sg + 1 + TX_DEPTH, st[NEXT]);
+        __syncthreads();
+    };
+    int sg = 0;
+    for (; sg + TX_DEPTH <= n_stages; sg += TX_DEPTH) {
+        step(sg, std::integral_constant<int, 0>{});
+        step(sg + 1, std::integral_constant<int, 1>{});
+        step(sg + 2, std::integral_constant<int, 2>{});
+    }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 0>{}); ++sg; }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 1>{}); ++sg; }
+
+    // partial tile of this batch split -> workspace [split][K1][K2]
+    float* __restrict__ P = kk.part + static_cast<int64_t>(split) * a.K1 * a.K2;
+    const int q = q0 + 32 * qt + i;
+#pragma unroll
+    for (int t = 0; t < PA; ++t) {
+        if (t < p_count) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * (p_first + t) + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (p < a.K1 && q < a.K2) P[static_cast<int64_t>(p) * a.K2 + q] = acc[t][r];
+            }
+        }
+    }
+    // column sums of A: the two row-oct lanes of a column pair are adjacent lanes
+    if (kk.part_cs && blockIdx.x == 0) {
+        cs0 += __shfl_xor(cs0, 1);
+        cs1 += __shfl_xor(cs1, 1);
+        if (col_ok && isA && ro == 0) {
+            kk.part_cs[static_cast<int64_t>(split) * a.K1 + gcol] = cs0;
+            kk.part_cs[static_cast<int64_t>(split) * a.K1 + gcol + 1] = cs1;
+        }
+    }
+}
+
 // fixed-order sum of the per-workgroup partial tiles: L lanes share one output element (lane l takes partials l, l+L,
 // ... in order, UNROLL loads in flight) and are combined with a fixed butterfly -> deterministic; L grows with the
 // number of partials so that the per-lane chain stays a few loads long (tower layers have hundreds of partials)
@@ -903,11 +1076,30 @@ static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps
     return pblk;
 }
 
+// bf16-split tn kernel: one group, A narrow enough to stage whole (<= 5 column tiles), 16-byte rows, a batch worth it
+static bool tn_x6_ok(const swr_gemm_tn_args& a) {
+    static const int off = getenv("SWR_TN_X6") ? atoi(getenv("SWR_TN_X6")) == 0 : 0;
+    return use_x6() && !off && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
+           a.ldb % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0 && a.M >= 4096 &&
+           a.M * a.lda < (1ll << 31) && a.M * a.ldb < (1ll << 31);      // 32-bit element offsets inside the kernel
+}
+static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
+    static const int blocks_target = getenv("SWR_TN_X6_BLOCKS") ? atoi(getenv("SWR_TN_X6_BLOCKS")) : 256;   // one per CU
+    const int qblk = static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
+    int64_t want = std::max<int64_t>(1, blocks_target / qblk);
+    want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (8 * TX_ROWS)));
+    rps = swr_ceil_div(swr_ceil_div(a.M, want), TX_ROWS) * TX_ROWS;
+    n_splits = static_cast<int>(swr_ceil_div(a.M, rps));
+}
+
 extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args) {
     if (!args || args->M <= 0 || args->K1 <= 0 || args->K2 <= 0 || args->groups < 1) return 0;
     int ta, splits;
     int64_t rps;
-    tn_plan(*args, ta, splits, rps);
+    if (tn_x6_ok(*args))
+        tn_x6_plan(*args, splits, rps);
+    else
+        tn_plan(*args, ta, splits, rps);
     return static_cast<size_t>(args->groups) * splits * (static_cast<size_t>(args->K1) * args->K2 + args->K1) * 4 + 256;
 }
 
@@ -931,10 +1123,43 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         }
         return SWR_OK;
     }
-    int ta;
-    const int pblk = tn_plan(a, ta, kk.splits, kk.rows_per_split);
     const size_t need = swr_gemm_tn_workspace_bytes(args);
     SWR_REQUIRE(workspace != nullptr && workspace_bytes >= need, SWR_ERR_WORKSPACE);
+    if (tn_x6_ok(a)) {
+        int n_splits;
+        tn_x6_plan(a, n_splits, kk.rows_per_split);
+        kk.splits = n_splits * GEMM_WAVES;                      // tn_reduce_kernel counts partial tiles as splits / 4
+        kk.part = static_cast<float*>(workspace);
+        kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(n_splits) * a.K1 * a.K2 : nullptr;
+        kk.qblk = kk.pblk = kk.n_tiles = 0;
+        const int pt = static_cast<int>(swr_ceil_div(a.K1, 32));
+        const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS)), static_cast<unsigned>(n_splits));
+        const unsigned lds = static_cast<unsigned>(2 * 3 * (pt * 32 + TX_QCOLS) * TX_PM * sizeof(__bf16));
+        const void* fn = nullptr;
+        switch (pt) {
+            case 1: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<1>); break;
+            case 2: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<2>); break;
+            case 3: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<3>); break;
+            case 4: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<4>); break;
+            default: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<5>); break;
+        }
+        // > 64 KB of dynamic LDS needs the attribute (idempotent, not a stream operation; first call = a warm-up step)
+        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+            return SWR_ERR_LAUNCH;
+        void* kargs[] = {&kk};
+        if (hipLaunchKernel(fn, grid, dim3(TX_THREADS), kargs, lds, st) != hipSuccess) return SWR_ERR_LAUNCH;
+        const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
+        const dim3 rblock(256);
+#define TN_RED(LV)                                                                                                      \
+    hipLaunchKernelGGL(tn_reduce_kernel<LV>, dim3(static_cast<unsigned>(swr_ceil_div(n * LV, 256)), 1u), rblock, 0, st, kk)
+        if (n_splits > 64) TN_RED(32);
+        else if (n_splits > 16) TN_RED(8);
+        else TN_RED(4);
+#undef TN_RED
+        return swr_launch_status();
+    }
+    int ta;
+    const int pblk = tn_plan(a, ta, kk.splits, kk.rows_per_split);
     kk.part = static_cast<float*>(workspace);
     kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(a.groups) * kk.splits * a.K1 * a.K2 : nullptr;
     const int zsplit = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
