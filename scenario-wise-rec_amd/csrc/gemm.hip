@@ -64,18 +64,32 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
         const int n = n0 + 32 * t + i;
         const float bn = (bias && n < N) ? bias[n] : 0.f;
         float sum = 0.f;
+        if (nvalid == 32 && n0 + 32 * t + 32 <= N && !a.accumulate) {
+            // whole tile inside C (wave-uniform test): no per-element predicates; wave-uniform row bases + one 32-bit
+            // lane offset, so each store is a scalar-base access instead of a 64-bit multiply-add per element
+            const uint32_t lane_off = static_cast<uint32_t>(4 * s) * static_cast<uint32_t>(a.ldc) + static_cast<uint32_t>(n);
+            float* __restrict__ tile_base = Cg + m0 * a.ldc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            float v = acc[t][r] + bn;
-            const bool ok = row < nvalid && n < N;
-            if (ok) {
-                float* c = Cg + (m0 + row) * a.ldc + n;
-                if (a.accumulate) v += *c;
-                *c = v;
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r] + bn;
+                (tile_base + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * a.ldc)[lane_off] = v;
                 sum += v;
+                acc[t][r] = v;
             }
-            acc[t][r] = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
+                float v = acc[t][r] + bn;
+                const bool ok = row < nvalid && n < N;
+                if (ok) {
+                    float* c = Cg + (m0 + row) * a.ldc + n;
+                    if (a.accumulate) v += *c;
+                    *c = v;
+                    sum += v;
+                }
+                acc[t][r] = v;
+            }
         }
         if (a.stat_partials) {
             // BatchNorm batch statistics of this 32-row tile, two-pass in registers
@@ -294,8 +308,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    auto ld4c = [&](const float* __restrict__ row, int k) -> float4 {      // k % 4 == 0; zero when k >= K
-        const float4 v = *reinterpret_cast<const float4*>(row + min(k, K - 4));
+    // Prefetched values stay RAW in their registers: any arithmetic on a loaded value at the load site (even the
+    // zeroing of k >= K) makes hipcc wait for the load right there (91 x s_waitcnt vmcnt(0) in this kernel before) and
+    // the rings prefetch nothing.  Addresses are clamped; the k >= K mask is applied when a value is consumed.
+    auto ld4raw = [&](const float* __restrict__ row, int k) -> float4 {      // k % 4 == 0
+        return *reinterpret_cast<const float4*>(row + min(k, K - 4));
+    };
+    auto mask4 = [&](float4 v, int k) -> float4 {
         const bool ok = k < K;
         return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     };
@@ -316,11 +335,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
 #pragma unroll
                 for (int p = 0; p < 3; ++p) stage_p[PS ? u : 0][p] = *reinterpret_cast<const bf16x4*>(src + p * a.plane_stride);
             } else {
-                stage[PS ? 0 : u] = ld4c(Bg + static_cast<int64_t>(n) * a.ldb, kc + 4 * (q & 7));
+                stage[PS ? 0 : u] = ld4raw(Bg + static_cast<int64_t>(n) * a.ldb, kc + 4 * (q & 7));
             }
         }
     };
-    auto stage_store = [&]() {
+    auto stage_store = [&](int kc) {
 #pragma unroll
         for (int u = 0; u < F4_PER_THREAD; ++u) {
             const int q = threadIdx.x + u * GEMM_THREADS;
@@ -330,10 +349,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
                 if (presplit) {
                     h = stage_p[PS ? u : 0][0]; m = stage_p[PS ? u : 0][1]; l = stage_p[PS ? u : 0][2];
                 } else {
-                    SPLIT3_INTO(stage[PS ? 0 : u].x, h, m, l, 0);
-                    SPLIT3_INTO(stage[PS ? 0 : u].y, h, m, l, 1);
-                    SPLIT3_INTO(stage[PS ? 0 : u].z, h, m, l, 2);
-                    SPLIT3_INTO(stage[PS ? 0 : u].w, h, m, l, 3);
+                    const float4 sv = mask4(stage[PS ? 0 : u], kc + kq);
+                    SPLIT3_INTO(sv.x, h, m, l, 0);
+                    SPLIT3_INTO(sv.y, h, m, l, 1);
+                    SPLIT3_INTO(sv.z, h, m, l, 2);
+                    SPLIT3_INTO(sv.w, h, m, l, 3);
                 }
                 __bf16* d = Bx + n * X6_PITCH + kq;
                 *reinterpret_cast<bf16x4*>(d) = h;
@@ -348,22 +368,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
     float4 ar[DEPTH][2];
     auto a_load = [&](int gi, float4 (&dst)[2]) {
 #pragma unroll
+        for (int hh = 0; hh < 2; ++hh) dst[hh] = ld4raw(arow, 16 * gi + 8 * s + 4 * hh);
+    };
+    auto a_use = [&](int gi, const float4 (&raw)[2], float4 (&v2)[2]) {      // mask (+ the fused BN / ReLU prologue)
+#pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int k = 16 * gi + 8 * s + 4 * hh;
-            float4 v = ld4c(arow, k);
+            float4 v = raw[hh];
             if (PRO) {
-                const float4 sc = ld4c(psc, k), sh = ld4c(psh, k);
+                const float4 sc = ld4raw(psc, k), sh = ld4raw(psh, k);
                 v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                 if (a.a_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
-            dst[hh] = v;
+            v2[hh] = mask4(v, k);
         }
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) a_load(d, ar[d]);
 
     stage_load(0);
-    stage_store();
+    stage_store(0);
     __syncthreads();
     const int n_chunks = (K + X6_KC - 1) / X6_KC;
     auto b_read = [&](bf16x8 (&bf)[3], int gq, int t) {
@@ -376,7 +400,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
         stage_load((c + 1) * X6_KC);                   // beyond K this loads zeros (never stored)
 #pragma unroll
         for (int gq = 0; gq < X6_KC / 16; ++gq) {
-            const float4 (&av)[2] = ar[gq + HALF * (DEPTH / 2)];
+            float4 av[2];
+            a_use(c * (X6_KC / 16) + gq, ar[gq + HALF * (DEPTH / 2)], av);
             bf16x8 ah, am, al;
             SPLIT3_INTO(av[0].x, ah, am, al, 0); SPLIT3_INTO(av[0].y, ah, am, al, 1);
             SPLIT3_INTO(av[0].z, ah, am, al, 2); SPLIT3_INTO(av[0].w, ah, am, al, 3);
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             a_load(c * (X6_KC / 16) + gq + DEPTH, ar[gq + HALF * (DEPTH / 2)]);
         }
         __syncthreads();                       // every wave is done reading this chunk's planes
-        if (c + 1 < n_chunks) stage_store();
+        if (c + 1 < n_chunks) stage_store((c + 1) * X6_KC);
         __syncthreads();
     };
     for (int c = 0; c < n_chunks; c += 2) {
