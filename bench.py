@@ -30,6 +30,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity headline)
 
 # KuaiRand-1K schema (scripts/run_kuairand_ctr_multi_domain.py:15-57, scripts/data/kuairand/load_data_1k.py:23-49,
 # README.md:137): user_id, video_id, 8 user categoricals, 18 one-hot groups, 4 video categoricals; 4 dense
@@ -262,11 +263,13 @@ def main():
 
 
 def measure_roofline(cfg, model, trainer, x, dev, iters):
-    """Dominant kernel of the step at this config (profiles/): the weight-gradient product of the stacked
-    expert + gate layer, dW[148, 516] = dZ^T[148, B] @ E[B, 516] (`gemm_tn_kernel`, reduction over the batch), on the
-    f32 MFMA pipe.  Algorithmic flops = 2 * B * 148 * 516; peak = the f32-input MFMA rate (157.3 TFLOP/s).
-    Timed live with HIP events on the launch stream over K launches of the product alone (the call also issues the
-    small fixed-order partial-tile reduction, < 15 % of it)."""
+    """Longest single kernel of the step at this config (profiles/): the weight-gradient product of the stacked
+    expert + gate layer, dW[148, 516] = dZ^T[148, B] @ E[B, 516] (reduction over the batch).  It runs on the bf16 MFMA
+    with every fp32 operand split into three bf16 terms and the six significant cross products accumulated in fp32
+    (`gemm_tn_x6_kernel`, csrc/gemm.hip): algorithmic flops of that algorithm = 6 * 2 * B * 148 * 516 bf16 flops, peak =
+    the dense bf16 MFMA rate (2.5 PFLOP/s).  `fp32_equivalent_tflops` = 2 * B * 148 * 516 / t, comparable with the f32-MFMA
+    peak of 157.3 TFLOP/s.  Timed live with HIP events on the launch stream over graph-captured launches of the product
+    alone (kernel + its small fixed-order partial-tile reduction)."""
     from scenario_wise_rec import ops
     B = cfg["batch"]
     fs, e, fd = len(cfg["vocabs"]), cfg["embed_dim"], cfg["n_dense"]
@@ -280,13 +283,18 @@ def measure_roofline(cfg, model, trainer, x, dev, iters):
     db = torch.empty(n1, device=dev)
     stream = torch.cuda.Stream()
     ms = time_kernel_events(lambda: ops.gemm_tn(dZ, E, dW, B, n1, k0, colsum=db), max(10, iters), stream)
-    flops = 2.0 * B * n1 * k0
+    x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f" and os.environ.get("SWR_TN_X6", "1") != "0"
+    flops32 = 2.0 * B * n1 * k0
+    flops = 6.0 * flops32 if x6 else flops32
+    peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_tn_kernel (+tn_reduce_kernel)", "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("void gemm_tn_kernel<5>"),
+    kname = "gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"
+    return {"kernel": kname + " (+tn_reduce_kernel)", "bound": "mfma", "achieved": achieved, "peak": peak,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic("void %s<5>" % kname),
             "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)",
             "algorithmic_bytes_per_launch": 4.0 * B * (n1 + k0),
-            "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms,
+            "algorithmic_flops_per_launch": flops, "mfma_dtype": "bf16 (3-way split of fp32 operands, fp32 accumulate)" if x6 else "f32",
+            "fp32_equivalent_tflops": flops32 / (ms * 1e-3) / 1e12, "avg_launch_ms": ms,
             "also": {"embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters)}}
 
 

@@ -897,8 +897,13 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     const int i = lane & 31, s = lane >> 5;
     const int qt = wave & 3, p_first = (wave >> 2) ? PA : 0;
     const int p_count = (wave >> 2) ? PT - PA : PA;
-    const int q0 = blockIdx.x * TX_QCOLS;
-    const int split = blockIdx.y;
+    // XCD-aware order (workgroup ids go round-robin over the 8 XCDs): the q-blocks of one batch split, which all read the
+    // same rows of A, are consecutive ids of ONE XCD -> A comes from HBM once, not once per q-block
+    const unsigned per_xcd = gridDim.x / 8;
+    const unsigned lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (lin >= kk.n_tiles) return;
+    const int q0 = static_cast<int>(lin % kk.qblk) * TX_QCOLS;
+    const int split = static_cast<int>(lin / kk.qblk);
     const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
     const int64_t me = min(ms + kk.rows_per_split, a.M);
 
@@ -1033,7 +1038,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
         }
     }
     // column sums of A: the two row-oct lanes of a column pair are adjacent lanes
-    if (kk.part_cs && blockIdx.x == 0) {
+    if (kk.part_cs && q0 == 0) {
         cs0 += __shfl_xor(cs0, 1);
         cs1 += __shfl_xor(cs1, 1);
         if (col_ok && isA && ro == 0) {
@@ -1156,9 +1161,11 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         kk.splits = n_splits * GEMM_WAVES;                      // tn_reduce_kernel counts partial tiles as splits / 4
         kk.part = static_cast<float*>(workspace);
         kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(n_splits) * a.K1 * a.K2 : nullptr;
-        kk.qblk = kk.pblk = kk.n_tiles = 0;
+        kk.qblk = static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
+        kk.pblk = 1;
+        kk.n_tiles = kk.qblk * static_cast<unsigned>(n_splits);
         const int pt = static_cast<int>(swr_ceil_div(a.K1, 32));
-        const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS)), static_cast<unsigned>(n_splits));
+        const dim3 grid((kk.n_tiles + 7) / 8 * 8);
         const unsigned lds = static_cast<unsigned>(2 * 3 * (pt * 32 + TX_QCOLS) * TX_PM * sizeof(__bf16));
         const void* fn = nullptr;
         switch (pt) {
