@@ -180,7 +180,9 @@ class DataParallelStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        # thread_local: the RCCL watchdog thread polls events while this thread captures; in the default (global) mode
+        # that poll would invalidate the capture
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             loss = self._forward_backward(self.x, self.y)
             ops.join_side_streams()
             arena, big, sparse = self._sparse()
@@ -192,7 +194,7 @@ class DataParallelStep(object):
             assert urow.data_ptr() == buffers[0].data_ptr() + 4 * r0 and ugrad.data_ptr() == buffers[0].data_ptr() + 4 * r1
         gathered = (buffers[1], A, offs, total)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g1.pool()):
+        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             merged = finish(arena["g"], gathered, self.world_size)
             for p, rg in zip(big, merged):
                 p._swr_sparse_grad = rg
