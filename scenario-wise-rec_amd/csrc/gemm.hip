@@ -258,6 +258,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define X6_KC 32                        // k per chunk (2 MFMA groups of 16)
 #define X6_PITCH 40                     // bf16 per LDS row: 32 + 8 pad -> 80-byte pitch, conflict-free ds_read_b128
+#define X6_DOUBLE_BUFFER(NT) 0         // measured: two buffers / one barrier per chunk is no faster than one / two
 
 struct Bf3 {
     __bf16 h, m, l;
@@ -285,8 +286,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
     constexpr int PLANE = NCOL * X6_PITCH;              // bf16 elements per plane
     constexpr int F4 = NCOL * X6_KC / 4;                // float4 of W per chunk
     constexpr int F4_PER_THREAD = (F4 + GEMM_THREADS - 1) / GEMM_THREADS;
-    extern __shared__ __attribute__((aligned(16))) __bf16 Bx[];     // [3 planes][NCOL][X6_PITCH], ONE buffer (38 KB at NT = 5:
-                                                                    // two workgroups per CU; the refill costs two barriers per chunk)
+    // [buffers][3 planes][NCOL][X6_PITCH]: two buffers while two workgroups still fit a CU (NT <= 5: 77 KB), so the
+    // refill of the next chunk overlaps this chunk's MFMAs and a chunk costs one barrier; one buffer (two barriers) above
+    constexpr bool DB = X6_DOUBLE_BUFFER(NT);
+    extern __shared__ __attribute__((aligned(16))) __bf16 Bx[];
     const swr_gemm_args& a = kk.a;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, s = lane >> 5;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             }
         }
     };
-    auto stage_store = [&](int kc) {
+    auto stage_store = [&](int kc, int buf) {
 #pragma unroll
         for (int u = 0; u < F4_PER_THREAD; ++u) {
             const int q = threadIdx.x + u * GEMM_THREADS;
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
                     SPLIT3_INTO(sv.z, h, m, l, 2);
                     SPLIT3_INTO(sv.w, h, m, l, 3);
                 }
-                __bf16* d = Bx + n * X6_PITCH + kq;
+                __bf16* d = Bx + buf * (3 * PLANE) + n * X6_PITCH + kq;
                 *reinterpret_cast<bf16x4*>(d) = h;
                 *reinterpret_cast<bf16x4*>(d + PLANE) = m;
                 *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = l;
@@ -387,11 +390,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
     for (int d = 0; d < DEPTH; ++d) a_load(d, ar[d]);
 
     stage_load(0);
-    stage_store(0);
+    stage_store(0, 0);
     __syncthreads();
     const int n_chunks = (K + X6_KC - 1) / X6_KC;
-    auto b_read = [&](bf16x8 (&bf)[3], int gq, int t) {
-        const __bf16* bp = Bx + (32 * t + i) * X6_PITCH + 16 * gq + 8 * s;
+    auto b_read = [&](bf16x8 (&bf)[3], int gq, int t, int buf) {
+        const __bf16* bp = Bx + buf * (3 * PLANE) + (32 * t + i) * X6_PITCH + 16 * gq + 8 * s;
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(bp + p * PLANE);
     };
@@ -408,12 +411,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             SPLIT3_INTO(av[1].x, ah, am, al, 4); SPLIT3_INTO(av[1].y, ah, am, al, 5);
             SPLIT3_INTO(av[1].z, ah, am, al, 6); SPLIT3_INTO(av[1].w, ah, am, al, 7);
             bf16x8 b0[3], b1[3];
-            b_read(b0, gq, 0);
+            b_read(b0, gq, 0, DB ? HALF : 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bf16x8 (&cur)[3] = (t & 1) ? b1 : b0;
                 bf16x8 (&nxt)[3] = (t & 1) ? b0 : b1;
-                if (t + 1 < NT) b_read(nxt, gq, t + 1);
+                if (t + 1 < NT) b_read(nxt, gq, t + 1, DB ? HALF : 0);
                 __builtin_amdgcn_sched_barrier(0);      // next tile's LDS reads are issued before this tile's MFMAs
                 f32x16 c_ = acc[t];
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cur[0], c_, 0, 0, 0);     // small terms first
@@ -426,9 +429,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             }
             a_load(c * (X6_KC / 16) + gq + DEPTH, ar[gq + HALF * (DEPTH / 2)]);
         }
-        __syncthreads();                       // every wave is done reading this chunk's planes
-        if (c + 1 < n_chunks) stage_store((c + 1) * X6_KC);
-        __syncthreads();
+        if (DB) {
+            if (c + 1 < n_chunks) stage_store((c + 1) * X6_KC, HALF ^ 1);      // the other buffer: last read in chunk c - 1
+            __syncthreads();
+        } else {
+            __syncthreads();                   // every wave is done reading this chunk's planes
+            if (c + 1 < n_chunks) stage_store((c + 1) * X6_KC, 0);
+            __syncthreads();
+        }
     };
     for (int c = 0; c < n_chunks; c += 2) {
         do_chunk(c, std::integral_constant<int, 0>{});
@@ -629,6 +637,19 @@ static bool use_x6() {
     return v == 1;
 }
 
+template <int NT, bool PRO, bool PS>
+static void launch_x6(dim3 grid, unsigned lds, hipStream_t st, const GemmK& kk) {
+    // more than 64 KB of dynamic LDS needs the attribute once per instantiation (not a stream operation; the first
+    // call of a shape happens in a warm-up step, never inside a hipGraph capture)
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_x6_kernel<NT, PRO, PS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<NT, PRO, PS>), grid, dim3(GEMM_THREADS), lds, st, kk);
+}
+
 template <bool BT>
 static int launch_rows(const swr_gemm_args* args, void* stream) {
     SWR_REQUIRE(args != nullptr, SWR_ERR_ARG);
@@ -659,13 +680,13 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(kk.n_tiles_m, GEMM_WAVES)), static_cast<unsigned>(nblk),
                     static_cast<unsigned>(a.groups));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define X6_BYTES(NTV) static_cast<unsigned>(3 * (NTV) * 32 * X6_PITCH * 2)
+#define X6_BYTES(NTV) static_cast<unsigned>((X6_DOUBLE_BUFFER(NTV) ? 2 : 1) * 3 * (NTV) * 32 * X6_PITCH * 2)
 #define LDS_BYTES(NTV) static_cast<unsigned>(2 * LDS_KC * ((NTV) * 32 + 4) * sizeof(float))
 #define GO(NTV)                                                                                                   \
     do {                                                                                                          \
-        if (x6_ok && pro) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, true, false>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
-        else if (x6_ok && a.B_split) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, false, true>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
-        else if (x6_ok) hipLaunchKernelGGL((gemm_rows_x6_kernel<NTV, false, false>), grid, dim3(GEMM_THREADS), X6_BYTES(NTV), st, kk);   \
+        if (x6_ok && pro) launch_x6<NTV, true, false>(grid, X6_BYTES(NTV), st, kk);   \
+        else if (x6_ok && a.B_split) launch_x6<NTV, false, true>(grid, X6_BYTES(NTV), st, kk);   \
+        else if (x6_ok) launch_x6<NTV, false, false>(grid, X6_BYTES(NTV), st, kk);   \
         else if (lds_ok && pro) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, true>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk);   \
         else if (lds_ok) hipLaunchKernelGGL((gemm_rows_lds_kernel<NTV, BT, false>), grid, dim3(GEMM_THREADS), LDS_BYTES(NTV), st, kk); \
         else if (vec && pro) hipLaunchKernelGGL((gemm_rows_kernel<NTV, BT, true, true>), grid, dim3(GEMM_THREADS), 0, st, kk);   \
