@@ -212,6 +212,10 @@ int swr_bn_finalize(const float* stat_partials, int n_tiles, int64_t M, int N,
                     float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, int n_tracked /* counters to bump (fused BN modules) */,
                     float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* Statistics of a tensor that no GEMM of this library produced (STAR's partitioned normalisation of the embedding,
+ * star.py:91-98): per 32-row tile and column the pair (mean, M2) in the layout swr_bn_finalize merges,
+ * stat_partials[ceil(M/32)][N][2]. */
+int swr_col_moments(const float* X, int64_t ldx, int64_t M, int N, float* stat_partials, void* stream);
 /* eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale */
 int swr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int N, float* scale, float* shift, void* stream);

@@ -262,6 +262,54 @@ extern "C" int swr_bn_finalize(const float* stat_partials, int n_tiles, int64_t 
     return swr_launch_status();
 }
 
+// (mean, M2) per 32-row tile and column of an arbitrary [M, N] tensor: workgroup = 8 tiles (256 rows) x 64 columns;
+// a thread owns one column of one tile half (16 rows, two passes in registers), halves combined by Chan's formula
+__global__ __launch_bounds__(BN_THREADS) void col_moments_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int N,
+                                                                 float* __restrict__ partials) {
+    __shared__ float s_sum[4][64], s_m2[4][64];
+    const int cx = threadIdx.x & 63, part = threadIdx.x >> 6;          // 4 row quarters of a 32-row tile
+    const int n = blockIdx.y * 64 + cx;
+    for (int tl = 0; tl < 8; ++tl) {
+        const int64_t tile = static_cast<int64_t>(blockIdx.x) * 8 + tl;
+        const int64_t m0 = tile * 32;
+        if (m0 >= M) break;                                             // uniform
+        const int rows = static_cast<int>(min<int64_t>(32, M - m0));
+        float v[8];
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = part * 8 + r;
+            v[r] = (n < N && row < rows) ? X[(m0 + row) * ldx + n] : 0.f;
+            sum += v[r];
+        }
+        s_sum[part][cx] = sum;
+        __syncthreads();
+        const float mean = ((s_sum[0][cx] + s_sum[1][cx]) + (s_sum[2][cx] + s_sum[3][cx])) / static_cast<float>(rows);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float d = v[r] - mean;
+            if (part * 8 + r < rows) m2 = fmaf(d, d, m2);
+        }
+        s_m2[part][cx] = m2;
+        __syncthreads();
+        if (part == 0 && n < N) {
+            float* p = partials + (tile * N + n) * 2;
+            p[0] = mean;
+            p[1] = (s_m2[0][cx] + s_m2[1][cx]) + (s_m2[2][cx] + s_m2[3][cx]);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int swr_col_moments(const float* X, int64_t ldx, int64_t M, int N, float* stat_partials, void* stream) {
+    SWR_REQUIRE(X && stat_partials && M > 0 && N > 0 && ldx >= N, SWR_ERR_ARG);
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(swr_ceil_div(M, 32), 8)), static_cast<unsigned>(swr_ceil_div(N, 64)));
+    hipLaunchKernelGGL(col_moments_kernel, grid, dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), X, ldx, M, N,
+                       stat_partials);
+    return swr_launch_status();
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       int N, float* scale, float* shift) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;

@@ -136,6 +136,7 @@ _SIGS = {
     "swr_gemm_tn_workspace_bytes": (_Z, [_P]),
     "swr_gemm_tn": (C.c_int, [_P, _P, _Z, _P]),
     "swr_bn_finalize": (C.c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "swr_col_moments": (C.c_int, [_P, _L, _L, _I, _P, _P]),
     "swr_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "swr_affine_act_fwd": (C.c_int, [_P, _L, _P, _P, _P, _I, _P, _L, _L, _I, _P]),
     "swr_bn_act_bwd_stats": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _P]),

@@ -89,10 +89,7 @@ class Star(SwrModule):
         aux_out = self.auxnet(emb)                                        # [B, 1]
         D = self.num_domains
         # partitioned norm, shared part (identical for every domain, star.py:95-98): biased variance, eps 1e-6
-        mean = emb.mean(dim=0)
-        cen = emb - mean
-        var = (cen * cen).mean(dim=0)
-        h = cen / torch.sqrt(var + self.eps)
+        h = ops.batch_standardize(emb, self.eps)
         for l in range(self.layer_num):
             ws, bs = [], []
             for d in range(D):

@@ -742,6 +742,60 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
     return TowerHead.apply(cfg, x, *W1s, *b1s, *bn["gamma"], *bn["beta"], *w2s, *b2s)
 
 
+class BatchStandardize(Function):
+    """y = (x - mean_batch) / sqrt(var_batch + eps), biased variance, no affine and no running statistics: the shared
+    part of STAR's partitioned normalisation (star.py:91-98).  Statistics by swr_col_moments + swr_bn_finalize, one
+    affine pass; the backward is the BatchNorm backward with gamma = 1 (two passes)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        H.require_device(x)
+        x = H.f32c(x)
+        M, N = x.shape
+        if M < 1:
+            raise ValueError("empty batch")
+        dev = x.device
+        n_tiles = (M + 31) // 32
+        partials = torch.empty((n_tiles, N, 2), dtype=torch.float32, device=dev)
+        H.check(lib.swr_col_moments(H.ptr(x), x.stride(0) if M > 1 else N, M, N, H.ptr(partials), H.stream()), "swr_col_moments")
+        mean, rstd, scale, shift = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(4))
+        H.check(lib.swr_bn_finalize(H.ptr(partials), n_tiles, M, N, None, None, float(eps), 0.0, None, None, None, 0,
+                                    H.ptr(mean), H.ptr(rstd), H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_finalize")
+        ldy = (N + 3) // 4 * 4
+        y = torch.empty((M, ldy), dtype=torch.float32, device=dev)
+        acts, n_acts = H.act_ranges(None, N)
+        H.check(lib.swr_affine_act_fwd(H.ptr(x), x.stride(0) if M > 1 else N, H.ptr(scale), H.ptr(shift), acts, n_acts,
+                                       H.ptr(y), ldy, M, N, H.stream()), "swr_affine_act_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        return y[:, :N] if ldy != N else y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        M, N = x.shape
+        dev = x.device
+        dy = H.f32c(dy)
+        ldx = x.stride(0) if M > 1 else N
+        acts, n_acts = H.act_ranges(None, N)
+        nt = (M + 63) // 64
+        partials = torch.empty((nt, N, 2), dtype=torch.float32, device=dev)
+        H.check(lib.swr_bn_act_bwd_stats(H.ptr(dy), dy.stride(0) if M > 1 else N, H.ptr(x), ldx, H.ptr(x), ldx, H.ptr(mean),
+                                         H.ptr(rstd), acts, n_acts, H.ptr(partials), M, N, H.stream()), "swr_bn_act_bwd_stats")
+        ca, cb, cc = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+        H.check(lib.swr_bn_bwd_finalize(H.ptr(partials), nt, M, N, None, H.ptr(rstd), None, None, 0, H.ptr(ca), H.ptr(cb),
+                                        H.ptr(cc), H.stream()), "swr_bn_bwd_finalize")
+        dx = torch.empty((M, N), dtype=torch.float32, device=dev)
+        H.check(lib.swr_act_bwd_apply(H.ptr(dy), dy.stride(0) if M > 1 else N, H.ptr(x), ldx, H.ptr(x), ldx, H.ptr(ca),
+                                      H.ptr(cb), H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dx), N, M, N, H.stream()),
+                "swr_act_bwd_apply")
+        return dx, None
+
+
+def batch_standardize(x, eps):
+    return BatchStandardize.apply(x, eps)
+
+
 class MatmulIO(Function):
     """y = x @ W + b with W stored [in, out] -- STAR's factorised FCN layer (star.py:103-107)."""
 
