@@ -1,6 +1,8 @@
 // Gate mixing, domain select, BCE and small elementwise helpers.
 // All kernels are streaming passes over [M, *] fp32 row-major data (HBM-bound); every reduction that
 // crosses workgroups goes through per-block partials summed in a fixed order (deterministic).
+#include <algorithm>
+
 #include "common.h"
 
 #define EW_THREADS 256
@@ -532,6 +534,87 @@ extern "C" int swr_select_bce_bwd(const float* p, const void* y, int y_dtype, in
     SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
     hipLaunchKernelGGL(select_bce_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M * D, EW_THREADS))), dim3(EW_THREADS), 0,
                        static_cast<hipStream_t>(stream), p, y, y_dtype, D, domain, dom_dtype, M, dloss, dV, lddv);
+    return swr_launch_status();
+}
+
+// ------------------------------------------------------------------ per-sample row-vector x matrix product
+// out[b, d, :] = T[b, d, :] @ Hm[b]  with a k x k matrix PER SAMPLE: the middle factor of HAMUR's adapter weights
+// W_b = U H_b V applied as ((h U) H_b) V (hamur.py:175-186 materialises U H_b V per sample instead).  HBM-bound on
+// the k*k floats of H_b per sample.  One wave per sample: H_b and the D rows staged in LDS, lane j owns column j.
+#define RM_WAVES 4
+__global__ __launch_bounds__(RM_WAVES * 64) void rowmat_fwd_kernel(const float* __restrict__ T, const float* __restrict__ Hm,
+                                                                   float* __restrict__ out, int64_t B, int D, int k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* h = lds + wave * (k * k + D * k);
+    float* t = h + k * k;
+    for (int64_t b = static_cast<int64_t>(blockIdx.x) * RM_WAVES + wave; b < B; b += static_cast<int64_t>(gridDim.x) * RM_WAVES) {
+        for (int q = lane; q < k * k; q += 64) h[q] = Hm[b * k * k + q];
+        for (int q = lane; q < D * k; q += 64) t[q] = T[b * D * k + q];
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < k; j += 64)
+            for (int d = 0; d < D; ++d) {
+                float acc = 0.f;
+                for (int i = 0; i < k; ++i) acc = fmaf(t[d * k + i], h[i * k + j], acc);
+                out[b * D * k + d * k + j] = acc;
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// dT[b, d, i] = sum_j dOut[b, d, j] Hm[b, i, j];   dHm[b, i, j] = sum_d T[b, d, i] dOut[b, d, j]
+__global__ __launch_bounds__(RM_WAVES * 64) void rowmat_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ T,
+                                                                   const float* __restrict__ Hm, float* __restrict__ dT,
+                                                                   float* __restrict__ dHm, int64_t B, int D, int k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* h = lds + wave * (k * k + 2 * D * k);
+    float* t = h + k * k;
+    float* g = t + D * k;
+    for (int64_t b = static_cast<int64_t>(blockIdx.x) * RM_WAVES + wave; b < B; b += static_cast<int64_t>(gridDim.x) * RM_WAVES) {
+        for (int q = lane; q < k * k; q += 64) h[q] = Hm[b * k * k + q];
+        for (int q = lane; q < D * k; q += 64) {
+            t[q] = T[b * D * k + q];
+            g[q] = dOut[b * D * k + q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (dT)
+            for (int i = lane; i < k; i += 64)
+                for (int d = 0; d < D; ++d) {
+                    float acc = 0.f;
+                    for (int j = 0; j < k; ++j) acc = fmaf(g[d * k + j], h[i * k + j], acc);
+                    dT[b * D * k + d * k + i] = acc;
+                }
+        if (dHm)
+            for (int j = lane; j < k; j += 64)
+                for (int i = 0; i < k; ++i) {
+                    float acc = 0.f;
+                    for (int d = 0; d < D; ++d) acc = fmaf(t[d * k + i], g[d * k + j], acc);
+                    dHm[b * k * k + i * k + j] = acc;
+                }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int swr_rowmat_fwd(const float* T, const float* Hm, float* out, int64_t B, int D, int k, void* stream) {
+    SWR_REQUIRE(T && Hm && out && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
+    const size_t lds = static_cast<size_t>(RM_WAVES) * (k * k + D * k) * sizeof(float);
+    SWR_REQUIRE(lds <= 64 * 1024, SWR_ERR_UNSUPPORTED);
+    if (B == 0) return SWR_OK;
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 8192));
+    hipLaunchKernelGGL(rowmat_fwd_kernel, dim3(grid), dim3(RM_WAVES * 64), lds, static_cast<hipStream_t>(stream), T, Hm, out, B, D, k);
+    return swr_launch_status();
+}
+
+extern "C" int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm, float* dT, float* dHm, int64_t B, int D,
+                              int k, void* stream) {
+    SWR_REQUIRE(dOut && T && Hm && (dT || dHm) && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
+    const size_t lds = static_cast<size_t>(RM_WAVES) * (k * k + 2 * D * k) * sizeof(float);
+    SWR_REQUIRE(lds <= 64 * 1024, SWR_ERR_UNSUPPORTED);
+    if (B == 0) return SWR_OK;
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 8192));
+    hipLaunchKernelGGL(rowmat_bwd_kernel, dim3(grid), dim3(RM_WAVES * 64), lds, static_cast<hipStream_t>(stream), dOut, T, Hm, dT,
+                       dHm, B, D, k);
     return swr_launch_status();
 }
 

@@ -743,12 +743,13 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
 
 
 class BatchStandardize(Function):
-    """y = (x - mean_batch) / sqrt(var_batch + eps), biased variance, no affine and no running statistics: the shared
-    part of STAR's partitioned normalisation (star.py:91-98).  Statistics by swr_col_moments + swr_bn_finalize, one
-    affine pass; the backward is the BatchNorm backward with gamma = 1 (two passes)."""
+    """y = gamma * (x - mean_batch) / sqrt(var_batch + eps) + beta, biased variance, no running statistics (gamma, beta
+    optional): the shared part of STAR's partitioned normalisation (star.py:91-98) and HAMUR's domain norm
+    (hamur.py:188-196).  Statistics by swr_col_moments + swr_bn_finalize, one affine pass; the backward is the
+    BatchNorm backward (two passes)."""
 
     @staticmethod
-    def forward(ctx, x, eps):
+    def forward(ctx, x, eps, gamma, beta):
         H.require_device(x)
         x = H.f32c(x)
         M, N = x.shape
@@ -759,20 +760,23 @@ class BatchStandardize(Function):
         partials = torch.empty((n_tiles, N, 2), dtype=torch.float32, device=dev)
         H.check(lib.swr_col_moments(H.ptr(x), x.stride(0) if M > 1 else N, M, N, H.ptr(partials), H.stream()), "swr_col_moments")
         mean, rstd, scale, shift = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(4))
-        H.check(lib.swr_bn_finalize(H.ptr(partials), n_tiles, M, N, None, None, float(eps), 0.0, None, None, None, 0,
+        g = H.f32c(gamma).contiguous() if gamma is not None else None
+        b = H.f32c(beta).contiguous() if beta is not None else None
+        H.check(lib.swr_bn_finalize(H.ptr(partials), n_tiles, M, N, H.ptr(g), H.ptr(b), float(eps), 0.0, None, None, None, 0,
                                     H.ptr(mean), H.ptr(rstd), H.ptr(scale), H.ptr(shift), H.stream()), "swr_bn_finalize")
         ldy = (N + 3) // 4 * 4
         y = torch.empty((M, ldy), dtype=torch.float32, device=dev)
         acts, n_acts = H.act_ranges(None, N)
         H.check(lib.swr_affine_act_fwd(H.ptr(x), x.stride(0) if M > 1 else N, H.ptr(scale), H.ptr(shift), acts, n_acts,
                                        H.ptr(y), ldy, M, N, H.stream()), "swr_affine_act_fwd")
-        ctx.save_for_backward(x, mean, rstd)
+        ctx.save_for_backward(x, mean, rstd, g)
+        ctx.has_affine = (gamma is not None, beta is not None)
         return y[:, :N] if ldy != N else y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, mean, rstd = ctx.saved_tensors
+        x, mean, rstd, g = ctx.saved_tensors
         M, N = x.shape
         dev = x.device
         dy = H.f32c(dy)
@@ -783,17 +787,48 @@ class BatchStandardize(Function):
         H.check(lib.swr_bn_act_bwd_stats(H.ptr(dy), dy.stride(0) if M > 1 else N, H.ptr(x), ldx, H.ptr(x), ldx, H.ptr(mean),
                                          H.ptr(rstd), acts, n_acts, H.ptr(partials), M, N, H.stream()), "swr_bn_act_bwd_stats")
         ca, cb, cc = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
-        H.check(lib.swr_bn_bwd_finalize(H.ptr(partials), nt, M, N, None, H.ptr(rstd), None, None, 0, H.ptr(ca), H.ptr(cb),
-                                        H.ptr(cc), H.stream()), "swr_bn_bwd_finalize")
-        dx = torch.empty((M, N), dtype=torch.float32, device=dev)
-        H.check(lib.swr_act_bwd_apply(H.ptr(dy), dy.stride(0) if M > 1 else N, H.ptr(x), ldx, H.ptr(x), ldx, H.ptr(ca),
-                                      H.ptr(cb), H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dx), N, M, N, H.stream()),
-                "swr_act_bwd_apply")
-        return dx, None
+        dgamma = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_affine[0] else None
+        dbeta = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_affine[1] else None
+        H.check(lib.swr_bn_bwd_finalize(H.ptr(partials), nt, M, N, H.ptr(g), H.ptr(rstd), H.ptr(dgamma), H.ptr(dbeta), 0,
+                                        H.ptr(ca), H.ptr(cb), H.ptr(cc), H.stream()), "swr_bn_bwd_finalize")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, N), dtype=torch.float32, device=dev)
+            H.check(lib.swr_act_bwd_apply(H.ptr(dy), dy.stride(0) if M > 1 else N, H.ptr(x), ldx, H.ptr(x), ldx, H.ptr(ca),
+                                          H.ptr(cb), H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dx), N, M, N, H.stream()),
+                    "swr_act_bwd_apply")
+        return dx, None, dgamma, dbeta
 
 
-def batch_standardize(x, eps):
-    return BatchStandardize.apply(x, eps)
+class RowMat(Function):
+    """out[b, d, :] = T[b, d, :] @ Hm[b]: the per-sample k x k factor of HAMUR's adapter (hamur.py:175-186)."""
+
+    @staticmethod
+    def forward(ctx, T, Hm):
+        H.require_device(T, Hm)
+        T, Hm = H.f32c(T).contiguous(), H.f32c(Hm).contiguous()
+        B, D, k = T.shape
+        out = torch.empty_like(T)
+        H.check(lib.swr_rowmat_fwd(H.ptr(T), H.ptr(Hm), H.ptr(out), B, D, k, H.stream()), "swr_rowmat_fwd")
+        ctx.save_for_backward(T, Hm)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        T, Hm = ctx.saved_tensors
+        B, D, k = T.shape
+        dout = H.f32c(dout).contiguous()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[0] else None
+        dHm = torch.empty_like(Hm) if ctx.needs_input_grad[1] else None
+        if dT is not None or dHm is not None:
+            H.check(lib.swr_rowmat_bwd(H.ptr(dout), H.ptr(T), H.ptr(Hm), H.ptr(dT), H.ptr(dHm), B, D, k, H.stream()),
+                    "swr_rowmat_bwd")
+        return dT, dHm
+
+
+def batch_standardize(x, eps, gamma=None, beta=None):
+    return BatchStandardize.apply(x, eps, gamma, beta)
 
 
 class MatmulIO(Function):

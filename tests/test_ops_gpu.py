@@ -474,3 +474,37 @@ def test_bnmix_path_matches_the_layerwise_path(B, ne, Hh, D):
         torch.testing.assert_close(gb[n], ga[n], rtol=2e-4, atol=atol, msg=n)
     for n in ba:
         torch.testing.assert_close(bb[n].float(), ba[n].float(), rtol=1e-5, atol=1e-6, msg=n)
+
+
+def test_rowmat_and_batch_standardize_against_torch():
+    """The two glue-free pieces of HAMUR's adapter / STAR's partitioned norm: per-sample row x matrix products and the
+    whole-batch standardisation (+ affine), forward and every gradient against torch's own autograd in fp64."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    B, D, k = 301, 3, 35
+    T = torch.randn(B, D, k, device="cuda", generator=g, requires_grad=True)
+    Hm = torch.randn(B, k, k, device="cuda", generator=g, requires_grad=True)
+    dO = torch.randn(B, D, k, device="cuda", generator=g)
+    out = ops.RowMat.apply(T, Hm)
+    out.backward(dO)
+    T64, H64 = T.detach().double().requires_grad_(True), Hm.detach().double().requires_grad_(True)
+    ref = torch.einsum("bdi,bij->bdj", T64, H64)
+    ref.backward(dO.double())
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(T.grad.double(), T64.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(Hm.grad.double(), H64.grad, rtol=1e-5, atol=1e-5)
+    M, N = 777, 38
+    x = (torch.randn(M, N, device="cuda", generator=g) * 3 + 1).requires_grad_(True)
+    gam = (torch.rand(N, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    bet = torch.randn(N, device="cuda", generator=g).requires_grad_(True)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    y = ops.batch_standardize(x, 1e-6, gam, bet)
+    y.backward(dy)
+    x64, g64, b64 = (t.detach().double().requires_grad_(True) for t in (x, gam, bet))
+    cen = x64 - x64.mean(0)
+    r = g64 * cen / torch.sqrt((cen * cen).mean(0) + 1e-6) + b64
+    r.backward(dy.double())
+    torch.testing.assert_close(y.double(), r, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad.double(), x64.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(gam.grad.double(), g64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bet.grad.double(), b64.grad, rtol=1e-4, atol=1e-4)
