@@ -164,7 +164,46 @@ SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measur
 SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "1"))   # measured: 1 (fork at once) 0.862 ms, 3 0.866, 2 0.94 (event nodes stall the branch)
 SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "0"))    # measured: forking the small (tower) products costs more
                                                                         # in cross-stream edges than the overlap returns
-_side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0}
+_side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
+         "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
+         "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
+         "epoch": 0}
+
+
+def add_side_job(fn):
+    """Run `fn()` on the side stream inside the next forward-time fork (EmbedGather.forward); `run_side_jobs()` runs
+    whatever is still pending on the current stream."""
+    _side["jobs"].append(fn)
+
+
+def run_side_jobs():
+    jobs, _side["jobs"] = _side["jobs"], []
+    for fn in jobs:
+        fn()
+
+
+def _fork_extras():
+    """Inside the forward-time fork, on the side stream: pending one-shot jobs and the transposed copies of the weights
+    whose dX product wants W^T (registered by the previous step's backward): launches that would otherwise sit on
+    the critical path of the backward pass."""
+    _side["epoch"] += 1
+    run_side_jobs()
+    for ent in _side["wt"].values():
+        ent["buf"].copy_(ent["src"].t())
+        ent["epoch"] = _side["epoch"]
+
+
+def _transposed_weight(W):
+    """W^T (contiguous) for the dX product: the copy made by this step's forward-time fork when there is one."""
+    key = (W.data_ptr(), W.shape[0], W.shape[1])
+    ent = _side["wt"].get(key)
+    if ent is not None and ent["epoch"] == _side["epoch"] and SIDE_STREAM:
+        join_side_streams()
+        return ent["buf"]
+    Wt = W.t().contiguous()
+    if SIDE_STREAM and len(_side["wt"]) < 64:
+        _side["wt"][key] = {"src": W.detach(), "buf": torch.empty_like(Wt), "epoch": -1}
+    return Wt
 
 
 def _side_stream(dev):
@@ -314,6 +353,7 @@ class EmbedGather(Function):
                     box["ws"] = torch.empty(box["nbytes"], dtype=torch.uint8, device=dev)
                     H.check(lib.swr_embed_bwd_sort(proto, n, H.ptr(keys), B, H.ptr(box["ws"]), box["nbytes"], H.stream()),
                             "swr_embed_bwd_sort")
+                    _fork_extras()
                 _defer_side(dev, sort_now)
                 ctx.presorted = box
         return out[:, :plan.width] if plan.width != plan.ld else out
@@ -577,7 +617,7 @@ class LinearBNAct(Function):
                     if ctx.planes_t is not None:
                         gemm("nt", dZ, W, dx, M, K, Ntot, ldb=Ntot, B_split=ctx.planes_t)    # W^T only through its planes
                     else:
-                        gemm("nt", dZ, W.t().contiguous(), dx, M, K, Ntot)
+                        gemm("nt", dZ, _transposed_weight(W), dx, M, K, Ntot)
                 else:
                     gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:

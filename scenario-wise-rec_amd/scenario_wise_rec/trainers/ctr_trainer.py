@@ -58,6 +58,9 @@ class CTRTrainer(object):
     # ---- one optimisation step (`ctr_trainer.py:67-73`) ---------------------------------------------
     def forward_backward(self, x_dict, y):
         """forward -> criterion -> zero_grad -> backward (`ctr_trainer.py:69-72`); returns the loss tensor."""
+        # zero_grad rides the forward pass's side-stream fork (its fill is pure launch latency on the main stream);
+        # if the model forks nothing it runs right after the forward, where the reference has it
+        ops.add_side_job(self.model.zero_grad)
         if isinstance(self.criterion, BCELoss):
             # the model's final domain select and the criterion in one launch when the model output IS the selected
             # probabilities (every multi-domain model here); otherwise the criterion runs the ordinary way
@@ -69,7 +72,7 @@ class CTRTrainer(object):
         else:
             y_pred = self.model(x_dict)
             loss = self.criterion(y_pred, y)
-        self.model.zero_grad()
+        ops.run_side_jobs()          # zero_grad, unless the fork already ran it
         ops.join_side_streams()      # work forked during the forward pass (embedding sort, W^T copies): joined here,
         loss.backward(gradient=self._one(loss))     # where the main stream still has the whole backward queued behind
         return loss
