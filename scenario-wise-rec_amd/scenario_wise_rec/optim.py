@@ -21,6 +21,7 @@ from ._hip import lib
 
 
 HIST_CAP = 1 << 20          # steps of (step_size, inv_bc2_sqrt) history kept on the device (8 MB)
+_EARLY_ADVANCED = set()     # hyper buffers whose step counter was advanced ahead of step() (advance_early)
 
 
 class LazyRows(object):
@@ -38,6 +39,9 @@ class LazyRows(object):
 
     def catchup(self, idx, hash_seed=0):
         """Replay the pending decay-only updates of the rows `idx` refers to (ids, any integer dtype; -1 = skip)."""
+        if self.hyper.data_ptr() in _EARLY_ADVANCED:
+            raise H.SwrError("a lookup of a lazily updated table after FusedAdam.advance_early(): the step counter already "
+                             "counts the coming update (use advance_early only with one lookup per step)")
         idx = idx.contiguous()
         n = idx.numel()
         ws = torch.empty(max(n, 1) * 8, dtype=torch.uint8, device=idx.device)
@@ -102,6 +106,24 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
+    def advance_early(self):
+        """Advance the step counter / bias corrections NOW (a 1-thread launch) so that `step()` need not: the trainer runs
+        this on the side stream during the forward pass, after the forward's own catch-up of the rows it reads.  Only
+        with one parameter group whose device scalars exist (i.e. from the second step on); `step()` notices."""
+        if len(self.param_groups) != 1 or 0 not in self._hyper or getattr(self, "_advanced", False):
+            return
+        ent = self._hyper[0]
+        if self.lazy_rows and ent[3] + 2 >= HIST_CAP:
+            return
+        hyper = self._hyper_dev(0, self.param_groups[0], ent[0].device)
+        hist = ent[2]
+        H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, H.stream()),
+                "swr_adam_advance")
+        ent[3] += 1
+        self._advanced = True
+        _EARLY_ADVANCED.add(hyper.data_ptr())
+
+    @torch.no_grad()
     def materialize(self):
         """Bring every lazily updated table fully up to date (exact); cheap no-op when nothing is pending."""
         for st in self._big.values():
@@ -140,9 +162,13 @@ class FusedAdam(torch.optim.Optimizer):
                         self._lazy_state(p, hist, hyper)       # (state must exist before the row kernel)
                 if ent[3] + 2 >= HIST_CAP:
                     raise H.SwrError("FusedAdam: step history full; call materialize() and rebuild the optimizer")
-            H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, stream),
-                    "swr_adam_advance")
-            ent[3] += 1
+            if gi == 0 and getattr(self, "_advanced", False):
+                self._advanced = False                         # advance_early() already did it for this step
+                _EARLY_ADVANCED.discard(hyper.data_ptr())
+            else:
+                H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, stream),
+                        "swr_adam_advance")
+                ent[3] += 1
             # contiguous runs: parameter, gradient and state addresses all advance together
             items = []
             for p in dense:

@@ -78,6 +78,8 @@ class CTRTrainer(object):
         return loss
 
     def train_step(self, x_dict, y):
+        if hasattr(self.optimizer, "advance_early") and os.environ.get("SWR_EARLY_ADVANCE", "1") != "0":
+            ops.add_side_job(self.optimizer.advance_early)      # the step-counter launch leaves the critical path too
         loss = self.forward_backward(x_dict, y)
         self.optimizer.step()
         return loss
