@@ -280,6 +280,27 @@ __device__ __forceinline__ Bf3 split3(float x) {
         L[idx] = s3_.l;                    \
     } while (0)
 
+// Two values at a time: v_cvt_pk_bf16_f32 rounds both, v_pk_add_f32 takes both remainders -- 4.5 VALU per value instead
+// of 7 (the split is the VALU work that sits in front of every MFMA group); bit-identical to split3().
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef SWR_SPLIT_SCALAR
+#define SPLIT3_PAIR(x0, x1, H, M, L, idx) do { SPLIT3_INTO(x0, H, M, L, idx); SPLIT3_INTO(x1, H, M, L, (idx) + 1); } while (0)
+#else
+#define SPLIT3_PAIR(x0, x1, H, M, L, idx)                                   \
+    do {                                                                    \
+        const f32x2 sx_ = {x0, x1};                                         \
+        const bf16x2 sh_ = __builtin_convertvector(sx_, bf16x2);            \
+        const f32x2 s1_ = sx_ - __builtin_convertvector(sh_, f32x2);        \
+        const bf16x2 sm_ = __builtin_convertvector(s1_, bf16x2);            \
+        const f32x2 s2_ = s1_ - __builtin_convertvector(sm_, f32x2);        \
+        const bf16x2 sl_ = __builtin_convertvector(s2_, bf16x2);            \
+        H[idx] = sh_[0]; H[(idx) + 1] = sh_[1];                             \
+        M[idx] = sm_[0]; M[(idx) + 1] = sm_[1];                             \
+        L[idx] = sl_[0]; L[(idx) + 1] = sl_[1];                             \
+    } while (0)
+#endif
+
 template <int NT, bool PRO, bool PS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD
     constexpr int NCOL = NT * 32;
@@ -353,10 +374,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
                     h = stage_p[PS ? u : 0][0]; m = stage_p[PS ? u : 0][1]; l = stage_p[PS ? u : 0][2];
                 } else {
                     const float4 sv = mask4(stage[PS ? 0 : u], kc + kq);
-                    SPLIT3_INTO(sv.x, h, m, l, 0);
-                    SPLIT3_INTO(sv.y, h, m, l, 1);
-                    SPLIT3_INTO(sv.z, h, m, l, 2);
-                    SPLIT3_INTO(sv.w, h, m, l, 3);
+                    SPLIT3_PAIR(sv.x, sv.y, h, m, l, 0);
+                    SPLIT3_PAIR(sv.z, sv.w, h, m, l, 2);
                 }
                 __bf16* d = Bx + buf * (3 * PLANE) + n * X6_PITCH + kq;
                 *reinterpret_cast<bf16x4*>(d) = h;
@@ -406,10 +425,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             float4 av[2];
             a_use(c * (X6_KC / 16) + gq, ar[gq + HALF * (DEPTH / 2)], av);
             bf16x8 ah, am, al;
-            SPLIT3_INTO(av[0].x, ah, am, al, 0); SPLIT3_INTO(av[0].y, ah, am, al, 1);
-            SPLIT3_INTO(av[0].z, ah, am, al, 2); SPLIT3_INTO(av[0].w, ah, am, al, 3);
-            SPLIT3_INTO(av[1].x, ah, am, al, 4); SPLIT3_INTO(av[1].y, ah, am, al, 5);
-            SPLIT3_INTO(av[1].z, ah, am, al, 6); SPLIT3_INTO(av[1].w, ah, am, al, 7);
+            SPLIT3_PAIR(av[0].x, av[0].y, ah, am, al, 0); SPLIT3_PAIR(av[0].z, av[0].w, ah, am, al, 2);
+            SPLIT3_PAIR(av[1].x, av[1].y, ah, am, al, 4); SPLIT3_PAIR(av[1].z, av[1].w, ah, am, al, 6);
             bf16x8 b0[3], b1[3];
             b_read(b0, gq, 0, DB ? HALF : 0);
 #pragma unroll
@@ -591,10 +608,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = (n < N && k + c < K) ? W[static_cast<int64_t>(n) * ldw + k + c] : 0.f;
     bf16x4 h, m, l;
-    SPLIT3_INTO(v[0], h, m, l, 0);
-    SPLIT3_INTO(v[1], h, m, l, 1);
-    SPLIT3_INTO(v[2], h, m, l, 2);
-    SPLIT3_INTO(v[3], h, m, l, 3);
+    SPLIT3_PAIR(v[0], v[1], h, m, l, 0);
+    SPLIT3_PAIR(v[2], v[3], h, m, l, 2);
     if (P && n < N) {
         __bf16* d = P + static_cast<int64_t>(n) * ld + k;
         *reinterpret_cast<bf16x4*>(d) = h;
@@ -970,11 +985,13 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
         bf16x8 h0, m0_, l0, h1, m1, l1;
         if (col_ok && left >= 8) {                                                       // (almost always)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                SPLIT3_INTO(raw[r].x, h0, m0_, l0, r);
-                SPLIT3_INTO(raw[r].y, h1, m1, l1, r);
+            for (int r = 0; r < 8; r += 2) {
+                SPLIT3_PAIR(raw[r].x, raw[r + 1].x, h0, m0_, l0, r);
+                SPLIT3_PAIR(raw[r].y, raw[r + 1].y, h1, m1, l1, r);
                 cs0 += raw[r].x;
                 cs1 += raw[r].y;
+                cs0 += raw[r + 1].x;
+                cs1 += raw[r + 1].y;
             }
         } else {
 #pragma unroll

@@ -10,7 +10,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libswr.so")
+# SWR_LIB: another build of the same library (A/B timing of two kernel variants inside one process image)
+_LIB_PATH = os.environ.get("SWR_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libswr.so")
 
 
 class SwrError(RuntimeError):
