@@ -162,9 +162,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # SWR_BENCH_FORCE_DP=1: take the N > 1 code path (process group, exchange step, two graphs) with world size 1 --
+    # the RCCL call sequence of the multi-GPU run, checkable on a one-GPU box
+    use_dp = world > 1 or bool(os.environ.get("SWR_BENCH_FORCE_DP"))
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -184,7 +188,7 @@ def main():
     x = {k: torch.from_numpy(v).to(dev) for k, v in xh.items()}
     y = torch.from_numpy(yh).to(dev)
 
-    if world > 1:
+    if use_dp:
         from scenario_wise_rec.parallel import DataParallelStep
         stepper = DataParallelStep(trainer, world)
         step_fn = lambda: stepper.train_step(x, y)
@@ -197,7 +201,7 @@ def main():
     graph = None
     if not args.no_graph:
         try:
-            if world == 1:
+            if not use_dp:
                 from scenario_wise_rec.trainers.graph import GraphedStep
                 graph = GraphedStep(trainer, x, y, warmup=args.warmup)
             else:
@@ -343,4 +347,9 @@ def gather_roofline(cfg, model, x, dev, iters):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

@@ -104,7 +104,10 @@ int swr_embed_gather_fwd(const swr_sparse_slot* sparse_host, int n_sparse,
  *   mode 2 (dense+): the table's gradient is ADDED to grad_dense (gradient arena fan-in);
  *   mode 1 (sparse): for large tables; `urow` / `ugrad` have one entry per
  *                    looked-up sample of the table, in sorted-row order:
- *                    urow[i] = row (first entry of each distinct row) or -1,
+ *                    urow[i] = row (first entry of each distinct row), otherwise the
+ *                    bitwise complement of the row the entry belongs to (negative: "no
+ *                    entry here"; consumers skip every negative id, and the list stays
+ *                    binary-searchable by row -- swr_dp_finish relies on that),
  *                    ugrad[i, :] = summed gradient of that row (or 0).
  * Sparse-mode tables must have the largest table ids. */
 typedef struct {
@@ -428,6 +431,31 @@ int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last, int32_t* 
                           void* workspace, size_t workspace_bytes, void* stream);
 int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t vocab, int dim,
                    const float* hist, const swr_adam_hyper* hyper_dev, void* stream);
+
+/* ------------------------------------------------------------ exchange ----
+ * Device side of the data-parallel exchange step: what torch.nn.DataParallel's gradient reduction
+ * does for the reference (trainers/ctr_trainer.py:45-47 -- replica gradients summed in device order), after ONE
+ * all-gather has put every rank's message [gradient arena (A words) | per large table: row ids (n int32), row
+ * gradients (n x dim)] side by side in `recv` ([world][total] fp32 words).  One launch:
+ *   dense_out[j]   = scale * sum_r recv[r][j], j < A, ranks added in order 0..world-1;
+ *   per large table: the `world` row lists (each in swr_embed_bwd's mode-1 format: ordered by row, negative = no
+ *   entry) are merged WITHOUT a sort: every entry looks its row up in the other ranks' lists (binary searches); the
+ *   lowest rank holding the row owns it and writes row id + scale * (sum of the holders' gradients in rank order) to
+ *   its own position of out_row / out_grad ([world * n] entries); all other positions get -1 / 0.
+ * Every rank computes bit-identical results from the same gathered buffer.  world <= SWR_DP_MAX_WORLD. */
+#define SWR_DP_MAX_WORLD 8
+#define SWR_DP_MAX_TABLES 16
+typedef struct {
+    int64_t row_off;       /* word offset of the row ids inside one rank's message */
+    int64_t grad_off;      /* word offset of the gradients */
+    int64_t n;             /* entries per rank */
+    int32_t dim;
+    int32_t pad;
+    int32_t* out_row;      /* [world * n] */
+    float* out_grad;       /* [world * n, dim] */
+} swr_dp_table;
+int swr_dp_finish(const float* recv, int world, int64_t total, int64_t A, float* dense_out,
+                  const swr_dp_table* tables_host, int n_tables, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(RB_THREADS) void finalize_kernel(const BwdMeta m, c
     const uint32_t key = ck[i];
     const bool head = (i == t.sorted_off) || (ck[i - 1] != key);
     const int64_t local = i - t.sorted_off;
-    if (e == 0) t.urow[local] = head ? static_cast<int32_t>(key) : -1;
+    if (e == 0) t.urow[local] = head ? static_cast<int32_t>(key) : ~static_cast<int32_t>(key);   // negative = no entry; still ordered by row
     const int64_t a = ACC_STRIPES * dense_acc_elems + (i - m.sparse_start) * m.dim_max + e;
     t.ugrad[local * t.dim + e] = head ? from_fixed(acc_hi[a], acc_lo[a]) : 0.f;
 }

@@ -112,6 +112,11 @@ class TowerArgs(C.Structure):
                 ("dZ1", C.c_void_p), ("lddz", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64)]
 
 
+class DpTable(C.Structure):
+    _fields_ = [("row_off", C.c_int64), ("grad_off", C.c_int64), ("n", C.c_int64), ("dim", C.c_int32), ("pad", C.c_int32),
+                ("out_row", C.c_void_p), ("out_grad", C.c_void_p)]
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("step", C.c_int64), ("step_size", C.c_float),
@@ -171,6 +176,7 @@ _SIGS = {
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    "swr_dp_finish": (C.c_int, [_P, _I, _L, _L, _P, _P, _I, _F, _P]),
 }
 EXPORTS = tuple(_SIGS)
 for _name, (_res, _args) in _SIGS.items():

@@ -51,7 +51,7 @@ def exchange_layout(dense_grad, sparse_grads):
         n, dim = ugrad.shape
         offs.append((pos, pos + n, n, dim, vocab))
         pos += n + n * dim
-    return A, offs, pos
+    return A, offs, (pos + 3) // 4 * 4          # whole 16-byte units: every rank's message starts aligned in `recv`
 
 
 def communicate(dense_grad, sparse_grads, world_size, group=None, buffers=None):
@@ -83,6 +83,8 @@ def finish(dense_grad, gathered, world_size, merge_rows=hip_merge_rows):
     """Device-side remainder of the exchange: the arenas of all ranks are summed in rank order and averaged, the
     gathered row entries are merged deterministically (every rank computes bit-identical results)."""
     recv, A, offs, total = gathered
+    if recv.is_cuda and merge_rows is hip_merge_rows and world_size <= 8 and len(offs) <= 16:
+        return _hip_finish(dense_grad, recv, A, offs, total, world_size)
     R = recv.view(world_size, total)
     if A:
         dense_grad.reshape(-1).copy_(R[:, :A].sum(dim=0))
@@ -93,6 +95,26 @@ def finish(dense_grad, gathered, world_size, merge_rows=hip_merge_rows):
         grads = R[:, r1:r1 + n * dim].reshape(world_size * n, dim)
         r, g = merge_rows(rows, grads.contiguous(), vocab)
         merged.append((r, g.mul_(1.0 / world_size)))
+    return merged
+
+
+def _hip_finish(dense_grad, recv, A, offs, total, world_size):
+    """`finish` as ONE launch (swr_dp_finish, csrc/exchange.hip): rank-ordered mean of the gradient arenas and the
+    sort-free merge of the large tables' row lists."""
+    from . import _hip as H
+    from ._hip import lib
+    tabs = (H.DpTable * max(1, len(offs)))()
+    merged = []
+    for t, (r0, r1, n, dim, _vocab) in enumerate(offs):
+        out_row = torch.empty(world_size * n, dtype=torch.int32, device=recv.device)
+        out_grad = torch.empty((world_size * n, dim), dtype=torch.float32, device=recv.device)
+        tabs[t] = H.DpTable(r0, r1, n, dim, 0, out_row.data_ptr(), out_grad.data_ptr())
+        merged.append((out_row, out_grad))
+    dense = dense_grad.reshape(-1) if A else None
+    if A and dense.data_ptr() != dense_grad.data_ptr():
+        raise H.SwrError("exchange: the gradient arena must be contiguous")
+    H.check(lib.swr_dp_finish(H.ptr(recv), world_size, total, A, H.ptr(dense) if A else None, tabs, len(offs),
+                              1.0 / world_size, H.stream()), "swr_dp_finish")
     return merged
 
 

@@ -508,3 +508,58 @@ def test_rowmat_and_batch_standardize_against_torch():
     torch.testing.assert_close(x.grad.double(), x64.grad, rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(gam.grad.double(), g64.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(bet.grad.double(), b64.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("world,n,dim,vocab,A", [(1, 300, 16, 50, 1000), (2, 1000, 16, 400, 4099), (8, 513, 8, 200, 0),
+                                                   (4, 2048, 64, 100000, 37), (3, 64, 16, 5, 8)])
+def test_dp_finish_merges_rank_lists_like_a_sort(world, n, dim, vocab, A):
+    """The exchange step's device half (swr_dp_finish): rank-ordered mean of the gradient arenas (bit-exact against
+    the same fp32 additions in numpy) and the sort-free merge of the ranks' row lists: every distinct row listed
+    once, by the lowest rank that holds it, with the holders' gradients added in rank order (bit-exact)."""
+    from scenario_wise_rec import parallel
+    rng = np.random.default_rng(world * 1000 + n)
+    msgs, lists = [], []
+    for r in range(world):
+        # a rank's list in swr_embed_bwd's mode-1 format: n looked-up rows in row order, first of a run = the row id
+        # (with the run's summed gradient), the others = ~row (zero gradient)
+        ids = np.sort(rng.integers(0, vocab, size=n)).astype(np.int32)
+        head = np.ones(n, bool)
+        head[1:] = ids[1:] != ids[:-1]
+        urow = np.where(head, ids, ~ids).astype(np.int32)
+        ugrad = (rng.standard_normal((n, dim)) * head[:, None]).astype(np.float32)
+        dense = rng.standard_normal(A).astype(np.float32)
+        lists.append((urow, ugrad))
+        msgs.append((dense, urow, ugrad))
+    total = (A + n + n * dim + 3) // 4 * 4
+    recv = np.zeros((world, total), np.float32)
+    for r, (dense, urow, ugrad) in enumerate(msgs):
+        recv[r, :A] = dense
+        recv[r, A:A + n] = urow.view(np.float32)
+        recv[r, A + n:A + n + n * dim] = ugrad.reshape(-1)
+    dense_out = torch.zeros(max(A, 1), device="cuda")
+    merged = parallel.finish(dense_out[:A] if A else None, (_dev(recv).reshape(-1), A, [(A, A + n, n, dim, vocab)], total), world)
+    scale = np.float32(1.0 / world)
+    if A:
+        want = msgs[0][0].copy()
+        for r in range(1, world):
+            want = want + msgs[r][0]
+        np.testing.assert_array_equal(dense_out[:A].cpu().numpy(), want * scale)
+    out_row, out_grad = (t.cpu().numpy() for t in merged[0])
+    assert out_row.shape == (world * n,) and out_grad.shape == (world * n, dim)
+    want_sum = {}
+    owner = {}
+    for r, (urow, ugrad) in enumerate(lists):
+        for i in np.nonzero(urow >= 0)[0]:
+            k = int(urow[i])
+            if k in want_sum:
+                want_sum[k] = want_sum[k] + ugrad[i]
+            else:
+                want_sum[k] = ugrad[i].copy()
+                owner[k] = r * n + i
+    listed = np.nonzero(out_row >= 0)[0]
+    assert sorted(out_row[listed].tolist()) == sorted(want_sum)            # every distinct row exactly once
+    for pos in listed:
+        k = int(out_row[pos])
+        assert owner[k] == pos
+        np.testing.assert_array_equal(out_grad[pos], want_sum[k] * scale)
+    assert np.all(out_grad[out_row < 0] == 0)
