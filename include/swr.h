@@ -132,12 +132,19 @@ int swr_embed_bwd(const swr_embed_grad_slot* slots_host, int n_slots,
  *   swr_embed_bwd_sort   : output pointers of the slots may be null; leaves the sorted entries in `workspace`;
  *   swr_embed_bwd_reduce : same arguments as swr_embed_bwd, same `workspace` (ordered after the sort by the caller).
  * swr_embed_bwd == sort followed by reduce on one stream.  Small dense tables never enter the sort (they are summed
- * in LDS per workgroup), whichever entry point is used. */
+ * in LDS per workgroup), whichever entry point is used.
+ *   swr_embed_bwd_reduce_part : the reduce in two pieces again, for the data-parallel step, which sends the large
+ *   tables' row lists to the other ranks while the rest still computes -- `part` 1: the sorted entries are reduced and
+ *   the mode-1 (urow, ugrad) lists written; 2 (after 1): the small tables' direct sums and every dense gradient;
+ *   3 = swr_embed_bwd_reduce. */
 int swr_embed_bwd_sort(const swr_embed_grad_slot* slots_host, int n_slots, const uint32_t* keys, int64_t B,
                        void* workspace, size_t workspace_bytes, void* stream);
 int swr_embed_bwd_reduce(const swr_embed_grad_slot* slots_host, int n_slots, const uint32_t* keys,
                          const float* dE, int64_t ld, int64_t B,
                          void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream);
+int swr_embed_bwd_reduce_part(const swr_embed_grad_slot* slots_host, int n_slots, const uint32_t* keys,
+                              const float* dE, int64_t ld, int64_t B, int part,
+                              void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream);
 
 /* ------------------------------------------------------------------ K2 ----
  * fp32 matrix products on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact
@@ -434,15 +441,19 @@ int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t vocab, i
 
 /* ------------------------------------------------------------ exchange ----
  * Device side of the data-parallel exchange step: what torch.nn.DataParallel's gradient reduction
- * does for the reference (trainers/ctr_trainer.py:45-47 -- replica gradients summed in device order), after ONE
- * all-gather has put every rank's message [gradient arena (A words) | per large table: row ids (n int32), row
- * gradients (n x dim)] side by side in `recv` ([world][total] fp32 words).  One launch:
- *   dense_out[j]   = scale * sum_r recv[r][j], j < A, ranks added in order 0..world-1;
+ * does for the reference (trainers/ctr_trainer.py:45-47 -- replica gradients summed in device order), after the
+ * all-gather(s) have put every rank's message side by side.  Two gathered buffers (they may be one and the same):
+ *   recv_dense [world][dense_stride] fp32 words -- the gradient arena (A words) at the start of each rank's message;
+ *   recv_rows  [world][rows_stride]  fp32 words -- per large table the row ids (n int32) and row gradients (n x dim)
+ *                                                  at `row_off` / `grad_off` of each rank's message.
+ * One launch:
+ *   dense_out[j]   = scale * sum_r recv_dense[r][j], j < A, ranks added in order 0..world-1;
  *   per large table: the `world` row lists (each in swr_embed_bwd's mode-1 format: ordered by row, negative = no
  *   entry) are merged WITHOUT a sort: every entry looks its row up in the other ranks' lists (binary searches); the
  *   lowest rank holding the row owns it and writes row id + scale * (sum of the holders' gradients in rank order) to
  *   its own position of out_row / out_grad ([world * n] entries); all other positions get -1 / 0.
- * Every rank computes bit-identical results from the same gathered buffer.  world <= SWR_DP_MAX_WORLD. */
+ * Every rank computes bit-identical results from the same gathered buffers.  world <= SWR_DP_MAX_WORLD; strides are
+ * multiples of 4 words and the buffers 16-byte aligned. */
 #define SWR_DP_MAX_WORLD 8
 #define SWR_DP_MAX_TABLES 16
 typedef struct {
@@ -454,8 +465,9 @@ typedef struct {
     int32_t* out_row;      /* [world * n] */
     float* out_grad;       /* [world * n, dim] */
 } swr_dp_table;
-int swr_dp_finish(const float* recv, int world, int64_t total, int64_t A, float* dense_out,
-                  const swr_dp_table* tables_host, int n_tables, float scale, void* stream);
+int swr_dp_finish(const float* recv_dense, int64_t dense_stride, int64_t A, float* dense_out,
+                  const float* recv_rows, int64_t rows_stride, const swr_dp_table* tables_host, int n_tables,
+                  int world, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -818,14 +818,15 @@ extern "C" size_t swr_embed_bwd_workspace_bytes(const swr_embed_grad_slot* slots
     return p.total;
 }
 
-// phases: 1 = build keys + sort (needs only the lookup keys), 2 = direct + reduce + finalise (needs dE), 3 = both
+// phases (bits): 1 = build keys + sort (needs only the lookup keys); 2 = reduce of the sorted entries + the sparse
+// tables' row lists; 4 = direct sums of the small tables + every dense gradient (2 and 4 need dE; 4 comes after 2)
 static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
                          int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag, void* stream) {
     SWR_REQUIRE(keys && workspace, SWR_ERR_ARG);
-    SWR_REQUIRE(!(phases & 2) || (dE && ld > 0), SWR_ERR_ARG);
+    SWR_REQUIRE(!(phases & 6) || (dE && ld > 0), SWR_ERR_ARG);
     if (B == 0) return SWR_OK;
     HostPlan p;
-    int rc = make_plan(slots, n_slots, B, p, (phases & 2) != 0);
+    int rc = make_plan(slots, n_slots, B, p, (phases & 6) != 0);
     if (rc != SWR_OK) return rc;
     SWR_REQUIRE(workspace_bytes >= p.total, SWR_ERR_WORKSPACE);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -855,11 +856,11 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
             cur ^= 1;
         }
     }
-    if (!(phases & 2)) return swr_launch_status();
+    if (!(phases & 6)) return swr_launch_status();
     const uint32_t* ck = kbuf[p.n_passes & 1];               // where the last pass left the sorted entries
     const uint32_t* sv = vbuf[p.n_passes & 1];
 
-    if (p.dm.n_blocks > 0) {
+    if ((phases & 4) && p.dm.n_blocks > 0) {
         // LDS sized by the largest group (small groups -> more workgroups per CU); 16-byte loads when every lookup
         // column span is 4-float aligned
         int max_elems = 0;
@@ -874,7 +875,7 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
             hipLaunchKernelGGL(direct_kernel<1>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
                                p.dm, keys, dE, ld, acc_hi, acc_lo, p.dense_acc_elems, err_flag);
     }
-    if (n > 0) {
+    if ((phases & 2) && n > 0) {
         int lpe = 1;
         while (lpe < m.dim_max && lpe < 64) lpe <<= 1;
         const dim3 grid(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(p.n_chunks), RB_THREADS / lpe)));
@@ -893,7 +894,7 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
 #undef LAUNCH_REDUCE
     }
     int gx = 0, dense_blocks = 0;
-    if (p.dense_acc_elems > 0) {
+    if ((phases & 4) && p.dense_acc_elems > 0) {
         int64_t biggest = 1;
         for (int t = 0; t < m.n_tables; ++t)
             if (m.tab[t].mode != 1 && m.tab[t].vocab * m.tab[t].dim > biggest) biggest = m.tab[t].vocab * m.tab[t].dim;
@@ -901,7 +902,7 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         dense_blocks = gx * m.n_tables;
     }
     int64_t sparse_blocks = 0;
-    if (m.sparse_start < n) sparse_blocks = swr_ceil_div((n - m.sparse_start) * m.dim_max, RB_THREADS);
+    if ((phases & 2) && m.sparse_start < n) sparse_blocks = swr_ceil_div((n - m.sparse_start) * m.dim_max, RB_THREADS);
     if (dense_blocks + sparse_blocks > 0)
         hipLaunchKernelGGL(finalize_kernel, dim3(static_cast<unsigned>(dense_blocks + sparse_blocks)), dim3(RB_THREADS), 0, st,
                            m, ck, reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo),
@@ -912,7 +913,7 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
 extern "C" int swr_embed_bwd(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
                              int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag,
                              void* stream) {
-    return run_embed_bwd(3, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
+    return run_embed_bwd(7, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
 }
 
 extern "C" int swr_embed_bwd_sort(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, int64_t B,
@@ -923,5 +924,12 @@ extern "C" int swr_embed_bwd_sort(const swr_embed_grad_slot* slots, int n_slots,
 extern "C" int swr_embed_bwd_reduce(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
                                     int64_t ld, int64_t B, void* workspace, size_t workspace_bytes, uint32_t* err_flag,
                                     void* stream) {
-    return run_embed_bwd(2, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
+    return run_embed_bwd(6, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
+}
+
+extern "C" int swr_embed_bwd_reduce_part(const swr_embed_grad_slot* slots, int n_slots, const uint32_t* keys, const float* dE,
+                                         int64_t ld, int64_t B, int part, void* workspace, size_t workspace_bytes,
+                                         uint32_t* err_flag, void* stream) {
+    SWR_REQUIRE(part >= 1 && part <= 3, SWR_ERR_ARG);
+    return run_embed_bwd(part << 1, slots, n_slots, keys, dE, ld, B, workspace, workspace_bytes, err_flag, stream);
 }

@@ -12,9 +12,10 @@
 #define DPF_THREADS 256
 
 struct DpK {
-    const float* recv;
+    const float* recv_d;
+    const float* recv;                       // the row lists' buffer
     int world;
-    int64_t total, A;
+    int64_t dstride, total, A;
     float* dense_out;
     float scale;
     int n_tables;
@@ -32,16 +33,16 @@ __global__ __launch_bounds__(DPF_THREADS) void dp_finish_kernel(const DpK k) {
         const int64_t j = (static_cast<int64_t>(blockIdx.x) * DPF_THREADS + tid) * 4;
         if (j >= k.A) return;
         if (j + 4 <= k.A) {
-            float4 s = *reinterpret_cast<const float4*>(k.recv + j);
+            float4 s = *reinterpret_cast<const float4*>(k.recv_d + j);
             for (int r = 1; r < k.world; ++r) {
-                const float4 v = *reinterpret_cast<const float4*>(k.recv + r * k.total + j);
+                const float4 v = *reinterpret_cast<const float4*>(k.recv_d + r * k.dstride + j);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             *reinterpret_cast<float4*>(k.dense_out + j) = make_float4(s.x * k.scale, s.y * k.scale, s.z * k.scale, s.w * k.scale);
         } else {
             for (int64_t q = j; q < k.A; ++q) {
-                float s = k.recv[q];
-                for (int r = 1; r < k.world; ++r) s += k.recv[r * k.total + q];
+                float s = k.recv_d[q];
+                for (int r = 1; r < k.world; ++r) s += k.recv_d[r * k.dstride + q];
                 k.dense_out[q] = s * k.scale;
             }
         }
@@ -123,21 +124,25 @@ __global__ __launch_bounds__(DPF_THREADS) void dp_finish_kernel(const DpK k) {
     }
 }
 
-extern "C" int swr_dp_finish(const float* recv, int world, int64_t total, int64_t A, float* dense_out,
-                             const swr_dp_table* tables, int n_tables, float scale, void* stream) {
-    SWR_REQUIRE(recv && world >= 1 && world <= SWR_DP_MAX_WORLD && total > 0 && A >= 0 && A <= total, SWR_ERR_ARG);
-    SWR_REQUIRE(n_tables >= 0 && n_tables <= SWR_DP_MAX_TABLES && (n_tables == 0 || tables), SWR_ERR_ARG);
-    SWR_REQUIRE(A == 0 || dense_out, SWR_ERR_ARG);
-    SWR_REQUIRE(total % 4 == 0 && swr_aligned16(recv) && (A == 0 || swr_aligned16(dense_out)), SWR_ERR_ALIGN);
+extern "C" int swr_dp_finish(const float* recv_dense, int64_t dense_stride, int64_t A, float* dense_out,
+                             const float* recv_rows, int64_t rows_stride, const swr_dp_table* tables, int n_tables,
+                             int world, float scale, void* stream) {
+    SWR_REQUIRE(world >= 1 && world <= SWR_DP_MAX_WORLD && A >= 0, SWR_ERR_ARG);
+    SWR_REQUIRE(n_tables >= 0 && n_tables <= SWR_DP_MAX_TABLES && (n_tables == 0 || (tables && recv_rows && rows_stride > 0)),
+                SWR_ERR_ARG);
+    SWR_REQUIRE(A == 0 || (dense_out && recv_dense && dense_stride >= A), SWR_ERR_ARG);
+    SWR_REQUIRE(A == 0 || (dense_stride % 4 == 0 && swr_aligned16(recv_dense) && swr_aligned16(dense_out)), SWR_ERR_ALIGN);
+    const int64_t total = rows_stride;
     DpK k;
-    k.recv = recv; k.world = world; k.total = total; k.A = A; k.dense_out = dense_out; k.scale = scale;
+    k.recv_d = recv_dense; k.recv = recv_rows; k.world = world; k.dstride = dense_stride; k.total = total; k.A = A;
+    k.dense_out = dense_out; k.scale = scale;
     k.n_tables = n_tables;
     k.dense_blocks = static_cast<int>(swr_ceil_div(A, DPF_THREADS * 4));
     int64_t blocks = 0;
     for (int t = 0; t < n_tables; ++t) {
         const swr_dp_table& T = tables[t];
-        SWR_REQUIRE(T.n >= 0 && T.dim > 0 && T.out_row && T.out_grad && T.row_off >= A && T.row_off + T.n <= total &&
-                    T.grad_off >= A && T.grad_off + T.n * T.dim <= total && T.n * world < (1ll << 31), SWR_ERR_ARG);
+        SWR_REQUIRE(T.n >= 0 && T.dim > 0 && T.out_row && T.out_grad && T.row_off >= 0 && T.row_off + T.n <= total &&
+                    T.grad_off >= 0 && T.grad_off + T.n * T.dim <= total && T.n * world < (1ll << 31), SWR_ERR_ARG);
         k.tab[t] = T;
         k.block0[t] = static_cast<int>(blocks);
         blocks += swr_ceil_div(T.n * world, DPF_THREADS);

@@ -135,6 +135,7 @@ _SIGS = {
     "swr_embed_bwd": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
     "swr_embed_bwd_sort": (C.c_int, [_P, _I, _P, _L, _P, _Z, _P]),
     "swr_embed_bwd_reduce": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
+    "swr_embed_bwd_reduce_part": (C.c_int, [_P, _I, _P, _P, _L, _L, _I, _P, _Z, _P, _P]),
     "swr_gemm_nt": (C.c_int, [_P, _P]),
     "swr_gemm_nn": (C.c_int, [_P, _P]),
     "swr_split_ld": (C.c_int64, [_L]),
@@ -176,7 +177,7 @@ _SIGS = {
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
-    "swr_dp_finish": (C.c_int, [_P, _I, _L, _L, _P, _P, _I, _F, _P]),
+    "swr_dp_finish": (C.c_int, [_P, _L, _L, _P, _P, _L, _P, _I, _I, _F, _P]),
 }
 EXPORTS = tuple(_SIGS)
 for _name, (_res, _args) in _SIGS.items():

@@ -275,6 +275,23 @@ def _on_side_stream(dev, fn, keep):
         torch.autograd.Variable._execution_engine.queue_callback(_join_side)
 
 
+# ---- split backward (data-parallel step): work whose results only the optimizer needs -- the weight-gradient products
+# and the small tables' gradients -- is held back until `run_late_jobs()`, so that the large tables' row lists are
+# ready (and on their way to the other ranks) as early as possible and the held-back work overlaps the all-gather.
+_late = {"on": False, "jobs": []}
+
+
+def split_backward(on):
+    """Set by parallel.DataParallelStep around its forward+backward; whoever sets it must call run_late_jobs()."""
+    _late["on"] = bool(on)
+
+
+def run_late_jobs():
+    jobs, _late["jobs"] = _late["jobs"], []
+    for fn in jobs:
+        fn()
+
+
 def _split_like(flat, tensors):
     """Slices of `flat` (first-dim concatenation) shaped like each of `tensors`."""
     out, off = [], 0
@@ -309,6 +326,9 @@ class EmbedGather(Function):
         # plan.sparse: list of (weight_pos, idx tensor, vocab, dim, out_col, hash_seed); plan.dense: (values, out_col)
         dev = weights[0].device if weights else plan.dense[0][0].device
         B = (plan.sparse[0][1] if plan.sparse else plan.dense[0][0]).shape[0]
+        if _late["jobs"]:
+            raise H.SwrError("a forward pass with held-back gradient work of the previous backward pending "
+                             "(split backward: run_late_jobs() was not called)")
         # slots whose table takes a gradient first: the backward reduces exactly that prefix
         plan.sparse = sorted(plan.sparse, key=lambda s: not weights[s[0]].requires_grad)
         ctx.n_grad_slots = sum(1 for s in plan.sparse if weights[s[0]].requires_grad)
@@ -403,8 +423,17 @@ class EmbedGather(Function):
         if ctx.presorted is not None and ctx.presorted["nbytes"] == nbytes:
             join_side_streams()                                       # the sort forked in forward() (no-op if joined)
             ws = ctx.presorted["ws"]
-            H.check(lib.swr_embed_bwd_reduce(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
-                                             H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce")
+            all_direct = all(g is None or isinstance(g, tuple) for g in grads)      # dense gradients go to the arena
+            if _late["on"] and sparse_out and all_direct:
+                # split backward: the row lists of the large tables now, everything else when the caller says so
+                def reduce_part(part, slots=slots, keys=ctx.keys, dE=dE, ws=ws):
+                    H.check(lib.swr_embed_bwd_reduce_part(slots, ns, H.ptr(keys), H.ptr(dE), dE.stride(0), B, part, H.ptr(ws),
+                                                          nbytes, H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce_part")
+                reduce_part(1)
+                _late["jobs"].append(lambda: reduce_part(2))
+            else:
+                H.check(lib.swr_embed_bwd_reduce(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
+                                                 H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce")
         else:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             H.check(lib.swr_embed_bwd(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
@@ -600,7 +629,10 @@ class LinearBNAct(Function):
             gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
                     gsC=N * K, gsColsum=N, ldc=K)
         side_dw = direct_w and SIDE_STREAM and (SIDE_DW or 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP)
-        if not side_dw:
+        late_dw = direct_w and _late["on"] and ctx.needs_input_grad[1] and not side_dw
+        if late_dw:
+            _late["jobs"].append(launch_dw)       # split backward: dX first, this product after the row lists are out
+        elif not side_dw:
             launch_dw()
         dx = None
         if ctx.needs_input_grad[1]:

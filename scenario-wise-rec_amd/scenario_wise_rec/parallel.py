@@ -6,13 +6,15 @@ RCCL over xGMI).  Replaces the reference's single-process `torch.nn.DataParallel
   * BatchNorm statistics are per shard (no SyncBN); rank 0's running statistics are the model's;
   * the loss is the mean over the GLOBAL batch: every rank back-propagates its local mean loss and the
     gradients are averaged (equal shards), which equals the sum of the reference's per-replica gradients;
-  * one exchange step per training step, two collectives:
-      1. dense: ONE all-reduce of the flat gradient arena (all non-table parameters and all small tables;
-         0.5 MB at the KuaiRand config -- latency-bound, so a single call, not one per tensor);
-      2. sparse: for each large table, all-gather of the per-rank row-reduced entries (row id, summed
-         gradient), then the same deterministic segmented reduction as the local backward over the
-         gathered entries -- every rank computes bit-identical row gradients, so replicas never drift
-         (there is no parameter broadcast after step 0).
+  * one exchange step per training step, two all-gathers (xGMI is point-to-point; the per-rank messages are
+    small, so gathering everything and reducing locally beats an all-reduce tree):
+      1. rows: per large table the rank's row-reduced entries (row id, summed gradient) -- sent as soon as the
+         backward has produced them, in flight while the weight-gradient products still compute;
+      2. dense: the flat gradient arena (all non-table parameters and all small tables; 0.5 MB at the KuaiRand
+         config -- latency-bound, so a single call, not one per tensor);
+    then ONE launch (swr_dp_finish) adds the arenas in rank order and merges the row lists without a sort; every
+    rank computes bit-identical gradients from the same gathered bytes, so replicas never drift (there is no
+    parameter broadcast after step 0).
   * the optimizer runs replicated.
 """
 import ctypes as C
@@ -113,8 +115,8 @@ def _hip_finish(dense_grad, recv, A, offs, total, world_size):
     dense = dense_grad.reshape(-1) if A else None
     if A and dense.data_ptr() != dense_grad.data_ptr():
         raise H.SwrError("exchange: the gradient arena must be contiguous")
-    H.check(lib.swr_dp_finish(H.ptr(recv), world_size, total, A, H.ptr(dense) if A else None, tabs, len(offs),
-                              1.0 / world_size, H.stream()), "swr_dp_finish")
+    H.check(lib.swr_dp_finish(H.ptr(recv), total, A, H.ptr(dense) if A else None, H.ptr(recv), total, tabs, len(offs),
+                              world_size, 1.0 / world_size, H.stream()), "swr_dp_finish")
     return merged
 
 
@@ -128,9 +130,14 @@ def exchange_gradients(dense_grad, sparse_grads, world_size, group=None, merge_r
 class DataParallelStep(object):
     """`CTRTrainer.train_step` with the gradient exchange between backward and the optimizer step.
 
-    `train_step` launches everything eagerly.  `capture(x, y)` records the step as TWO hipGraphs -- forward +
-    backward, and merge + optimizer -- with the RCCL collectives issued eagerly in between (3 calls at the
-    KuaiRand config), so a replayed step costs two graph launches and the collectives instead of ~60 launches."""
+    The backward pass is split (ops.split_backward): the large tables' row lists are produced first and leave for
+    the other ranks at once (an asynchronous all-gather on RCCL's stream); the weight-gradient products and the small
+    tables' gradients -- results only the optimizer needs -- are computed WHILE that all-gather is in flight; a second,
+    small all-gather carries the gradient arena; one launch (swr_dp_finish) averages and merges.
+
+    `train_step` launches everything eagerly.  `capture(x, y)` records the step as THREE hipGraphs (forward + backward
+    up to the row lists | held-back gradient work | arena mean + optimizer) with the two collectives and the row merge
+    issued eagerly in between, so a replayed step costs three graph launches and two collectives instead of ~60 launches."""
 
     def __init__(self, trainer, world_size=None, group=None):
         self.trainer = trainer
@@ -146,12 +153,101 @@ class DataParallelStep(object):
 
     # ---- pieces ---------------------------------------------------------------------------------------
     def _forward_backward(self, x_dict, y):
-        return self.trainer.forward_backward(x_dict, y).detach()
+        """Forward + the part of the backward that ends with the large tables' row lists; the rest waits in
+        ops.run_late_jobs()."""
+        model = self.trainer.model
+        ops.split_backward(hasattr(model, "arena") and model.arena() is not None)
+        try:
+            return self.trainer.forward_backward(x_dict, y).detach()
+        finally:
+            ops.split_backward(False)
 
     def _sparse(self):
         arena = self.trainer.model.arena()
         big = [p for p in arena["big"] if getattr(p, "_swr_sparse_grad", None) is not None]
         return arena, big, [(p._swr_sparse_grad[0], p._swr_sparse_grad[1], p.shape[0]) for p in big]
+
+    def _exchange_buffers(self, dense, big, sparse):
+        """Static send / receive buffers of the two messages: rows = per large table [row ids | row gradients], and
+        dense = the gradient arena.  The large tables' backward is pointed at its slots of the rows message
+        (`_swr_sparse_out`, read by ops.EmbedGather.backward) so that from the next step on nothing is copied but the
+        0.5 MB gradient arena."""
+        if self.world_size > 8 or len(sparse) > 16:
+            raise ops.H.SwrError("DataParallelStep: at most 8 ranks and 16 row-sparse tables")
+        A = dense.numel()
+        offs, pos = [], 0
+        for urow, ugrad, vocab in sparse:
+            n, dim = ugrad.shape
+            offs.append((pos, pos + n, n, dim, vocab))
+            pos += n + n * dim
+        total, A4 = (pos + 3) // 4 * 4, (A + 3) // 4 * 4
+        key = (A, tuple(offs))
+        if getattr(self, "_xb_key", None) != key:
+            self._xb_key = key
+            dev, W = dense.device, self.world_size
+            f32 = dict(dtype=torch.float32, device=dev)
+            # the arena itself is the dense message when its length keeps every rank's copy 16-byte aligned in `recv_d`
+            self._xb = {"A": A, "A4": A4, "offs": offs, "total": total, "in_place": A > 0 and A % 4 == 0 and dense.is_contiguous(),
+                        "send_d": torch.zeros(max(A4, 4), **f32), "recv_d": torch.empty(W * max(A4, 4), **f32),      # A4 == A when in place
+                        "send_r": torch.zeros(max(total, 4), **f32), "recv_r": torch.empty(W * max(total, 4), **f32)}
+            send = self._xb["send_r"]
+            for p, (r0, r1, n, dim, _v) in zip(big, offs):
+                p._swr_sparse_out = (send[r0:r1].view(torch.int32), send[r1:r1 + n * dim].view(n, dim))
+            # merged row lists (static: the captured optimizer step reads them)
+            H = ops.H
+            tabs = (H.DpTable * max(1, len(offs)))()
+            merged = []
+            for t, (r0, r1, n, dim, _vocab) in enumerate(offs):
+                out_row = torch.empty(W * n, dtype=torch.int32, device=dev)
+                out_grad = torch.empty((W * n, dim), **f32)
+                tabs[t] = H.DpTable(r0, r1, n, dim, 0, out_row.data_ptr(), out_grad.data_ptr())
+                merged.append((out_row, out_grad))
+            self._xb["tabs"], self._xb["merged"] = tabs, merged
+        return self._xb
+
+    def _send_rows(self, xb, sparse):
+        """Start the all-gather of the row lists (asynchronous: it runs on RCCL's stream, ordered after everything
+        enqueued so far); returns the work handle, or None without large tables."""
+        if not xb["offs"]:
+            return None
+        send = xb["send_r"]
+        base = send.data_ptr()
+        for (r0, r1, n, dim, _v), (urow, ugrad, _vocab) in zip(xb["offs"], sparse):
+            if urow.data_ptr() != base + 4 * r0:                             # first step only: not yet written in place
+                send[r0:r1].copy_(urow.contiguous().view(torch.float32))    # bit copy of the int32 ids
+            if ugrad.data_ptr() != base + 4 * r1:
+                send[r1:r1 + n * dim].copy_(ugrad.reshape(-1))
+        return dist.all_gather_into_tensor(xb["recv_r"], send, group=self.group, async_op=True)
+
+    def _send_dense(self, xb, dense, pack):
+        """All-gather of the gradient arena (sent in place when its length allows; else through a packed copy, made
+        here when `pack`, or by the captured graph)."""
+        if xb["in_place"]:
+            dist.all_gather_into_tensor(xb["recv_d"], dense.reshape(-1), group=self.group)
+            return
+        if pack:
+            xb["send_d"][:xb["A"]].copy_(dense.reshape(-1))
+        dist.all_gather_into_tensor(xb["recv_d"], xb["send_d"], group=self.group)
+
+    def _merge_rows(self, xb, big):
+        """swr_dp_finish, row lists only (needs just the first all-gather); hands the merged lists to the optimizer."""
+        H, W = ops.H, self.world_size
+        if xb["offs"]:
+            H.check(H.lib.swr_dp_finish(None, 0, 0, None, H.ptr(xb["recv_r"]), max(xb["total"], 4), xb["tabs"],
+                                        len(xb["offs"]), W, 1.0 / W, H.stream()), "swr_dp_finish(rows)")
+        for p, rg in zip(big, xb["merged"]):
+            p._swr_sparse_grad = rg
+            p._swr_sparse_local = False      # rows other ranks touched are in the list too
+
+    def _mean_dense(self, xb, dense):
+        """swr_dp_finish, gradient arenas only: rank-ordered mean, written back into the arena."""
+        H, W = ops.H, self.world_size
+        flat = dense.reshape(-1)
+        if flat.data_ptr() != dense.data_ptr():
+            raise H.SwrError("exchange: the gradient arena must be contiguous")
+        if xb["A"]:
+            H.check(H.lib.swr_dp_finish(H.ptr(xb["recv_d"]), max(xb["A4"], 4), xb["A"], H.ptr(flat), None, 0, None, 0,
+                                        W, 1.0 / W, H.stream()), "swr_dp_finish(dense)")
 
     def train_step(self, x_dict, y):
         tr = self.trainer
@@ -160,38 +256,27 @@ class DataParallelStep(object):
         arena = model.arena() if hasattr(model, "arena") else None
         if arena is None:
             # no arena (foreign module): per-tensor exchange
+            ops.run_late_jobs()
             for p in model.parameters():
                 if p.grad is not None:
                     dist.all_reduce(p.grad, group=self.group)
                     p.grad.mul_(1.0 / self.world_size)
         else:
             arena, big, sparse = self._sparse()
-            bufs = self._exchange_buffers(arena["g"], big, sparse)
-            merged = finish(arena["g"], communicate(arena["g"], sparse, self.world_size, self.group, bufs), self.world_size)
-            for p, rg in zip(big, merged):
-                p._swr_sparse_grad = rg
-                p._swr_sparse_local = False      # rows other ranks touched are in the list too
+            xb = self._exchange_buffers(arena["g"], big, sparse)
+            work = self._send_rows(xb, sparse)
+            ops.run_late_jobs()                                   # overlaps the row lists' all-gather
+            self._send_dense(xb, arena["g"], pack=True)
+            if work is not None:
+                work.wait()
+            self._merge_rows(xb, big)
+            self._mean_dense(xb, arena["g"])
         tr.optimizer.step()
         return loss
 
-    def _exchange_buffers(self, dense, big, sparse):
-        """(send, recv) for the current message layout; the large tables' backward is pointed at its slots of `send`
-        (`_swr_sparse_out`, read by ops.EmbedGather.backward) so that from the next step on nothing is copied but the
-        0.5 MB gradient arena."""
-        A, offs, total = exchange_layout(dense, sparse)
-        key = (A, tuple(offs))
-        if getattr(self, "_xb_key", None) != key:
-            self._xb_key = key
-            self._xb = (torch.empty(total, dtype=torch.float32, device=dense.device),
-                        torch.empty(self.world_size * total, dtype=torch.float32, device=dense.device))
-            send = self._xb[0]
-            for p, (r0, r1, n, dim, _v) in zip(big, offs):
-                p._swr_sparse_out = (send[r0:r1].view(torch.int32), send[r1:r1 + n * dim].view(n, dim))
-        return self._xb
-
     # ---- captured variant -----------------------------------------------------------------------------
     def capture(self, x_dict, y, warmup=2):
-        """Static input buffers + two captured graphs.  Feed batches with `load`, run with `replay`."""
+        """Static input buffers + three captured graphs.  Feed batches with `load`, run with `replay`."""
         self.x = {k: v.clone() for k, v in x_dict.items()}
         self.y = y.clone()
         side = torch.cuda.Stream()
@@ -208,21 +293,26 @@ class DataParallelStep(object):
             loss = self._forward_backward(self.x, self.y)
             ops.join_side_streams()
             arena, big, sparse = self._sparse()
-            buffers = self._exchange_buffers(arena["g"], big, sparse)          # established by the warm-up steps
-            A, offs, total = exchange_layout(arena["g"], sparse)
-            if A:
-                buffers[0][:A].copy_(arena["g"].reshape(-1))                   # the only packing copy, inside graph 1
-        for (urow, ugrad, _v), (r0, r1, n, dim, _v2) in zip(sparse, offs):
-            assert urow.data_ptr() == buffers[0].data_ptr() + 4 * r0 and ugrad.data_ptr() == buffers[0].data_ptr() + 4 * r1
-        gathered = (buffers[1], A, offs, total)
+            xb = self._exchange_buffers(arena["g"], big, sparse)                # established by the warm-up steps
+        base = xb["send_r"].data_ptr()
+        for (urow, ugrad, _v), (r0, r1, n, dim, _v2) in zip(sparse, xb["offs"]):
+            assert urow.data_ptr() == base + 4 * r0 and ugrad.data_ptr() == base + 4 * r1      # written in place
+        g1b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1b, pool=g1.pool(), capture_error_mode="thread_local"):
+            ops.run_late_jobs()
+            ops.join_side_streams()
+            if not xb["in_place"]:
+                xb["send_d"][:xb["A"]].copy_(arena["g"].reshape(-1))           # the only packing copy
         g2 = torch.cuda.CUDAGraph()
+        for p, rg in zip(big, xb["merged"]):          # (the merge itself is launched eagerly, on the side stream, in replay)
+            p._swr_sparse_grad = rg
+            p._swr_sparse_local = False
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
-            merged = finish(arena["g"], gathered, self.world_size)
-            for p, rg in zip(big, merged):
-                p._swr_sparse_grad = rg
-                p._swr_sparse_local = False
+            self._mean_dense(xb, arena["g"])
             self.trainer.optimizer.step()
-        self._graphs = (g1, g2, buffers)
+        self._graphs = (g1, g1b, g2, xb)
+        self._big, self._arena_g = big, arena["g"]
+        self._merge_stream = torch.cuda.Stream()
         self.loss = loss
         return self
 
@@ -232,8 +322,21 @@ class DataParallelStep(object):
         self.y.copy_(y, non_blocking=True)
 
     def replay(self):
-        g1, g2, (send, recv) = self._graphs
+        g1, g1b, g2, xb = self._graphs
+        cur = torch.cuda.current_stream()
         g1.replay()
-        dist.all_gather_into_tensor(recv, send, group=self.group)       # the step's one collective
+        rows = bool(xb["offs"])
+        if rows:                                                                # the row lists leave now ...
+            work = dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group, async_op=True)
+            self._merge_stream.wait_stream(cur)                                 # (after the previous step's readers)
+        g1b.replay()                                                            # ... while the rest of the gradients is computed
+        if rows:
+            # the merge needs only the first all-gather: its own stream, so it too hides behind the gradient products
+            with torch.cuda.stream(self._merge_stream):
+                work.wait()
+                self._merge_rows(xb, self._big)
+        self._send_dense(xb, self._arena_g, pack=False)
+        if rows:
+            cur.wait_stream(self._merge_stream)
         g2.replay()
         return self.loss
