@@ -739,6 +739,10 @@ struct TnK {
     float* part;              // [groups][splits][K1][K2]
     float* part_cs;           // [groups][splits][K1]  (colsum) or null
     unsigned qblk, pblk, n_tiles;   // column tiles, row-tile groups, qblk * pblk * zsplit * groups
+    // x6 kernel with a ragged last column tile (K2 = 128 j + r, r <= 32): the tile is not a column block of its own;
+    // block b of a batch split takes it on the stages with stage % qblk == b and writes its partial sums to replica b
+    // (columns tail_q0 + 32 b .. of a partial row of pitch k2p); tn_reduce_kernel adds the replicas.  0 = no tail.
+    int tail_q0, tail_rep, k2p;
 };
 
 template <int TA>
@@ -921,9 +925,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const TnK kk) 
 #define TX_THREADS 512
 #define TX_DEPTH 3                      // stages in flight in registers
 
-template <int PT>
+template <int PT, bool TAIL>
 __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
-    constexpr int ACOLS = PT * 32, COLS = ACOLS + TX_QCOLS;
+    constexpr int ACOLS = PT * 32, COLS = ACOLS + TX_QCOLS + (TAIL ? 32 : 0);    // slab: A | 128 columns of B | tail tile
     constexpr int UNITS = 2 * (COLS / 2);                              // (row oct, column pair)
     constexpr int PA = (PT + 1) / 2;                                   // p-tiles of the first wave group
     constexpr int PLANE = COLS * TX_PM, BUF = 3 * PLANE;               // bf16 elements
@@ -938,7 +942,8 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     const unsigned per_xcd = gridDim.x / 8;
     const unsigned lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (lin >= kk.n_tiles) return;
-    const int q0 = static_cast<int>(lin % kk.qblk) * TX_QCOLS;
+    const int qb = static_cast<int>(lin % kk.qblk);
+    const int q0 = qb * TX_QCOLS;
     const int split = static_cast<int>(lin / kk.qblk);
     const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
     const int64_t me = min(ms + kk.rows_per_split, a.M);
@@ -948,6 +953,13 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     for (int t = 0; t < PA; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // tail tile x p-tiles (wave - 4) and (wave - 4) + 4, waves 4-7 only (the wave group with the smaller share)
+    constexpr int TT = TAIL ? (PT > 4 ? 2 : 1) : 1;
+    f32x16 acc_tail[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_tail[t][r] = 0.f;
 
     // this thread's staging unit: row oct `ro` (rows 8 ro .. 8 ro + 7 of the stage), column pair `cp` of the slab
     // the staging units go to waves 4-7 first (they own the smaller half of the p-tiles: their split work overlaps the
@@ -957,7 +969,8 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     const int ro = uid & 1, cp = unit_on ? (uid >> 1) : 0;
     const int scol = 2 * cp;                                           // slab column (A columns, then the 128 B columns)
     const bool isA = scol < ACOLS;
-    const int gcol = isA ? scol : q0 + (scol - ACOLS);
+    const bool isT = TAIL && scol >= ACOLS + TX_QCOLS;
+    const int gcol = isA ? scol : (isT ? kk.tail_q0 + (scol - ACOLS - TX_QCOLS) : q0 + (scol - ACOLS));
     const bool col_ok = unit_on && (isA ? gcol < a.K1 : gcol < a.K2);  // K1, K2 even
     const float* __restrict__ src = (isA ? a.A : a.B) + (col_ok ? gcol : 0);
     const int64_t ld = isA ? a.lda : a.ldb;
@@ -980,10 +993,10 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     };
     const int rows_total = static_cast<int>(me - ms);
     auto stage_store = [&](int stage, const float2 (&raw)[8], __bf16* buf) {
-        if (!unit_on) return;
+        if (!col_ok) return;                      // columns past the matrix were zeroed once (prologue)
         const int left = rows_total - stage * TX_ROWS - 8 * ro;                          // valid rows of this unit
         bf16x8 h0, m0_, l0, h1, m1, l1;
-        if (col_ok && left >= 8) {                                                       // (almost always)
+        if (left >= 8) {                                                                 // (almost always)
 #pragma unroll
             for (int r = 0; r < 8; r += 2) {
                 SPLIT3_PAIR(raw[r].x, raw[r + 1].x, h0, m0_, l0, r);
@@ -996,7 +1009,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const bool ok = col_ok && r < left;
+                const bool ok = r < left;
                 const float vx = ok ? raw[r].x : 0.f, vy = ok ? raw[r].y : 0.f;
                 SPLIT3_INTO(vx, h0, m0_, l0, r);
                 SPLIT3_INTO(vy, h1, m1, l1, r);
@@ -1022,6 +1035,19 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     // prologue: stages 0 .. DEPTH-1 in flight, stage 0 into buffer 0, then stage DEPTH takes its slot
 #pragma unroll
     for (int d = 0; d < TX_DEPTH; ++d) stage_load(d, st[d]);           // beyond the end: zeros (never used)
+    if (unit_on && !col_ok) {                                          // slab columns past the matrix: zero in both buffers, once
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = static_cast<__bf16>(0.f);
+#pragma unroll
+        for (int bsel = 0; bsel < 2; ++bsel)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                __bf16* d = Lx + bsel * BUF + pl * PLANE + scol * TX_PM + 8 * ro;
+                *reinterpret_cast<bf16x8*>(d) = z;
+                *reinterpret_cast<bf16x8*>(d + TX_PM) = z;
+            }
+    }
     stage_store(0, st[0], Lx);
     stage_load(TX_DEPTH, st[0]);
     __syncthreads();
@@ -1049,6 +1075,25 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
                 acc[t] = c_;
             }
         }
+        if (TAIL && wave >= 4 && (sg % static_cast<int>(kk.qblk)) == qb) {       // this block's turn at the tail tile
+            bf16x8 tb[3], ta[3];
+            frag(tb, buf, ACOLS + TX_QCOLS);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int pt_ = (wave - 4) + 4 * t;
+                if (pt_ < PT) {
+                    frag(ta, buf, 32 * pt_);
+                    f32x16 c_ = acc_tail[t];
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[2], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[1], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[0], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[1], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[0], c_, 0, 0, 0);
+                    acc_tail[t] = c_;
+                }
+            }
+        }
         if (sg + 1 < n_stages) stage_store(sg + 1, st[NEXT], Lx + ((sg + 1) & 1) * BUF);
         stage_load(sg + 1 + TX_DEPTH, st[NEXT]);
         __syncthreads();
@@ -1062,16 +1107,32 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     if (sg < n_stages) { step(sg, std::integral_constant<int, 0>{}); ++sg; }
     if (sg < n_stages) { step(sg, std::integral_constant<int, 1>{}); ++sg; }
 
-    // partial tile of this batch split -> workspace [split][K1][K2]
-    float* __restrict__ P = kk.part + static_cast<int64_t>(split) * a.K1 * a.K2;
+    // partial tile of this batch split -> workspace [split][K1][k2p]
+    const int k2p = kk.k2p;
+    float* __restrict__ P = kk.part + static_cast<int64_t>(split) * a.K1 * k2p;
     const int q = q0 + 32 * qt + i;
+    const int q_end = TAIL ? kk.tail_q0 : a.K2;
 #pragma unroll
     for (int t = 0; t < PA; ++t) {
         if (t < p_count) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = 32 * (p_first + t) + (r & 3) + 8 * (r >> 2) + 4 * s;
-                if (p < a.K1 && q < a.K2) P[static_cast<int64_t>(p) * a.K2 + q] = acc[t][r];
+                if (p < a.K1 && q < q_end) P[static_cast<int64_t>(p) * k2p + q] = acc[t][r];
+            }
+        }
+    }
+    if (TAIL && wave >= 4) {                                           // replica qb of the tail tile's partial sums
+        const int qtl = kk.tail_q0 + 32 * qb + i;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int pt_ = (wave - 4) + 4 * t;
+            if (pt_ < PT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * pt_ + (r & 3) + 8 * (r >> 2) + 4 * s;
+                    if (p < a.K1 && kk.tail_q0 + i < a.K2) P[static_cast<int64_t>(p) * k2p + qtl] = acc_tail[t][r];
+                }
             }
         }
     }
@@ -1094,6 +1155,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
     const swr_gemm_tn_args& a = kk.a;
     const int g = blockIdx.y;
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
+    const int64_t np = static_cast<int64_t>(a.K1) * kk.k2p;           // elements of one partial matrix (pitch k2p >= K2)
     const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int64_t j = tid / L;
     const int sub = static_cast<int>(tid % L);
@@ -1110,7 +1172,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
         return sum;
     };
     float sum = 0.f;
-    if (j < n) sum = lane_sum(kk.part + static_cast<int64_t>(g) * nparts * n + j, n);
+    if (j < n) {
+        const int64_t r = j / a.K2, c = j - r * a.K2;
+        const float* __restrict__ pj = kk.part + static_cast<int64_t>(g) * nparts * np + r * kk.k2p + c;
+        sum = lane_sum(pj, np);
+        if (kk.tail_rep > 0 && c >= kk.tail_q0)                          // the other replicas of the tail tile, in order
+            for (int b = 1; b < kk.tail_rep; ++b) sum += lane_sum(pj + 32 * b, np);
+    }
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off);
     if (j < n && sub == 0) {
@@ -1151,9 +1219,15 @@ static bool tn_x6_ok(const swr_gemm_tn_args& a) {
            a.ldb % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0 && a.M >= 4096 &&
            a.M * a.lda < (1ll << 31) && a.M * a.ldb < (1ll << 31);      // 32-bit element offsets inside the kernel
 }
+// ragged last column tile folded into the full 128-column blocks (see TnK): K2 = 128 j + r with j >= 1, 0 < r <= 32
+static bool tn_x6_tail(const swr_gemm_tn_args& a) {
+    static const int off = getenv("SWR_TN_X6_TAIL") ? atoi(getenv("SWR_TN_X6_TAIL")) == 0 : 0;
+    const int r = a.K2 % TX_QCOLS;
+    return !off && a.K2 > TX_QCOLS && r > 0 && r <= 32;
+}
 static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
     static const int blocks_target = getenv("SWR_TN_X6_BLOCKS") ? atoi(getenv("SWR_TN_X6_BLOCKS")) : 256;   // one per CU
-    const int qblk = static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
+    const int qblk = tn_x6_tail(a) ? a.K2 / TX_QCOLS : static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
     int64_t want = std::max<int64_t>(1, blocks_target / qblk);
     want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (8 * TX_ROWS)));
     rps = swr_ceil_div(swr_ceil_div(a.M, want), TX_ROWS) * TX_ROWS;
@@ -1168,7 +1242,9 @@ extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args) {
         tn_x6_plan(*args, splits, rps);
     else
         tn_plan(*args, ta, splits, rps);
-    return static_cast<size_t>(args->groups) * splits * (static_cast<size_t>(args->K1) * args->K2 + args->K1) * 4 + 256;
+    size_t k2p = args->K2;
+    if (tn_x6_ok(*args) && tn_x6_tail(*args)) k2p = static_cast<size_t>(args->K2 / TX_QCOLS) * (TX_QCOLS + 32);
+    return static_cast<size_t>(args->groups) * splits * (static_cast<size_t>(args->K1) * k2p + args->K1) * 4 + 256;
 }
 
 extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1197,24 +1273,30 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         int n_splits;
         tn_x6_plan(a, n_splits, kk.rows_per_split);
         kk.splits = n_splits * GEMM_WAVES;                      // tn_reduce_kernel counts partial tiles as splits / 4
+        const bool tail = tn_x6_tail(a);
+        kk.qblk = tail ? static_cast<unsigned>(a.K2 / TX_QCOLS) : static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
+        kk.tail_q0 = tail ? static_cast<int>(kk.qblk) * TX_QCOLS : 0;
+        kk.tail_rep = tail ? static_cast<int>(kk.qblk) : 0;
+        kk.k2p = tail ? static_cast<int>(kk.qblk) * (TX_QCOLS + 32) : a.K2;
         kk.part = static_cast<float*>(workspace);
-        kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(n_splits) * a.K1 * a.K2 : nullptr;
-        kk.qblk = static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
+        kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(n_splits) * a.K1 * kk.k2p : nullptr;
         kk.pblk = 1;
         kk.n_tiles = kk.qblk * static_cast<unsigned>(n_splits);
         const int pt = static_cast<int>(swr_ceil_div(a.K1, 32));
         const dim3 grid((kk.n_tiles + 7) / 8 * 8);
-        const unsigned lds = static_cast<unsigned>(2 * 3 * (pt * 32 + TX_QCOLS) * TX_PM * sizeof(__bf16));
+        const unsigned lds = static_cast<unsigned>(2 * 3 * (pt * 32 + TX_QCOLS + (tail ? 32 : 0)) * TX_PM * sizeof(__bf16));
         const void* fn = nullptr;
+#define TNX(PTV) (tail ? reinterpret_cast<const void*>(gemm_tn_x6_kernel<PTV, true>) : reinterpret_cast<const void*>(gemm_tn_x6_kernel<PTV, false>))
         switch (pt) {
-            case 1: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<1>); break;
-            case 2: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<2>); break;
-            case 3: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<3>); break;
-            case 4: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<4>); break;
-            default: fn = reinterpret_cast<const void*>(gemm_tn_x6_kernel<5>); break;
+            case 1: fn = TNX(1); break;
+            case 2: fn = TNX(2); break;
+            case 3: fn = TNX(3); break;
+            case 4: fn = TNX(4); break;
+            default: fn = TNX(5); break;
         }
+#undef TNX
         // > 64 KB of dynamic LDS needs the attribute (idempotent, not a stream operation; first call = a warm-up step)
-        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)
             return SWR_ERR_LAUNCH;
         void* kargs[] = {&kk};
         if (hipLaunchKernel(fn, grid, dim3(TX_THREADS), kargs, lds, st) != hipSuccess) return SWR_ERR_LAUNCH;
@@ -1230,6 +1312,8 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
     }
     int ta;
     const int pblk = tn_plan(a, ta, kk.splits, kk.rows_per_split);
+    kk.tail_q0 = kk.tail_rep = 0;
+    kk.k2p = a.K2;
     kk.part = static_cast<float*>(workspace);
     kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(a.groups) * kk.splits * a.K1 * a.K2 : nullptr;
     const int zsplit = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
