@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- train samples/s of the multi-domain CTR hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2] [--no-graph] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1..6] [--no-graph] [--no-cpu-baseline]
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): KuaiRand-shaped 5-domain
 MMoE with 4 experts, embed_dim 16, batch 65 536 per GPU, synthetic device-resident inputs, random-init
@@ -39,10 +39,36 @@ KUAIRAND_VOCABS = [1000, 4371900, 8, 2, 3, 2, 8, 8, 7, 7,
                    3, 8, 200, 300]
 KUAIRAND_DOMAIN_SHARES = [0.207, 0.666, 0.077, 0.035, 0.016]      # README.md:42-46
 
+# Ali-CCP field cardinalities (scripts/run_ali_ccp_ctr_ranking_multi_domain.py:11-34 names the 23 sparse + 8 dense fields;
+# README.md:138: 238 k users, 467 k items; the other sizes are this build's choice, of the public dataset's magnitudes)
+ALICCP_VOCABS = [238635, 98, 14, 3, 8, 4, 4, 3, 5, 467298, 6929, 263942, 106399, 5888, 104830, 51878, 37148, 4,
+                 5853, 105622, 53843, 31858, 3]
+
 CONFIGS = {
+    # the metric's configuration (BASELINE.json configs[1])
     2: dict(name="kuairand_mmoe4_e16_b65536", family="MMOE", vocabs=KUAIRAND_VOCABS, embed_dim=16, n_dense=4,
             batch=65536, domain_shares=KUAIRAND_DOMAIN_SHARES,
             hyper=dict(domain_num=5, n_expert=4, expert_params={"dims": [32]}, tower_params={"dims": [16]})),
+    # the other BASELINE.json configurations, runnable with --config N (not the bench line; configs 3-5 are 8-GPU
+    # configurations: `batch` is the per-GPU shard, global batch / 8)
+    1: dict(name="movielens_sharedbottom_e8_b4096", family="SharedBottom", vocabs=[6040, 3706, 2, 21, 3439, 18],
+            embed_dim=8, n_dense=1, batch=4096, domain_shares=[0.211, 0.395, 0.394],
+            hyper=dict(domain_num=3, bottom_params={"dims": [128]}, tower_params={"dims": [8]})),
+    3: dict(name="aliccp_star_e16_b131072_over8", family="Star", vocabs=ALICCP_VOCABS, embed_dim=16, n_dense=8,
+            batch=131072 // 8, domain_shares=[0.378, 0.0075, 0.615],
+            hyper=dict(num_domains=3, fcn_dims=[256, 128, 64, 32, 16, 8], aux_dims=[16])),
+    4: dict(name="mind_ple_e32_b65536_over8", family="PLE", vocabs=[748000, 20000, 300], embed_dim=32, n_dense=0,
+            batch=65536 // 8, domain_shares=[0.459, 0.198, 0.180, 0.163],
+            hyper=dict(domain_num=4, n_level=1, n_expert_specific=2, n_expert_shared=1,
+                       expert_params={"dims": [64, 32]}, tower_params={"dims": [16]})),
+    5: dict(name="synthetic8_hamursmall_100Mrows_e64_b262144_over8", family="HamurSmall",
+            vocabs=[50_000_000, 50_000_000, 1000, 1000, 100, 10], embed_dim=64, n_dense=4, batch=262144 // 8,
+            domain_shares=[1.0] * 8, on_device_init=True,
+            hyper=dict(domain_num=8, fcn_dims=[256, 128], hyper_dims=[64], k=35)),
+    6: dict(name="synthetic8_ppnet_100Mrows_e64_b262144_over8", family="PPNet",
+            vocabs=[50_000_000, 50_000_000, 1000, 1000, 100, 10, 8], embed_dim=64, n_dense=4, batch=262144 // 8,
+            domain_shares=[1.0] * 8, on_device_init=True, id_features=2,
+            hyper=dict(domain_num=8, fcn_dims=[128, 64, 32])),
 }
 
 
@@ -70,8 +96,12 @@ def build_model(cfg, seed=2024):
     from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
     from scenario_wise_rec.models import multi_domain as md
     torch.manual_seed(seed)
-    feats = [DenseFeature(f"d{i}") for i in range(cfg["n_dense"])] + \
-            [SparseFeature(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
+    dense = [DenseFeature(f"d{i}") for i in range(cfg["n_dense"])]
+    sparse = [SparseFeature(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
+    feats = dense + sparse
+    if cfg["family"] == "PPNet":           # id part (user, item) | scenario-agnostic part (ppnet.py:33)
+        nid = cfg["id_features"]
+        return md.PPNet(sparse[:nid], dense + sparse[nid:], **cfg["hyper"]), feats
     return getattr(md, cfg["family"])(feats, **cfg["hyper"]), feats
 
 
@@ -176,7 +206,11 @@ def main():
 
     from scenario_wise_rec import _hip as H
     from scenario_wise_rec.trainers import CTRTrainer
-    model, feats = build_model(cfg)
+    if cfg.get("on_device_init"):          # 100 M-row tables: initialise in HBM, not through 26 GB of host memory
+        with torch.device(dev):
+            model, feats = build_model(cfg)
+    else:
+        model, feats = build_model(cfg)
     if os.environ.get("SWR_BENCH_FREEZE_TABLES"):          # debugging aid: no embedding backward / table update
         for n_, p_ in model.named_parameters():
             if "embed_dict" in n_:
@@ -249,9 +283,10 @@ def main():
 
     # ---- roofline of the dominant kernel (see DESIGN.md "Measurement") ------------------------------------
     print(f"[bench] timed region done: {ms:.3f} ms/step", file=sys.stderr, flush=True)
-    roof = None if args.no_roofline else measure_roofline(cfg, model, trainer, x, dev, args.steps)
+    roof = None if (args.no_roofline or args.config != 2) else measure_roofline(cfg, model, trainer, x, dev, args.steps)
     out = {
-        "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X",
+        "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X" if args.config == 2
+                  else "train samples/sec, " + cfg["name"],
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -261,7 +296,7 @@ def main():
                    "final_loss": final_loss},
         "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.config == 2:
         out["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(out))
 
@@ -294,7 +329,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters):
     achieved = flops / (ms * 1e-3) / 1e12
     kname = "gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"
     return {"kernel": kname + " (+tn_reduce_kernel)", "bound": "mfma", "achieved": achieved, "peak": peak,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic("void %s<5>" % kname),
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic("void %s<5" % kname),
             "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)",
             "algorithmic_bytes_per_launch": 4.0 * B * (n1 + k0),
             "algorithmic_flops_per_launch": flops, "mfma_dtype": "bf16 (3-way split of fp32 operands, fp32 accumulate)" if x6 else "f32",
@@ -308,7 +343,11 @@ def pmc_traffic(kernel):
     path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
     try:
         with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+            kernels = json.load(f)["kernels"]
+        for name, ent in kernels.items():          # template arguments may follow (`<5, true>`)
+            if name.startswith(kernel):
+                return ent["hbm_bytes_per_launch"]
+        return None
     except (OSError, KeyError, ValueError):
         return None
 
