@@ -439,6 +439,22 @@ int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last, int32_t* 
 int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t vocab, int dim,
                    const float* hist, const swr_adam_hyper* hyper_dev, void* stream);
 
+/* ------------------------------------------------------------- metrics ----
+ * Evaluation metrics on the device: replaces `.tolist()` + sklearn.metrics.log_loss /
+ * roc_auc_score of CTRTrainer.evaluate / evaluate_multi_domain_loss (trainers/ctr_trainer.py:99-165).
+ *   prob [n] fp32 predictions, label [n] (any value dtype; > 0.5 = positive), domain [n] (any index dtype).
+ *   counts [(n_domains + 1) * 3] uint64: per domain d (slot n_domains = ALL rows, whatever their domain id):
+ *       rows, positives, 2U -- U the Mann-Whitney statistic with ties counted 1/2, so AUC = 2U / (2 P N), exactly
+ *       the area sklearn's trapezoid rule gives; integer arithmetic, bitwise reproducible;
+ *   logloss_sum [n_domains + 1] fp64: sum of -(y log p + (1 - y) log(1 - p)), p clipped to [2^-52, 1 - 2^-52]
+ *       (sklearn's clip of a float64 array), summed in a fixed order.
+ * The host divides (and reports None for an empty domain / raises for a single-class one, as the reference's
+ * sklearn calls do).  n < 2^31, n_domains <= 254. */
+size_t swr_eval_metrics_workspace_bytes(int64_t n, int n_domains);
+int swr_eval_metrics(const float* prob, const void* label, int label_dtype, const void* domain, int domain_dtype,
+                     int64_t n, int n_domains, unsigned long long* counts, double* logloss_sum,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------ exchange ----
  * Device side of the data-parallel exchange step: what torch.nn.DataParallel's gradient reduction
  * does for the reference (trainers/ctr_trainer.py:45-47 -- replica gradients summed in device order), after the

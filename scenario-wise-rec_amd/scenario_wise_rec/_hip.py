@@ -177,6 +177,8 @@ _SIGS = {
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    "swr_eval_metrics_workspace_bytes": (_Z, [_L, _I]),
+    "swr_eval_metrics": (C.c_int, [_P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _Z, _P]),
     "swr_dp_finish": (C.c_int, [_P, _L, _L, _P, _P, _L, _P, _I, _I, _F, _P]),
 }
 EXPORTS = tuple(_SIGS)

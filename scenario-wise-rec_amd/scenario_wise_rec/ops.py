@@ -1167,3 +1167,30 @@ class StopGradCols(Function):
         g = g.clone()
         g[:, ctx.span[0]:ctx.span[1]] = 0
         return g, None, None
+
+
+# =========================================================================== evaluation metrics
+def eval_metrics(prob, label, domain, n_domains):
+    """Per-domain and overall log-loss / ROC-AUC ingredients of a prediction run, computed on the device
+    (csrc/metrics.hip) instead of `.tolist()` + sklearn on the host (`trainers/ctr_trainer.py:99-165`).
+    prob [n] fp32, label [n] any value dtype, domain [n] any integer dtype.  Returns four python lists of length
+    n_domains + 1 (last slot = all rows): rows, positives, 2U (integers; AUC = 2U / (2 P N)), log-loss sums (floats)."""
+    H.require_device(prob, label, domain)
+    prob = H.f32c(prob.reshape(-1))
+    label = label.reshape(-1).contiguous()
+    domain = domain.reshape(-1).contiguous()
+    n = prob.numel()
+    if label.numel() != n or domain.numel() != n:
+        raise ValueError("eval_metrics: prob, label and domain must have the same length")
+    D = int(n_domains)
+    nbytes = lib.swr_eval_metrics_workspace_bytes(n, D)
+    if nbytes == 0:
+        raise H.SwrError("swr_eval_metrics: unsupported shape (n < 2^31, 1 <= n_domains <= 254)")
+    dev = prob.device
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    counts = torch.empty((D + 1) * 3, dtype=torch.int64, device=dev)
+    ll = torch.empty(D + 1, dtype=torch.float64, device=dev)
+    H.check(lib.swr_eval_metrics(H.ptr(prob), H.ptr(label), H.dtype_code(label), H.ptr(domain), H.dtype_code(domain), n, D,
+                                 H.ptr(counts), H.ptr(ll), H.ptr(ws), nbytes, H.stream()), "swr_eval_metrics")
+    c = counts.cpu().view(D + 1, 3).tolist()
+    return [r[0] for r in c], [r[1] for r in c], [r[2] for r in c], ll.cpu().tolist()

@@ -143,13 +143,56 @@ class CTRTrainer(object):
         d = torch.cat(ds).cpu().tolist() if with_domain else []
         return t, p, d
 
+    # ---- metrics on the device: no `.tolist()` of the predictions, no host-side sort ------------
+    def _device_metrics_ok(self):
+        return self.device.type == "cuda" and self.evaluate_fn is roc_auc_score and os.environ.get("SWR_DEVICE_METRICS", "1") != "0"
+
+    def _forward_all_device(self, model, data_loader, desc):
+        model.eval()
+        ys, ps, ds = [], [], []
+        with torch.no_grad():
+            for x_dict, y in tqdm.tqdm(data_loader, desc=desc, smoothing=0, mininterval=1.0):
+                x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
+                ps.append(model(x_dict).reshape(-1))
+                ys.append(y.reshape(-1).to(self.device, non_blocking=True))
+                ds.append(x_dict["domain_indicator"].reshape(-1))
+        H.check_errors()
+        if not ps:
+            return None
+        return torch.cat(ps), torch.cat(ys), torch.cat(ds)
+
+    @staticmethod
+    def _metric_pair(rows, pos, two_u, ll_sum):
+        """(logloss, auc) of one group from the device sums, with sklearn's conventions for degenerate groups."""
+        if rows == 0:
+            return None, None
+        neg = rows - pos
+        if pos == 0 or neg == 0:
+            # sklearn.metrics.log_loss cannot infer the two classes from one label (ValueError, as in the reference run)
+            raise ValueError("y_true contains only one label (%s). Please provide the list of all expected class labels "
+                             "explicitly through the labels argument." % (1.0 if pos else 0.0))
+        return ll_sum / rows, two_u / (2.0 * pos * neg)
+
     def evaluate(self, model, data_loader, mode="val"):
+        if self._device_metrics_ok():
+            got = self._forward_all_device(model, data_loader, "validation")
+            if got is not None:
+                rows, pos, two_u, ll = ops.eval_metrics(got[0], got[1], got[2], 1)
+                logloss, auc = self._metric_pair(rows[1], pos[1], two_u[1], ll[1])
+                return auc, logloss
         targets, predicts, _ = self._forward_all(model, data_loader, "validation")
         return self.evaluate_fn(targets, predicts), log_loss(targets, predicts)
 
     def evaluate_multi_domain_loss(self, model, data_loader, domain_num):
         """-> (logloss per domain, auc per domain, total logloss, total auc); None for empty domains
         (`ctr_trainer.py:113-152`)."""
+        if self._device_metrics_ok():
+            got = self._forward_all_device(model, data_loader, "validation")
+            if got is None:
+                return [None] * domain_num, [None] * domain_num, None, None
+            rows, pos, two_u, ll = ops.eval_metrics(got[0], got[1], got[2], domain_num)
+            pairs = [self._metric_pair(rows[d], pos[d], two_u[d], ll[d]) for d in range(domain_num + 1)]
+            return [p[0] for p in pairs[:-1]], [p[1] for p in pairs[:-1]], pairs[-1][0], pairs[-1][1]
         targets, predicts, domains = self._forward_all(model, data_loader, "validation", with_domain=True)
         domain_logloss, domain_auc = [], []
         for d in range(domain_num):

@@ -564,3 +564,65 @@ def test_dp_finish_merges_rank_lists_like_a_sort(world, n, dim, vocab, A):
         assert owner[k] == pos
         np.testing.assert_array_equal(out_grad[pos], want_sum[k] * scale)
     assert np.all(out_grad[out_row < 0] == 0)
+
+
+@pytest.mark.parametrize("n,D,ties,ydt,ddt", [(1000, 5, 50, np.float32, np.int64), (7, 2, 3, np.int64, np.int8),
+                                              (100003, 8, 1000, np.float16, np.int32), (65536, 3, 0, np.float32, np.int64),
+                                              (300000, 5, 0, np.float32, np.int16)])
+def test_eval_metrics_match_sklearn(n, D, ties, ydt, ddt):
+    """Device log-loss / AUC (csrc/metrics.hip) against sklearn.metrics on the same arrays: counts exact, 2U an exact
+    integer (AUC compared at 1e-12: sklearn integrates a float trapezoid), log-loss at 1e-12 relative (fp64 sums).
+    Quantised scores give heavy ties; domain D - 1 is empty; ids outside [0, D) count only in the overall figure."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(n + D)
+    p = rng.random(n).astype(np.float32)
+    if ties:
+        p = (np.floor(p * ties) / ties).astype(np.float32)          # includes exact 0.0 (clipped in the log-loss)
+    y = (rng.random(n) < 0.3).astype(ydt)
+    dom = rng.integers(-1, D, size=n).astype(ddt)                    # -1: outside; D - 1 never drawn below
+    dom[dom == D - 1] = 0
+    if n >= 7:
+        y[:2] = [0, 1]
+        dom[:2] = 0                                                  # domain 0 has both classes
+    rows, pos, two_u, ll = ops.eval_metrics(_dev(p), _dev(y), _dev(dom), D)
+    d64 = dom.astype(np.int64)
+    yb = (y.astype(np.float64) > 0.5)
+    for d in list(range(D)) + [D]:
+        sel = np.ones(n, bool) if d == D else d64 == d
+        assert rows[d] == int(sel.sum()) and pos[d] == int(yb[sel].sum())
+        if rows[d] == 0:
+            assert two_u[d] == 0 and ll[d] == 0.0
+            continue
+        P, N = pos[d], rows[d] - pos[d]
+        pd_, yd = p[sel].astype(np.float64), yb[sel].astype(np.float64)
+        want_ll = -np.sum(yd * np.log(np.clip(pd_, 2.0 ** -52, 1 - 2.0 ** -52)) +
+                          (1 - yd) * np.log(1 - np.clip(pd_, 2.0 ** -52, 1 - 2.0 ** -52)))
+        np.testing.assert_allclose(ll[d], want_ll, rtol=1e-12, atol=1e-12)
+        if P and N:
+            np.testing.assert_allclose(ll[d] / rows[d], log_loss(yd.tolist(), pd_.tolist()), rtol=1e-12)
+            np.testing.assert_allclose(two_u[d] / (2.0 * P * N), roc_auc_score(yd.tolist(), pd_.tolist()), rtol=1e-12, atol=1e-15)
+    assert rows[D - 1] == 0 if n >= 7 else True
+
+
+def test_trainer_device_metrics_equal_the_sklearn_path(monkeypatch):
+    """CTRTrainer.evaluate / evaluate_multi_domain_loss with the device metrics == the reference's host path
+    (`.tolist()` + sklearn) on the same model and loader; empty domain -> None."""
+    from _golden import Case, build_product_model, to_device
+    from scenario_wise_rec.trainers import CTRTrainer
+    c = Case("mmoe")
+    model = build_product_model(c, device="cuda:0")
+    tr = CTRTrainer(model, "t", device="cuda:0")
+    x, y = c.batch(0)
+    x = {k: torch.from_numpy(v) for k, v in x.items()}
+    yt = torch.from_numpy(y)
+    B = len(y)
+    loader = [({k: v[i:i + 100] for k, v in x.items()}, yt[i:i + 100]) for i in range(0, B, 100)]
+    D = int(x["domain_indicator"].max()) + 2          # one more domain than the data has: it must report None
+    dev = tr.evaluate_multi_domain_loss(model, loader, D), tr.evaluate(model, loader)
+    monkeypatch.setenv("SWR_DEVICE_METRICS", "0")
+    host = tr.evaluate_multi_domain_loss(model, loader, D), tr.evaluate(model, loader)
+    assert dev[0][0][-1] is None and dev[0][1][-1] is None and host[0][0][-1] is None
+    for a, b in zip(dev[0][0][:-1] + dev[0][1][:-1] + [dev[0][2], dev[0][3]] + list(dev[1]),
+                    host[0][0][:-1] + host[0][1][:-1] + [host[0][2], host[0][3]] + list(host[1])):
+        np.testing.assert_allclose(a, b, rtol=1e-10)
