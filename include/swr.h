@@ -439,6 +439,43 @@ int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last, int32_t* 
 int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t vocab, int dim,
                    const float* hist, const swr_adam_hyper* hyper_dev, void* stream);
 
+/* ---------------------------------------------------------------- STAR ----
+ * STAR's factorised weights (reference models/multi_domain/star.py:99-107): per layer, for ALL domains in one launch
+ * each way, the effective weights W_s (.) W_d[d] in Linear layout [out, in] and biases b_s + b_d[d] -- the first layer
+ * (`first` = 1) also folds in the domain affine of the partitioned normalisation (gamma_s gamma_d[d], beta_s +
+ * beta_d[d]; star.py:91-100) -- and, backwards, every parameter gradient from the gradients of the effective tensors.
+ * Parameters are in the reference's layout: weights [in, out], biases [out], affine vectors [in].  Gradient pointers
+ * may be null (not needed); `accumulate` = 1 adds into them (gradient arena), 0 overwrites.  dW_eff / db_eff may be
+ * null per domain (no gradient arrived from it). */
+#define SWR_STAR_MAX_DOMAINS 8
+typedef struct {
+    int32_t D, in_dim, out_dim, first;
+    const float* Ws;
+    const float* bs;
+    const float* Wd[SWR_STAR_MAX_DOMAINS];
+    const float* bd[SWR_STAR_MAX_DOMAINS];
+    const float* gamma_s;
+    const float* beta_s;
+    const float* gamma_d[SWR_STAR_MAX_DOMAINS];
+    const float* beta_d[SWR_STAR_MAX_DOMAINS];
+    float* W_eff[SWR_STAR_MAX_DOMAINS];       /* forward outputs [out, in] */
+    float* b_eff[SWR_STAR_MAX_DOMAINS];       /* [out] */
+    const float* dW_eff[SWR_STAR_MAX_DOMAINS];   /* backward inputs */
+    const float* db_eff[SWR_STAR_MAX_DOMAINS];
+    float* dWs;
+    float* dbs;
+    float* dWd[SWR_STAR_MAX_DOMAINS];
+    float* dbd[SWR_STAR_MAX_DOMAINS];
+    float* dgamma_s;
+    float* dbeta_s;
+    float* dgamma_d[SWR_STAR_MAX_DOMAINS];
+    float* dbeta_d[SWR_STAR_MAX_DOMAINS];
+    int32_t accumulate;
+    int32_t pad;
+} swr_star_layer_args;
+int swr_star_layer_fwd(const swr_star_layer_args* args, void* stream);
+int swr_star_layer_bwd(const swr_star_layer_args* args, void* stream);
+
 /* ------------------------------------------------------------- metrics ----
  * Evaluation metrics on the device: replaces `.tolist()` + sklearn.metrics.log_loss /
  * roc_auc_score of CTRTrainer.evaluate / evaluate_multi_domain_loss (trainers/ctr_trainer.py:99-165).

@@ -112,6 +112,19 @@ class TowerArgs(C.Structure):
                 ("dZ1", C.c_void_p), ("lddz", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64)]
 
 
+_P8 = C.c_void_p * 8
+
+
+class StarLayerArgs(C.Structure):
+    _fields_ = [("D", C.c_int32), ("in_dim", C.c_int32), ("out_dim", C.c_int32), ("first", C.c_int32),
+                ("Ws", C.c_void_p), ("bs", C.c_void_p), ("Wd", _P8), ("bd", _P8),
+                ("gamma_s", C.c_void_p), ("beta_s", C.c_void_p), ("gamma_d", _P8), ("beta_d", _P8),
+                ("W_eff", _P8), ("b_eff", _P8), ("dW_eff", _P8), ("db_eff", _P8),
+                ("dWs", C.c_void_p), ("dbs", C.c_void_p), ("dWd", _P8), ("dbd", _P8),
+                ("dgamma_s", C.c_void_p), ("dbeta_s", C.c_void_p), ("dgamma_d", _P8), ("dbeta_d", _P8),
+                ("accumulate", C.c_int32), ("pad", C.c_int32)]
+
+
 class DpTable(C.Structure):
     _fields_ = [("row_off", C.c_int64), ("grad_off", C.c_int64), ("n", C.c_int64), ("dim", C.c_int32), ("pad", C.c_int32),
                 ("out_row", C.c_void_p), ("out_grad", C.c_void_p)]
@@ -177,6 +190,8 @@ _SIGS = {
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    "swr_star_layer_fwd": (C.c_int, [_P, _P]),
+    "swr_star_layer_bwd": (C.c_int, [_P, _P]),
     "swr_eval_metrics_workspace_bytes": (_Z, [_L, _I]),
     "swr_eval_metrics": (C.c_int, [_P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _Z, _P]),
     "swr_dp_finish": (C.c_int, [_P, _L, _L, _P, _P, _L, _P, _I, _I, _F, _P]),

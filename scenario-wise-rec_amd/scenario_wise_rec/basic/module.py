@@ -13,6 +13,8 @@ nn.Parameters of the reference-compatible module tree are views into those buffe
 Embedding tables above `SwrModule.dense_table_limit_bytes` stay outside: their gradients are
 row-sparse (`ops.EmbedGather`), their update is a row kernel + an untouched-row sweep.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -20,7 +22,9 @@ _ALIGN = 4      # elements: every arena member group starts 16-byte aligned
 
 
 class SwrModule(nn.Module):
-    dense_table_limit_bytes = 4 << 20
+    # tables above this size take row-sparse gradients (row lists + exact lazy Adam) instead of a dense [V, E] gradient
+    # that is zeroed, swept and Adam-stepped in full every step; SWR_DENSE_TABLE_LIMIT (bytes) overrides
+    dense_table_limit_bytes = int(os.environ.get("SWR_DENSE_TABLE_LIMIT", 1 << 20))
     _apply_depth = 0
 
     # ---- layout ------------------------------------------------------------------------------

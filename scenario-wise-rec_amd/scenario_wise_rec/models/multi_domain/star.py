@@ -1,4 +1,6 @@
 """STAR: star topology adaptive recommender (reference: `models/multi_domain/star.py:10-118`)."""
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import init
@@ -91,6 +93,18 @@ class Star(SwrModule):
         # partitioned norm, shared part (identical for every domain, star.py:95-98): biased variance, eps 1e-6
         h = ops.batch_standardize(emb, self.eps)
         for l in range(self.layer_num):
+            if D <= 8 and os.environ.get("SWR_STAR_FUSED", "1") != "0":
+                # effective weights of the layer for all domains: one launch each way (csrc/star.hip)
+                first = l == 0
+                params = [self.share_parm_w[l], self.share_parm_b[l]] + ([self.dn_share_gamma, self.dn_share_bias] if first else [])
+                params += [self.domain_specific_w[d][l] for d in range(D)] + [self.domain_specific_b[d][l] for d in range(D)]
+                if first:
+                    params += list(self.domain_specific_dn_gamma) + list(self.domain_specific_dn_bias)
+                eff = ops.star_layer_weights(first, D, *params)
+                bns = [self.domain_specific_bn[d][l] for d in range(D)]
+                h = ops.linear_bn_act(h, list(eff[:D]), list(eff[D:]), bn=_bn_dict(bns), acts="relu",
+                                      groups=(1 if l == 0 else D), training=self.training)
+                continue
             ws, bs = [], []
             for d in range(D):
                 w = self.share_parm_w[l] * self.domain_specific_w[d][l]            # [in, out]

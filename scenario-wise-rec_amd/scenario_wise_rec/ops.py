@@ -121,8 +121,10 @@ def _grad_alias(params, kind=1):
         return None
     gs = []
     for p in params:
+        if not p.is_leaf or not p.requires_grad:       # (derived tensors, e.g. STAR's effective weights: autograd carries those)
+            return None
         g = getattr(p, "grad", None)
-        if g is None or not p.is_leaf or not p.requires_grad or g.dtype != torch.float32:
+        if g is None or g.dtype != torch.float32:
             return None
         gs.append(g)
     if len(gs) == 1:
@@ -1194,3 +1196,89 @@ def eval_metrics(prob, label, domain, n_domains):
                                  H.ptr(counts), H.ptr(ll), H.ptr(ws), nbytes, H.stream()), "swr_eval_metrics")
     c = counts.cpu().view(D + 1, 3).tolist()
     return [r[0] for r in c], [r[1] for r in c], [r[2] for r in c], ll.cpu().tolist()
+
+
+# =========================================================================== STAR factorised weights
+class StarLayerWeights(Function):
+    """Effective weights / biases of one STAR layer for all domains (reference `star.py:99-107`; the first layer also
+    folds in the partitioned norm's domain affine, `star.py:91-100`): one launch each way (csrc/star.hip) instead of
+    ~10 elementwise launches per (layer, domain) and three times as many in the backward pass.
+
+    params = Ws [in, out], bs [out], (first: gamma_s [in], beta_s [in]), D x Wd, D x bd, (first: D x gamma_d, D x beta_d).
+    Returns D weights in Linear layout [out, in] (adjacent views of one buffer: the stacked operand of the layer's
+    product is a zero-copy view) followed by D biases [out]."""
+
+    @staticmethod
+    def forward(ctx, first, D, *params):
+        H.require_device(*params)
+        Ws = params[0]
+        I, O = Ws.shape
+        dev = Ws.device
+        off = 4 if first else 2
+        a = H.StarLayerArgs()
+        a.D, a.in_dim, a.out_dim, a.first = D, I, O, int(first)
+        ps = [H.f32c(p.detach()) for p in params]
+        a.Ws, a.bs = ps[0].data_ptr(), ps[1].data_ptr()
+        if first:
+            a.gamma_s, a.beta_s = ps[2].data_ptr(), ps[3].data_ptr()
+        Wst = torch.empty((D * O, I), dtype=torch.float32, device=dev)
+        bst = torch.empty(D * O, dtype=torch.float32, device=dev)
+        for d in range(D):
+            a.Wd[d], a.bd[d] = ps[off + d].data_ptr(), ps[off + D + d].data_ptr()
+            if first:
+                a.gamma_d[d], a.beta_d[d] = ps[off + 2 * D + d].data_ptr(), ps[off + 3 * D + d].data_ptr()
+            a.W_eff[d] = Wst.data_ptr() + 4 * d * O * I
+            a.b_eff[d] = bst.data_ptr() + 4 * d * O
+        H.check(lib.swr_star_layer_fwd(C.byref(a), H.stream()), "swr_star_layer_fwd")
+        ctx.first, ctx.D, ctx.params, ctx.keep = first, D, params, ps
+        return tuple(Wst[d * O:(d + 1) * O] for d in range(D)) + tuple(bst[d * O:(d + 1) * O] for d in range(D))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        first, D, params, ps = ctx.first, ctx.D, ctx.params, ctx.keep
+        I, O = params[0].shape
+        dev = params[0].device
+        off = 4 if first else 2
+        n = len(params)
+        # straight into the gradient arena when every parameter's .grad lives there (zero_grad zeroed it), else fresh tensors
+        direct = [_grad_alias([p]) if ctx.needs_input_grad[2 + j] else None for j, p in enumerate(params)]
+        all_direct = all(g is not None or not ctx.needs_input_grad[2 + j] for j, g in enumerate(direct))
+        if all_direct:
+            out = direct
+        else:
+            out = [torch.empty_like(p, memory_format=torch.contiguous_format) if ctx.needs_input_grad[2 + j] else None
+                   for j, p in enumerate(params)]
+        a = H.StarLayerArgs()
+        a.D, a.in_dim, a.out_dim, a.first, a.accumulate = D, I, O, int(first), int(all_direct)
+        a.Ws, a.bs = ps[0].data_ptr(), ps[1].data_ptr()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        a.dWs, a.dbs = ptr(out[0]), ptr(out[1])
+        if first:
+            a.gamma_s, a.beta_s = ps[2].data_ptr(), ps[3].data_ptr()
+            a.dgamma_s, a.dbeta_s = ptr(out[2]), ptr(out[3])
+        keep = []
+        for d in range(D):
+            a.Wd[d], a.bd[d] = ps[off + d].data_ptr(), ps[off + D + d].data_ptr()
+            a.dWd[d], a.dbd[d] = ptr(out[off + d]), ptr(out[off + D + d])
+            if first:
+                a.gamma_d[d], a.beta_d[d] = ps[off + 2 * D + d].data_ptr(), ps[off + 3 * D + d].data_ptr()
+                a.dgamma_d[d], a.dbeta_d[d] = ptr(out[off + 2 * D + d]), ptr(out[off + 3 * D + d])
+            gW, gb = grads[d], grads[D + d]
+            if gW is not None:
+                gW = H.f32c(gW)
+                keep.append(gW)
+                a.dW_eff[d] = gW.data_ptr()
+            if gb is not None:
+                gb = H.f32c(gb)
+                keep.append(gb)
+                a.db_eff[d] = gb.data_ptr()
+        H.check(lib.swr_star_layer_bwd(C.byref(a), H.stream()), "swr_star_layer_bwd")
+        if all_direct:
+            _mark_touched([p for j, p in enumerate(params) if ctx.needs_input_grad[2 + j]])
+            return (None, None) + (None,) * n
+        return (None, None) + tuple(out)
+
+
+def star_layer_weights(first, D, *params):
+    return StarLayerWeights.apply(bool(first), int(D), *params)

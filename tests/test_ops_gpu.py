@@ -626,3 +626,35 @@ def test_trainer_device_metrics_equal_the_sklearn_path(monkeypatch):
     for a, b in zip(dev[0][0][:-1] + dev[0][1][:-1] + [dev[0][2], dev[0][3]] + list(dev[1]),
                     host[0][0][:-1] + host[0][1][:-1] + [host[0][2], host[0][3]] + list(host[1])):
         np.testing.assert_allclose(a, b, rtol=1e-10)
+
+
+@pytest.mark.parametrize("D,I,O,first", [(3, 37, 20, True), (3, 64, 32, False), (1, 5, 1, True), (8, 16, 8, False)])
+def test_star_layer_weights_against_torch(D, I, O, first):
+    """csrc/star.hip (one launch per layer each way) against the reference's elementwise formulation
+    (`star.py:91-107`) differentiated by torch autograd, fp32: values to 1e-6, gradients to 1e-5 relative."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(D * 100 + I)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).requires_grad_(True)
+    Ws, bs = mk(I, O), mk(O)
+    gs, be = mk(I), mk(I)
+    Wd, bd = [mk(I, O) for _ in range(D)], [mk(O) for _ in range(D)]
+    gd, bed = [mk(I) for _ in range(D)], [mk(I) for _ in range(D)]
+    params = [Ws, bs] + ([gs, be] if first else []) + Wd + bd + ((gd + bed) if first else [])
+    eff = ops.star_layer_weights(first, D, *params)
+    cot = [torch.randn(e.shape, device="cuda", generator=g) for e in eff]
+    got = torch.autograd.grad(eff, params, cot)
+    want_eff = []
+    for d in range(D):
+        w = Ws * Wd[d]
+        b = bs + bd[d]
+        if first:
+            b = b + (be + bed[d]) @ w
+            w = (gs * gd[d]).unsqueeze(1) * w
+        want_eff.append((w.t().contiguous(), b))
+    want_out = [w for w, _ in want_eff] + [b for _, b in want_eff]
+    want = torch.autograd.grad(want_out, params, cot)
+    for a, b in zip(eff, want_out):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for a, b, p in zip(got, want, params):
+        scale = float(b.abs().max()) + 1e-6
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 * scale)
