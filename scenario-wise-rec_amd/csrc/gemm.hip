@@ -944,7 +944,9 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     if (lin >= kk.n_tiles) return;
     const int qb = static_cast<int>(lin % kk.qblk);
     const int q0 = qb * TX_QCOLS;
-    const int split = static_cast<int>(lin / kk.qblk);
+    const int pb = static_cast<int>((lin / kk.qblk) % kk.pblk);        // A wider than 5 tiles: column blocks of PT tiles
+    const int p0 = pb * ACOLS;
+    const int split = static_cast<int>(lin / (kk.qblk * kk.pblk));
     const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
     const int64_t me = min(ms + kk.rows_per_split, a.M);
 
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     const int scol = 2 * cp;                                           // slab column (A columns, then the 128 B columns)
     const bool isA = scol < ACOLS;
     const bool isT = TAIL && scol >= ACOLS + TX_QCOLS;
-    const int gcol = isA ? scol : (isT ? kk.tail_q0 + (scol - ACOLS - TX_QCOLS) : q0 + (scol - ACOLS));
+    const int gcol = isA ? p0 + scol : (isT ? kk.tail_q0 + (scol - ACOLS - TX_QCOLS) : q0 + (scol - ACOLS));
     const bool col_ok = unit_on && (isA ? gcol < a.K1 : gcol < a.K2);  // K1, K2 even
     const float* __restrict__ src = (isA ? a.A : a.B) + (col_ok ? gcol : 0);
     const int64_t ld = isA ? a.lda : a.ldb;
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
         if (t < p_count) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int p = 32 * (p_first + t) + (r & 3) + 8 * (r >> 2) + 4 * s;
+                const int p = p0 + 32 * (p_first + t) + (r & 3) + 8 * (r >> 2) + 4 * s;
                 if (p < a.K1 && q < q_end) P[static_cast<int64_t>(p) * k2p + q] = acc[t][r];
             }
         }
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
             if (pt_ < PT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int p = 32 * pt_ + (r & 3) + 8 * (r >> 2) + 4 * s;
+                    const int p = p0 + 32 * pt_ + (r & 3) + 8 * (r >> 2) + 4 * s;
                     if (p < a.K1 && kk.tail_q0 + i < a.K2) P[static_cast<int64_t>(p) * k2p + qtl] = acc_tail[t][r];
                 }
             }
@@ -1215,7 +1217,7 @@ static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps
 // bf16-split tn kernel: one group, A narrow enough to stage whole (<= 5 column tiles), 16-byte rows, a batch worth it
 static bool tn_x6_ok(const swr_gemm_tn_args& a) {
     static const int off = getenv("SWR_TN_X6") ? atoi(getenv("SWR_TN_X6")) == 0 : 0;
-    return use_x6() && !off && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
+    return use_x6() && !off && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX * 8 && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
            a.ldb % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0 && a.M >= 4096 &&
            a.M * a.lda < (1ll << 31) && a.M * a.ldb < (1ll << 31);      // 32-bit element offsets inside the kernel
 }
@@ -1228,7 +1230,8 @@ static bool tn_x6_tail(const swr_gemm_tn_args& a) {
 static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
     static const int blocks_target = getenv("SWR_TN_X6_BLOCKS") ? atoi(getenv("SWR_TN_X6_BLOCKS")) : 256;   // one per CU
     const int qblk = tn_x6_tail(a) ? a.K2 / TX_QCOLS : static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
-    int64_t want = std::max<int64_t>(1, blocks_target / qblk);
+    const int pblk = static_cast<int>(swr_ceil_div(swr_ceil_div(a.K1, 32), TN_TA_MAX));
+    int64_t want = std::max<int64_t>(1, blocks_target / (qblk * pblk));
     want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (8 * TX_ROWS)));
     rps = swr_ceil_div(swr_ceil_div(a.M, want), TX_ROWS) * TX_ROWS;
     n_splits = static_cast<int>(swr_ceil_div(a.M, rps));
@@ -1280,9 +1283,10 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         kk.k2p = tail ? static_cast<int>(kk.qblk) * (TX_QCOLS + 32) : a.K2;
         kk.part = static_cast<float*>(workspace);
         kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(n_splits) * a.K1 * kk.k2p : nullptr;
-        kk.pblk = 1;
-        kk.n_tiles = kk.qblk * static_cast<unsigned>(n_splits);
-        const int pt = static_cast<int>(swr_ceil_div(a.K1, 32));
+        const int pt_all = static_cast<int>(swr_ceil_div(a.K1, 32));
+        kk.pblk = static_cast<unsigned>(swr_ceil_div(pt_all, TN_TA_MAX));          // A column blocks of <= 5 tiles
+        kk.n_tiles = kk.qblk * kk.pblk * static_cast<unsigned>(n_splits);
+        const int pt = static_cast<int>(swr_ceil_div(pt_all, kk.pblk));
         const dim3 grid((kk.n_tiles + 7) / 8 * 8);
         const unsigned lds = static_cast<unsigned>(2 * 3 * (pt * 32 + TX_QCOLS + (tail ? 32 : 0)) * TX_PM * sizeof(__bf16));
         const void* fn = nullptr;
