@@ -1217,7 +1217,7 @@ static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps
 // bf16-split tn kernel: one group, A narrow enough to stage whole (<= 5 column tiles), 16-byte rows, a batch worth it
 static bool tn_x6_ok(const swr_gemm_tn_args& a) {
     static const int off = getenv("SWR_TN_X6") ? atoi(getenv("SWR_TN_X6")) == 0 : 0;
-    return use_x6() && !off && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX * 8 && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
+    return use_x6() && !off && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX * 32 && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
            a.ldb % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0 && a.M >= 4096 &&
            a.M * a.lda < (1ll << 31) && a.M * a.ldb < (1ll << 31);      // 32-bit element offsets inside the kernel
 }

@@ -163,7 +163,7 @@ def test_embedding_backward_is_deterministic():
 
 
 @pytest.mark.parametrize("M,N,K", [(250, 148, 516), (64, 1, 16), (1000, 33, 7), (31, 300, 52), (4096, 256, 376),
-                                   (5003, 148, 516), (4100, 64, 36), (8192, 20, 132), (4500, 96, 288), (5000, 300, 132), (4200, 512, 64),
+                                   (5003, 148, 516), (4100, 64, 36), (8192, 20, 132), (4500, 96, 288), (5000, 300, 132), (4200, 512, 64), (4100, 2048, 36),
                                    (6000, 160, 300)])     # tn on the bf16-split kernel (516, 132, 288: ragged last tile folded into the full blocks)
 def test_gemm_forms(M, N, K):
     """nt / nn / tn on the f32 MFMA pipe against fp64 matmul: exact-fp32 fma chains, so the error is
