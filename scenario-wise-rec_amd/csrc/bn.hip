@@ -328,36 +328,42 @@ extern "C" int swr_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 // ------------------------------------------------------------------------------ affine + act forward
+// general-width path (N not a multiple of 4, or wider than 1024): thread = one column, EW_ROWS rows of it -- no
+// per-element division by N, the column's coefficients and activation looked up once
+#define EW_ROWS 16
 __global__ __launch_bounds__(BN_THREADS) void affine_act_fwd_kernel(const float* __restrict__ Z, int64_t ldz,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift, const ActSpec acts,
-                                                                    float* __restrict__ Y, int64_t ldy, int64_t M, int N) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * BN_THREADS + threadIdx.x;
-    const int64_t m = idx / N;
-    const int n = static_cast<int>(idx - m * N);
-    if (m >= M) return;
+                                                                    float* __restrict__ Y, int64_t ldy, int64_t M, int N,
+                                                                    int rows_per_block) {
+    const int n = blockIdx.x * BN_THREADS + threadIdx.x;
+    if (n >= N) return;
     int lo, group;
     const int act = find_act(acts, n, lo, group);
-    const float* z = Z + m * ldz;
-    const float v = (scale ? scale[n] : 1.f) * z[n] + (shift ? shift[n] : 0.f);
-    float y;
-    if (act == SWR_ACT_RELU) {
-        y = fmaxf(v, 0.f);
-    } else if (act == SWR_ACT_SIGMOID) {
-        y = swr_sigmoid(v);
-    } else if (act == SWR_ACT_SOFTMAX) {
-        const int g0 = lo + ((n - lo) / group) * group;
-        float mx = -INFINITY;
-        for (int j = 0; j < group; ++j)
-            mx = fmaxf(mx, (scale ? scale[g0 + j] : 1.f) * z[g0 + j] + (shift ? shift[g0 + j] : 0.f));
-        float den = 0.f;
-        for (int j = 0; j < group; ++j)
-            den += expf((scale ? scale[g0 + j] : 1.f) * z[g0 + j] + (shift ? shift[g0 + j] : 0.f) - mx);
-        y = expf(v - mx) / den;
-    } else {
-        y = v;
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.y) * rows_per_block, m1 = min<int64_t>(m0 + rows_per_block, M);
+    for (int64_t m = m0; m < m1; ++m) {
+        const float* z = Z + m * ldz;
+        const float v = sc * z[n] + sh;
+        float y;
+        if (act == SWR_ACT_RELU) {
+            y = fmaxf(v, 0.f);
+        } else if (act == SWR_ACT_SIGMOID) {
+            y = swr_sigmoid(v);
+        } else if (act == SWR_ACT_SOFTMAX) {
+            const int g0 = lo + ((n - lo) / group) * group;
+            float mx = -INFINITY;
+            for (int j = 0; j < group; ++j)
+                mx = fmaxf(mx, (scale ? scale[g0 + j] : 1.f) * z[g0 + j] + (shift ? shift[g0 + j] : 0.f));
+            float den = 0.f;
+            for (int j = 0; j < group; ++j)
+                den += expf((scale ? scale[g0 + j] : 1.f) * z[g0 + j] + (shift ? shift[g0 + j] : 0.f) - mx);
+            y = expf(v - mx) / den;
+        } else {
+            y = v;
+        }
+        Y[m * ldy + n] = y;
     }
-    Y[m * ldy + n] = y;
 }
 
 extern "C" int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scale, const float* shift,
@@ -376,8 +382,9 @@ extern "C" int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scal
                            dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N, pl);
         return swr_launch_status();
     }
-    hipLaunchKernelGGL(affine_act_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M * N, BN_THREADS))), dim3(BN_THREADS),
-                       0, static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N);
+    const int rpb = static_cast<int>(std::max<int64_t>(EW_ROWS, swr_ceil_div(M, 65535)));       // gridDim.y <= 65535
+    hipLaunchKernelGGL(affine_act_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(N, BN_THREADS)), static_cast<unsigned>(swr_ceil_div(M, rpb))),
+                       dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N, rpb);
     return swr_launch_status();
 }
 
@@ -499,15 +506,19 @@ extern "C" int swr_bn_bwd_finalize(const float* partials, int n_tiles, int64_t M
 __global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
     int64_t ldz, const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ cc,
-    const float* __restrict__ mean, const ActSpec acts, float* __restrict__ dZ, int64_t lddz, int64_t M, int N) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * BN_THREADS + threadIdx.x;
-    const int64_t m = idx / N;
-    const int n = static_cast<int>(idx - m * N);
-    if (m >= M) return;
-    float v = act_grad(acts, dY + m * lddy, Y + m * ldy, n);
-    if (ca) v *= ca[n];
-    if (cb) v = fmaf(cb[n], Z[m * ldz + n] - mean[n], v) + cc[n];
-    dZ[m * lddz + n] = v;
+    const float* __restrict__ mean, const ActSpec acts, float* __restrict__ dZ, int64_t lddz, int64_t M, int N,
+    int rows_per_block) {
+    const int n = blockIdx.x * BN_THREADS + threadIdx.x;           // thread = one column, rows_per_block rows of it
+    if (n >= N) return;
+    const float a_ = ca ? ca[n] : 1.f;
+    const float b_ = cb ? cb[n] : 0.f, c_ = cb ? cc[n] : 0.f, mu = cb ? mean[n] : 0.f;
+    const int64_t m0 = static_cast<int64_t>(blockIdx.y) * rows_per_block, m1 = min<int64_t>(m0 + rows_per_block, M);
+    for (int64_t m = m0; m < m1; ++m) {
+        float v = act_grad(acts, dY + m * lddy, Y + m * ldy, n);
+        if (ca) v *= a_;
+        if (cb) v = fmaf(b_, Z[m * ldz + n] - mu, v) + c_;
+        dZ[m * lddz + n] = v;
+    }
 }
 
 extern "C" int swr_act_bwd_apply(const float* dY, int64_t lddy, const float* Y, int64_t ldy, const float* Z, int64_t ldz,
@@ -529,7 +540,8 @@ extern "C" int swr_act_bwd_apply(const float* dY, int64_t lddy, const float* Y, 
                            dZ, lddz, M, N, pl);
         return swr_launch_status();
     }
-    hipLaunchKernelGGL(act_bwd_apply_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M * N, BN_THREADS))), dim3(BN_THREADS),
-                       0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, as, dZ, lddz, M, N);
+    const int rpb = static_cast<int>(std::max<int64_t>(EW_ROWS, swr_ceil_div(M, 65535)));       // gridDim.y <= 65535
+    hipLaunchKernelGGL(act_bwd_apply_kernel, dim3(static_cast<unsigned>(swr_ceil_div(N, BN_THREADS)), static_cast<unsigned>(swr_ceil_div(M, rpb))),
+                       dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, as, dZ, lddz, M, N, rpb);
     return swr_launch_status();
 }
