@@ -476,6 +476,21 @@ typedef struct {
 int swr_star_layer_fwd(const swr_star_layer_args* args, void* stream);
 int swr_star_layer_bwd(const swr_star_layer_args* args, void* stream);
 
+/* ------------------------------------------------------------ input columns ----
+ * Row permutation of a columnar, device-resident dataset (replaces DataLoader(shuffle=True) over
+ * TorchDataset, whose __getitem__ builds one python dict per ROW, utils/data.py:11-22,55): for every column c,
+ * dst[c][i] = src[c][perm[i]], i < n_out -- all columns in ONE launch, element sizes 1 / 2 / 4 / 8 bytes.  Byte copy,
+ * bit-exact; perm values must lie in [0, n_in) (out-of-range entries are clamped and raise SWR_FLAG_INDEX_OOR). */
+#define SWR_TAKE_MAX_COLUMNS 96
+typedef struct {
+    const void* src;
+    void* dst;
+    int32_t elem_bytes;    /* 1, 2, 4 or 8 */
+    int32_t pad;
+} swr_take_column;
+int swr_take_rows(const swr_take_column* columns_host, int n_columns, const int64_t* perm, int64_t n_in, int64_t n_out,
+                  uint32_t* err_flag, void* stream);
+
 /* ------------------------------------------------------------- metrics ----
  * Evaluation metrics on the device: replaces `.tolist()` + sklearn.metrics.log_loss /
  * roc_auc_score of CTRTrainer.evaluate / evaluate_multi_domain_loss (trainers/ctr_trainer.py:99-165).

@@ -125,6 +125,10 @@ class StarLayerArgs(C.Structure):
                 ("accumulate", C.c_int32), ("pad", C.c_int32)]
 
 
+class TakeColumn(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("elem_bytes", C.c_int32), ("pad", C.c_int32)]
+
+
 class DpTable(C.Structure):
     _fields_ = [("row_off", C.c_int64), ("grad_off", C.c_int64), ("n", C.c_int64), ("dim", C.c_int32), ("pad", C.c_int32),
                 ("out_row", C.c_void_p), ("out_grad", C.c_void_p)]
@@ -190,6 +194,7 @@ _SIGS = {
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    "swr_take_rows": (C.c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "swr_star_layer_fwd": (C.c_int, [_P, _P]),
     "swr_star_layer_bwd": (C.c_int, [_P, _P]),
     "swr_eval_metrics_workspace_bytes": (_Z, [_L, _I]),

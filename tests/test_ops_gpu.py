@@ -658,3 +658,41 @@ def test_star_layer_weights_against_torch(D, I, O, first):
     for a, b, p in zip(got, want, params):
         scale = float(b.abs().max()) + 1e-6
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 * scale)
+
+
+def test_device_data_loader_serves_the_same_batches():
+    """DeviceDataLoader (row f3): without shuffle the batches are the DataLoader(TorchDataset) batches bit for bit (ragged
+    last batch, drop_last); with shuffle every epoch is a permutation of the rows applied consistently to all columns."""
+    from scenario_wise_rec.utils.data import DeviceDataLoader, TorchDataset
+    from torch.utils.data import DataLoader
+    rng = np.random.default_rng(5)
+    n = 1003
+    x = {"a": rng.integers(0, 1 << 40, n).astype(np.int64), "b": rng.integers(0, 100, n).astype(np.int8),
+         "c": rng.random(n).astype(np.float32), "d": rng.integers(0, 3000, n).astype(np.int16), "e": rng.random(n).astype(np.float64),
+         "domain_indicator": rng.integers(0, 3, n).astype(np.int32)}
+    y = (rng.random(n) < 0.3).astype(np.float32)
+    ref = DataLoader(TorchDataset({k: torch.from_numpy(v) for k, v in x.items()}, torch.from_numpy(y)), batch_size=128)
+    got = DeviceDataLoader(x, y, 128)
+    assert len(got) == len(ref) == 8
+    for (xr, yr), (xg, yg) in zip(ref, got):
+        assert torch.equal(yr, yg.cpu())
+        for k in x:
+            assert xg[k].dtype == xr[k].dtype and torch.equal(xr[k], xg[k].cpu()), k
+    assert len(DeviceDataLoader(x, y, 128, drop_last=True)) == 7
+    sh = DeviceDataLoader(x, y, 100, shuffle=True, generator=torch.Generator(device="cuda").manual_seed(1))
+    key = x["a"].astype(np.float64) * 7 + x["c"]                      # identifies a row
+    order = {float(v): i for i, v in enumerate(key)}
+    epochs = []
+    for _ in range(2):
+        rows = []
+        for xb, yb in sh:
+            a, c = xb["a"].cpu().numpy(), xb["c"].cpu().numpy()
+            idx = np.array([order[float(v)] for v in a.astype(np.float64) * 7 + c])
+            for k in x:
+                np.testing.assert_array_equal(xb[k].cpu().numpy(), x[k][idx])      # all columns moved together
+            np.testing.assert_array_equal(yb.cpu().numpy(), y[idx])
+            rows.append(idx)
+        rows = np.concatenate(rows)
+        assert sorted(rows.tolist()) == list(range(n))                               # a permutation
+        epochs.append(rows)
+    assert not np.array_equal(epochs[0], epochs[1]) and not np.array_equal(epochs[0], np.arange(n))
