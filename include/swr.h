@@ -187,6 +187,10 @@ typedef struct {
                               ([3][>= N rows][ld_split] bf16, zero-padded to a multiple of 32 columns); the bf16-split
                               kernel then stages it with plain copies instead of re-splitting B in every workgroup */
     int64_t ld_split, plane_stride;   /* in bf16 elements */
+    int32_t n_compute;     /* 0 = all: columns n >= n_compute of C are written as ZERO without being computed (whole
+                              32-column tiles are skipped; nt bf16-split kernel, one group).  dX of a layer that sits on
+                              the embedding concat: the trailing dense-feature columns take no gradient */
+    int32_t pad0;
 } swr_gemm_args;
 
 int swr_gemm_nt(const swr_gemm_args* args_host, void* stream);

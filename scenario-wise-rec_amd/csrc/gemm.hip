@@ -331,6 +331,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // column tiles this workgroup really computes (wave-uniform): tiles past N -- or past n_compute, whose columns are
+    // stored as the zeros their accumulators still hold -- are skipped instead of multiplied and masked
+    const int n_need = (a.n_compute > 0 && a.n_compute < N) ? a.n_compute : N;
+    const int nt_valid = max(0, min(NT, (n_need - n0 + 31) / 32));
 
     // Prefetched values stay RAW in their registers: any arithmetic on a loaded value at the load site (even the
     // zeroing of k >= K) makes hipcc wait for the load right there (91 x s_waitcnt vmcnt(0) in this kernel before) and
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             b_read(b0, gq, 0, DB ? HALF : 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                if (t >= nt_valid) break;               // (uniform) nothing but empty tiles from here on
                 bf16x8 (&cur)[3] = (t & 1) ? b1 : b0;
                 bf16x8 (&nxt)[3] = (t & 1) ? b0 : b1;
                 if (t + 1 < NT) b_read(nxt, gq, t + 1, DB ? HALF : 0);

@@ -70,7 +70,8 @@ class GemmArgs(C.Structure):
                 ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int32),
                 ("accumulate", C.c_int32), ("stat_partials", C.c_void_p), ("groups", C.c_int32),
                 ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsBias", C.c_int64),
-                ("gsScale", C.c_int64), ("B_split", C.c_void_p), ("ld_split", C.c_int64), ("plane_stride", C.c_int64)]
+                ("gsScale", C.c_int64), ("B_split", C.c_void_p), ("ld_split", C.c_int64), ("plane_stride", C.c_int64),
+                ("n_compute", C.c_int32), ("pad0", C.c_int32)]
 
 
 class GemmTnArgs(C.Structure):

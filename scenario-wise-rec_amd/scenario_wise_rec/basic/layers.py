@@ -96,7 +96,11 @@ def _plan_part(plan, weights, wpos, layer, x, sparse, dense):
 def _run_plan(plan, weights):
     plan.ld = (plan.width + 3) // 4 * 4
     plan.want_grad = torch.is_grad_enabled()       # Function.forward itself always runs with grad mode off
-    return ops.EmbedGather.apply(plan, *weights)
+    out = ops.EmbedGather.apply(plan, *weights)
+    # columns that can take a gradient: everything up to the end of the last embedding column (dense-feature columns are
+    # inputs).  A layer that reads this tensor need not compute d/dx beyond it (ops.LinearBNAct: `n_compute` of dX).
+    out._swr_grad_cols = max((col + dim for _w, _i, _v, dim, col, _s in plan.sparse), default=0)
+    return out
 
 
 def fused_lookup(x, parts):

@@ -26,13 +26,14 @@ def _ld(t):
 
 def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_relu=False, accumulate=False,
          stat_partials=None, groups=1, gsA=0, gsB=0, gsC=0, gsBias=0, gsScale=0, lda=None, ldb=None, ldc=None,
-         B_split=None):
+         B_split=None, n_compute=0):
     """kind 'nt': C[m,n] = sum_k A[m,k] B[n,k];  'nn': C[m,n] = sum_k A[m,k] B[k,n].
     B_split: (planes, ld, plane_stride) from split_weights -- B already split into bf16 planes ('nt', one group)."""
     a = H.GemmArgs()
     if B_split is not None:
         a.B_split, a.ld_split, a.plane_stride = B_split[0].data_ptr(), B_split[1], B_split[2]
     a.M, a.N, a.K = M, N, K
+    a.n_compute = int(n_compute)        # columns >= n_compute of C are written as zeros, not computed (0 = all)
     a.A, a.lda = A.data_ptr(), lda if lda is not None else _ld(A)
     a.B, a.ldb = B.data_ptr(), ldb if ldb is not None else _ld(B)
     a.bias = bias.data_ptr() if bias is not None else None
@@ -489,6 +490,7 @@ class LinearBNAct(Function):
     @staticmethod
     def forward(ctx, cfg, x, *params):
         # params = n_w weights [N_i, K] + n_w biases (or none) + (gammas + betas if bn)
+        x_in = x
         nw = cfg["n_w"]
         Ws, rest = params[:nw], params[nw:]
         bs = rest[:nw] if cfg["has_bias"] else ()
@@ -551,6 +553,7 @@ class LinearBNAct(Function):
             H.check(lib.swr_affine_act_fwd(H.ptr(Z), Ntot, H.ptr(scale), H.ptr(shift), acts, n_acts, H.ptr(Y), Ntot, M,
                                            Ntot, H.stream()), "swr_affine_act_fwd")
         ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
+        ctx.grad_cols = getattr(x_in, "_swr_grad_cols", None)
         ctx.params = params
         ctx.training_bn = training
         ctx.mix = mix
@@ -648,10 +651,13 @@ class LinearBNAct(Function):
                     # layout is the one the bf16-split MFMA kernel stages into LDS
                     # (forking this 5 us copy onto the side stream at forward time was measured: the extra
                     # cross-stream edge costs ~12 us of main-stream latency, more than the copy)
+                    # x = the embedding concat: its trailing dense-feature columns take no gradient (EmbeddingLayer
+                    # marks the tensor), so whole column tiles of dX past them are skipped and stored as zeros
+                    nc = ctx.grad_cols if (ctx.grad_cols is not None and 0 < ctx.grad_cols < K) else 0
                     if ctx.planes_t is not None:
-                        gemm("nt", dZ, W, dx, M, K, Ntot, ldb=Ntot, B_split=ctx.planes_t)    # W^T only through its planes
+                        gemm("nt", dZ, W, dx, M, K, Ntot, ldb=Ntot, B_split=ctx.planes_t, n_compute=nc)    # W^T only through its planes
                     else:
-                        gemm("nt", dZ, _transposed_weight(W), dx, M, K, Ntot)
+                        gemm("nt", dZ, _transposed_weight(W), dx, M, K, Ntot, n_compute=nc)
                 else:
                     gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:

@@ -696,3 +696,18 @@ def test_device_data_loader_serves_the_same_batches():
         assert sorted(rows.tolist()) == list(range(n))                               # a permutation
         epochs.append(rows)
     assert not np.array_equal(epochs[0], epochs[1]) and not np.array_equal(epochs[0], np.arange(n))
+
+
+def test_gemm_n_compute_skips_trailing_column_tiles():
+    """swr_gemm_args.n_compute: columns below it are the ordinary product (bit for bit), columns from it on are stored as
+    zeros without being computed (dX of the layer on the embedding concat: dense-feature columns take no gradient)."""
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(3)
+    M, N, K = 4100, 516, 148
+    A, W = _dev(rng.standard_normal((M, K)).astype(np.float32)), _dev(rng.standard_normal((N, K)).astype(np.float32))
+    full = torch.empty((M, N), device="cuda")
+    part = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm("nt", A, W, full, M, N, K)
+    ops.gemm("nt", A, W, part, M, N, K, n_compute=512)
+    assert torch.equal(part[:, :512], full[:, :512])
+    assert torch.count_nonzero(part[:, 512:]) == 0
