@@ -164,7 +164,8 @@ PRESPLIT = os.environ.get("SWR_PRESPLIT", "0") == "1"      # weights pre-split i
                                                              # 16 us SLOWER per step than splitting in every workgroup (opt-in)
 SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measured: the chip-filling dW product only slows
                                                                         # whatever it is overlapped with; off by default
-SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "1"))   # measured: 1 (fork at once) 0.862 ms, 3 0.866, 2 0.94 (event nodes stall the branch)
+SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "4"))   # measured: 4 (edge at once, launches after the next main kernel) 0.700 ms,
+                                                        # 1 (fork at once) 0.709, 3 (edge and launches later) 0.711, 2 (event nodes) stalls the branch
 SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "0"))    # measured: forking the small (tower) products costs more
                                                                         # in cross-stream edges than the overlap returns
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
@@ -237,7 +238,9 @@ def _fork_side(dev, fn, after_event=None):
     """Run `fn()` (kernel launches / allocations) on the side stream, ordered after `after_event` (or after
     everything enqueued so far on the current stream)."""
     side = _side_stream(dev)
-    if after_event is not None:
+    if isinstance(after_event, str):
+        pass                               # mode 4: the dependency was taken when the work was deferred
+    elif after_event is not None:
         side.wait_event(after_event)
     else:
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -253,6 +256,12 @@ def _defer_side(dev, fn):
     the point where `_defer_side` was called (an event recorded now)."""
     if SIDE_MODE == 1:                 # immediate fork
         _fork_side(dev, fn)
+        return
+    if SIDE_MODE == 4:                 # edge now, launches later: the side stream takes its dependency on the main stream
+        # HERE (after the gather), but its kernels are enqueued only after the main stream's next kernel -- in a
+        # captured graph the nodes of that kernel then come first in capture order
+        _side_stream(dev).wait_stream(torch.cuda.current_stream(dev))
+        _side["deferred"].append((dev, fn, "nowait"))
         return
     ev = None
     if SIDE_MODE == 2:                 # deferred, ordered after an event recorded here
