@@ -49,12 +49,14 @@ def test_exchange_step_reproduces_dataparallel_gradients(name, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("limit", [None, 2048])
-def test_two_ranks_full_hip_step(limit):
-    """limit=2048 bytes forces every table above 32 rows x 16 onto the row-sparse exchange."""
-    out = run_workers("full-gpu", "mmoe_dp2", 2, extra=() if limit is None else (str(limit),))
+@pytest.mark.parametrize("name,world,limit", [("mmoe_dp2", 2, None), ("mmoe_dp2", 2, 2048), ("mmoe_dp8", 8, 2048)])
+def test_two_ranks_full_hip_step(name, world, limit):
+    """limit=2048 bytes forces every table above 32 rows x 16 onto the row-sparse exchange; the 8-rank case (all ranks
+    on cuda:0, gloo) runs the split backward, both all-gathers and the sort-free merge at the world size of a full
+    node against the reference's 8-shard DataParallel result."""
+    out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),))
     got = np.load(os.path.join(out, "state1.npz"))
-    c = Case("mmoe_dp2")
+    c = Case(name)
     for k, v in c.group("state1").items():
         if k.endswith("num_batches_tracked"):
             assert int(got[k]) == int(v)
@@ -65,7 +67,7 @@ def test_two_ranks_full_hip_step(limit):
 @pytest.mark.gpu
 @pytest.mark.parametrize("limit", [None, 2048])
 def test_two_rank_captured_step_matches_eager(limit):
-    """DataParallelStep.capture (two hipGraphs around eager collectives) vs three eager steps: identical state."""
+    """DataParallelStep.capture (three hipGraphs around eager collectives) vs three eager steps: identical state."""
     extra = () if limit is None else (str(limit),)
     a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra), "state1.npz"))
     b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra, env_extra={"DP_EAGER_REFERENCE": "1"}),
