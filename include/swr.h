@@ -480,6 +480,20 @@ typedef struct {
 int swr_star_layer_fwd(const swr_star_layer_args* args, void* stream);
 int swr_star_layer_bwd(const swr_star_layer_args* args, void* stream);
 
+/* ------------------------------------------------------------ routed inference ----
+ * MMoE head in eval mode, routed: every row mixes the experts with its OWN domain's gate
+ * probabilities and runs its own domain's tower [Linear(H, T) -> BatchNorm(eval) -> ReLU -> Linear(T, 1)] -> sigmoid;
+ * the reference evaluates every domain's mix and tower on the whole batch and selects afterwards
+ * (models/multi_domain/mmoe.py:48-55) -- identical results in eval mode, D x less tower work, one launch.
+ *   Y [M, >= ne H + D ne]: expert outputs (ne blocks of H columns) then the D gates' softmax probabilities (ne each);
+ *   W1 [D][T][H], b1 [D][T], scale1 / shift1 [D][T] (BatchNorm eval affine, swr_bn_eval_coeffs), w2 [D][T], b2 [D];
+ *   out [M]: probabilities; 0.0 for a domain id outside [0, D). */
+int swr_routed_mmoe_eval_supported(int n_expert, int H, int D, int T);
+int swr_routed_mmoe_eval(const float* Y, int64_t ldy, int64_t M, int n_expert, int H, int D, int T,
+                         const float* W1, const float* b1, const float* scale1, const float* shift1,
+                         const float* w2, const float* b2, const void* domain, int domain_dtype, float* out,
+                         void* stream);
+
 /* ------------------------------------------------------------ input columns ----
  * Row permutation of a columnar, device-resident dataset (replaces DataLoader(shuffle=True) over
  * TorchDataset, whose __getitem__ builds one python dict per ROW, utils/data.py:11-22,55): for every column c,

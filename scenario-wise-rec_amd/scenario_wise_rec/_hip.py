@@ -195,6 +195,8 @@ _SIGS = {
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    "swr_routed_mmoe_eval_supported": (C.c_int, [_I, _I, _I, _I]),
+    "swr_routed_mmoe_eval": (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "swr_take_rows": (C.c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "swr_star_layer_fwd": (C.c_int, [_P, _P]),
     "swr_star_layer_bwd": (C.c_int, [_P, _P]),

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...basic.layers import MLP, EmbeddingLayer, LayerBank, mlp_bank_forward, mlp_bank_groups
+from ...basic.layers import MLP, EmbeddingLayer, LayerBank, _bn_dict, mlp_bank_forward, mlp_bank_groups
 from ...basic.module import SwrModule
 
 
@@ -76,6 +76,16 @@ class MMOE(SwrModule):
             ex = torch.cat([m(embed_x) for m in experts], dim=1)
             y = torch.cat([ex, mlp_bank_forward(gates, embed_x, shared_input=True)], dim=1)
         H_ = experts[0].out_dim
+        t0 = self.towers[0]
+        if (not self.training and not torch.is_grad_enabled() and y.is_cuda and os.environ.get("SWR_ROUTED_EVAL", "1") != "0"
+                and t0.n_blocks == 1 and t0.act == "relu" and t0.has_output_layer and t0.dropout_p == 0
+                and ops.routed_mmoe_eval_supported(ne, H_, D, t0.block(0)[0].out_features)):
+            # inference: a row needs only its own domain's gate mix and tower (BatchNorm is a fixed affine in eval mode)
+            blocks = [t.block(0) for t in self.towers]
+            outs = [t.output_linear() for t in self.towers]
+            return ops.routed_mmoe_eval(y, ne, H_, [b[0].weight for b in blocks], [b[0].bias for b in blocks],
+                                        _bn_dict([b[1] for b in blocks]), [o.weight for o in outs], [o.bias for o in outs],
+                                        domain_id)
         desc = ops.make_mix_desc(D, ne, H_, 0, ne * H_, ne, [list(range(ne))] * D)
         pooled = ops.MoeMix.apply(y, desc, y.shape[1])                           # [B, D*H]
         logits = mlp_bank_forward(list(self.towers), pooled, shared_input=False)  # [B, D]

@@ -1297,3 +1297,33 @@ class StarLayerWeights(Function):
 
 def star_layer_weights(first, D, *params):
     return StarLayerWeights.apply(bool(first), int(D), *params)
+
+
+# =========================================================================== routed inference
+def routed_mmoe_eval(y, n_expert, H_, towers_w1, towers_b1, towers_bn, towers_w2, towers_b2, domain_id):
+    """Eval-mode MMoE head, routed: every row mixes the experts with its own domain's gate probabilities and runs its
+    own domain's tower (csrc/routed.hip) instead of every domain's on the whole batch followed by the select
+    (`mmoe.py:48-55`).  y [B, ne*H + D*ne] = expert outputs + gate softmax probabilities; returns probabilities [B]."""
+    H.require_device(y, towers_w1[0], domain_id)
+    y = H.f32c(y)
+    D = len(towers_w1)
+    T = towers_w1[0].shape[0]
+    dev = y.device
+    W1, b1 = _cat_params(towers_w1), _cat_params(towers_b1)
+    w2, b2 = _cat_params([w.reshape(-1) for w in towers_w2]), _cat_params(towers_b2)
+    gamma, beta = _cat_params(towers_bn["gamma"]), _cat_params(towers_bn["beta"])
+    rm, rv = _cat_params(towers_bn["running_mean"]), _cat_params(towers_bn["running_var"])
+    scale = torch.empty(D * T, dtype=torch.float32, device=dev)
+    shift = torch.empty(D * T, dtype=torch.float32, device=dev)
+    H.check(lib.swr_bn_eval_coeffs(H.ptr(gamma), H.ptr(beta), H.ptr(rm), H.ptr(rv), towers_bn["eps"], D * T, H.ptr(scale),
+                                   H.ptr(shift), H.stream()), "swr_bn_eval_coeffs")
+    dom = domain_id.reshape(-1).contiguous()
+    out = torch.empty(y.shape[0], dtype=torch.float32, device=dev)
+    H.check(lib.swr_routed_mmoe_eval(H.ptr(y), y.stride(0), y.shape[0], n_expert, H_, D, T, H.ptr(W1), H.ptr(b1), H.ptr(scale),
+                                     H.ptr(shift), H.ptr(w2), H.ptr(b2), H.ptr(dom), H.dtype_code(dom), H.ptr(out), H.stream()),
+            "swr_routed_mmoe_eval")
+    return out
+
+
+def routed_mmoe_eval_supported(n_expert, H_, D, T):
+    return bool(lib.swr_routed_mmoe_eval_supported(int(n_expert), int(H_), int(D), int(T)))

@@ -737,3 +737,24 @@ def test_fit_with_device_loader_and_device_metrics(tmp_path):
     assert set(state) == set(model.state_dict())
     for k, v in model.state_dict().items():
         assert torch.equal(v.cpu(), state[k]), k
+
+
+@pytest.mark.parametrize("name", ["mmoe", "mmoe_out_of_range_domain", "mmoe_empty_domain", "mmoe_narrow_dtypes", "mmoe_b1000"])
+def test_routed_eval_equals_the_dense_eval_path(name, monkeypatch):
+    """Eval-mode MMoE: the routed head (own gate mix + own tower per row, csrc/routed.hip) against the dense all-domain
+    path + select of the reference, same model and batch: within fp32 reassociation (1e-6 on probabilities), exact 0.0
+    for out-of-range domain ids; both against the reference's golden eval probabilities."""
+    from _golden import Case, build_product_model, to_device, assert_probs_close
+    c = Case(name)
+    model = build_product_model(c).eval()
+    x, _ = c.batch(0)
+    xd = to_device(x)
+    with torch.no_grad():
+        routed = model(xd).cpu().numpy()
+        monkeypatch.setenv("SWR_ROUTED_EVAL", "0")
+        dense = model(xd).cpu().numpy()
+    np.testing.assert_allclose(routed, dense, rtol=0, atol=1e-6)
+    dom = np.asarray(x["domain_indicator"]).astype(np.int64)
+    D = model.domain_num
+    assert np.all(routed[(dom < 0) | (dom >= D)] == 0.0)
+    assert_probs_close(routed, c.z["eval_probs"], tol=1e-4)
