@@ -426,6 +426,11 @@ int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int dim,
                   const int32_t* urow, const float* ugrad, int64_t n_entries,
                   uint32_t* bitmap /* sweep mode, nullable */, int32_t* last /* lazy mode, nullable */,
                   const swr_adam_hyper* hyper_dev, void* stream);
+/* swr_adam_dense + swr_adam_rows (lazy mode) in ONE launch: the common step of one parameter arena + one large table */
+int swr_adam_dense_rows(float* dense_p, const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n,
+                        float* p, float* m, float* v, int64_t vocab, int dim,
+                        const int32_t* urow, const float* ugrad, int64_t n_entries, int32_t* last,
+                        const swr_adam_hyper* hyper_dev, void* stream);
 int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vocab, int dim,
                              uint32_t* bitmap, int clear_bitmap /* 1: zero the bitmap afterwards (normal use) */,
                              const swr_adam_hyper* hyper_dev, void* stream);

@@ -93,6 +93,52 @@ extern "C" int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int di
     return swr_launch_status();
 }
 
+// the two launches above as ONE (the common step: one contiguous parameter arena + one large lazily updated table):
+// workgroups [0, dense_blocks) stream the arena, the rest take the row entries -- at config 2 each launch is pure
+// latency (~5 us), so one fewer is what this saves
+__global__ __launch_bounds__(AD_THREADS) void adam_dense_rows_kernel(float* __restrict__ dp, const float* __restrict__ dg,
+                                                                     float* __restrict__ dm, float* __restrict__ dv, int64_t dn,
+                                                                     int dense_blocks, float* __restrict__ p, float* __restrict__ m,
+                                                                     float* __restrict__ v, int64_t vocab, int dim,
+                                                                     const int32_t* __restrict__ urow, const float* __restrict__ ugrad,
+                                                                     int64_t n_entries, int32_t* __restrict__ last,
+                                                                     const swr_adam_hyper* __restrict__ hp) {
+    const swr_adam_hyper h = *hp;
+    if (static_cast<int>(blockIdx.x) < dense_blocks) {
+        const int64_t stride = static_cast<int64_t>(dense_blocks) * AD_THREADS;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x; i < dn; i += stride) {
+            float pi = dp[i], mi = dm[i], vi = dv[i];
+            adam_elem(pi, dg[i], mi, vi, h);
+            dp[i] = pi; dm[i] = mi; dv[i] = vi;
+        }
+        return;
+    }
+    const int64_t idx = static_cast<int64_t>(blockIdx.x - dense_blocks) * AD_THREADS + threadIdx.x;
+    const int64_t i = idx / dim;
+    if (i >= n_entries) return;
+    const int e = static_cast<int>(idx - i * dim);
+    const int32_t row = urow[i];
+    if (row < 0 || row >= vocab) return;
+    const int64_t o = static_cast<int64_t>(row) * dim + e;
+    float pi = p[o], mi = m[o], vi = v[o];
+    adam_elem(pi, ugrad[i * dim + e], mi, vi, h);
+    p[o] = pi; m[o] = mi; v[o] = vi;
+    if (e == 0) last[row] = static_cast<int32_t>(h.step);
+}
+
+extern "C" int swr_adam_dense_rows(float* dp, const float* dg, float* dm, float* dv, int64_t dn, float* p, float* m, float* v,
+                                   int64_t vocab, int dim, const int32_t* urow, const float* ugrad, int64_t n_entries,
+                                   int32_t* last, const swr_adam_hyper* hyper, void* stream) {
+    SWR_REQUIRE(dp && dg && dm && dv && dn > 0 && p && m && v && urow && ugrad && last && hyper && vocab > 0 && dim > 0 &&
+                    n_entries > 0, SWR_ERR_ARG);
+    const int dense_blocks = static_cast<int>(swr_ceil_div(dn, AD_THREADS) < 4096 ? swr_ceil_div(dn, AD_THREADS) : 4096);
+    const int64_t row_blocks = swr_ceil_div(n_entries * dim, AD_THREADS);
+    hipLaunchKernelGGL(adam_dense_rows_kernel, dim3(static_cast<unsigned>(dense_blocks + row_blocks)), dim3(AD_THREADS), 0,
+                       static_cast<hipStream_t>(stream), dp, dg, dm, dv, dn, dense_blocks, p, m, v, vocab, dim, urow, ugrad,
+                       n_entries, last, hyper);
+    return swr_launch_status();
+}
+
 // every row NOT marked in the bitmap takes g = wd * p (zero data gradient); one wave-slice of 32 rows per
 // bitmap word, the word is cleared after use so the bitmap leaves as it came (all zero)
 __global__ __launch_bounds__(AD_THREADS) void adam_sweep_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,

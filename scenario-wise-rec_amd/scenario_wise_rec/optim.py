@@ -195,6 +195,16 @@ class FusedAdam(torch.optim.Optimizer):
                 print(f"[adam] dense params {len(dense)} runs {[(r[4]) for r in runs]} sparse {len(sparse)} "
                       f"untouched {sum(1 for p in group['params'] if p.grad is not None and not getattr(p, '_swr_touched', True))}",
                       file=sys.stderr, flush=True)
+            if self.lazy_rows and len(runs) == 1 and len(sparse) == 1 and runs[0][4] > 0 and sparse[0][1][0].numel() > 0:
+                # one arena + one large table (config 2): both updates in one launch
+                p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep = runs[0]
+                p, (urow, ugrad) = sparse[0]
+                st = self._lazy_state(p, hist, hyper)
+                H.check(lib.swr_adam_dense_rows(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr), n,
+                                                H.ptr(p), H.ptr(st.m), H.ptr(st.v), p.shape[0], p.shape[1], H.ptr(urow),
+                                                H.ptr(ugrad), urow.numel(), H.ptr(st.last), H.ptr(hyper), stream),
+                        "swr_adam_dense_rows")
+                continue
             for p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep in runs:
                 H.check(lib.swr_adam_dense(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
                                            n, H.ptr(hyper), stream), "swr_adam_dense")
