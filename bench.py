@@ -15,6 +15,7 @@ bounded sample).  N > 1: one process per GPU (torch.distributed, backend nccl = 
 weak scaling (65 536 rows per GPU).
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -99,10 +100,11 @@ def build_model(cfg, seed=2024):
     dense = [DenseFeature(f"d{i}") for i in range(cfg["n_dense"])]
     sparse = [SparseFeature(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
     feats = dense + sparse
+    hyper = copy.deepcopy(cfg["hyper"])    # (the HAMUR constructors append k*k to the caller's hyper_dims, hamur.py:77,288)
     if cfg["family"] == "PPNet":           # id part (user, item) | scenario-agnostic part (ppnet.py:33)
         nid = cfg["id_features"]
-        return md.PPNet(sparse[:nid], dense + sparse[nid:], **cfg["hyper"]), feats
-    return getattr(md, cfg["family"])(feats, **cfg["hyper"]), feats
+        return md.PPNet(sparse[:nid], dense + sparse[nid:], **hyper), feats
+    return getattr(md, cfg["family"])(feats, **hyper), feats
 
 
 def gather_bytes_per_sample(cfg, idx_bytes=8):

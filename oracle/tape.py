@@ -221,8 +221,10 @@ def einsum(spec, *ops):
                 continue
             others = [ops[j].v for j in range(len(ops)) if j != i]
             osubs = [ins[j] for j in range(len(ops)) if j != i]
-            op.acc(np.einsum(",".join([out] + osubs) + "->" + ins[i], g, *others))
-    return Var(np.einsum(spec, *[o.v for o in ops]), tuple(ops), bw)
+            op.acc(np.einsum(",".join([out] + osubs) + "->" + ins[i], g, *others, optimize=True))
+    # optimize=True: pairwise contractions (the same sums in another association; the naive three-operand loop is
+    # O(B m k k n) and takes minutes at HAMUR's BASELINE widths)
+    return Var(np.einsum(spec, *[o.v for o in ops], optimize=True), tuple(ops), bw)
 
 
 # ------------------------------------------------------------------ fused nn

@@ -132,3 +132,34 @@ def build_product_model(case, device="cuda"):
 def to_device(x, device="cuda"):
     import torch
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in x.items()}
+
+
+def perturb_product(model, seed):
+    """Input-sensitive re-initialisation of a product model (the default N(0, 1e-4) embeddings make every model
+    almost constant): the rules of tests/golden/make_golden.py `perturb`, applied by name."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            dev = p.device
+            def put(t):
+                p.copy_(t.to(dev))
+            if "embed_dict" in name:
+                put(torch.randn(p.shape, generator=g) * 0.3)
+            elif name.startswith(("u.", "v.")):
+                put(torch.rand(p.shape, generator=g) * 0.3 + 0.1)
+            elif name.startswith(("share_parm_b", "domain_specific_b.")):
+                put(torch.rand(p.shape, generator=g) * 0.98 + 0.02)
+            elif name.startswith("b_list") or name in ("bias1", "bias2", "dn_share_bias") \
+                    or "dn_bias" in name or (name.endswith(".bias") and p.dim() == 1):
+                sign = (torch.rand(p.shape, generator=g) < 0.5).float() * 2 - 1
+                put(sign * (torch.rand(p.shape, generator=g) * 0.13 + 0.02))
+            elif name in ("gamma1", "gamma2", "dn_share_gamma") or "dn_gamma" in name:
+                put(torch.rand(p.shape, generator=g) + 0.5)
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_((torch.rand(mod.weight.shape, generator=g) + 0.5).to(mod.weight.device))
+                mod.bias.copy_((torch.randn(mod.bias.shape, generator=g) * 0.2).to(mod.bias.device))
+                mod.running_mean.copy_((torch.randn(mod.running_mean.shape, generator=g) * 0.1).to(mod.weight.device))
+                mod.running_var.copy_((torch.rand(mod.running_var.shape, generator=g) + 0.5).to(mod.weight.device))
+    return model

@@ -22,7 +22,20 @@ def _has_gpu():
         return False
 
 
+# Family-level golden parity first, component tests next, multi-process (data-parallel) tests last: under `-x` a
+# failure in a later group cannot hide the results of an earlier one.
+_ORDER = ("test_parity_gpu", "test_baseline_shapes_gpu", "test_ops_gpu", "test_lazy_adam_gpu", "test_graph_gpu")
+
+
+def _group(item):
+    name = item.fspath.basename[:-3]
+    if name == "test_parallel":
+        return len(_ORDER) + 1
+    return _ORDER.index(name) if name in _ORDER else len(_ORDER)
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_group)          # stable: the order inside a file is kept
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

@@ -45,6 +45,21 @@ def numpy_merge_rows(urow, ugrad, vocab):
     return torch.from_numpy(out_r), torch.from_numpy(out_g)
 
 
+def dump_gradients(model):
+    """The gradients the optimizer step consumed: arena views as they are, row lists of the large tables as dense arrays."""
+    out = {}
+    for k, p in model.named_parameters():
+        sg = getattr(p, "_swr_sparse_grad", None)
+        if sg is not None:
+            r, g = sg[0].cpu().numpy(), sg[1].cpu().numpy()
+            full = np.zeros(tuple(p.shape), np.float64)
+            np.add.at(full, r[r >= 0], g[r >= 0].astype(np.float64))
+            out[k] = full.astype(np.float32)
+        elif p.grad is not None and getattr(p, "_swr_touched", True):
+            out[k] = p.grad.cpu().numpy()
+    return out
+
+
 def main():
     mode, name, out_dir = sys.argv[1:4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -102,8 +117,22 @@ def main():
             step.train_step(to_device(x, "cuda:0"), torch.from_numpy(y).cuda())
         torch.cuda.synchronize()
         H.check_errors()
-        if rank == 0:
-            np.savez(os.path.join(out_dir, "state1.npz"), **{k: v.cpu().numpy() for k, v in model.state_dict().items()})
+        # every rank dumps the state it holds and (eager mode) the exchanged gradients the optimizer consumed: the
+        # test compares gradients -- not only the post-Adam state, which sees little more than their signs -- with the
+        # reference's DataParallel result, and checks that all replicas are bitwise equal
+        np.savez(os.path.join(out_dir, "state1.npz" if rank == 0 else f"state1_rank{rank}.npz"),
+                 **{k: v.cpu().numpy() for k, v in model.state_dict().items()})
+        if mode == "full-gpu":
+            np.savez(os.path.join(out_dir, f"grads_rank{rank}.npz"), **dump_gradients(model))
+            # what this rank RECEIVED: every rank's gradient arena (pre-exchange local gradients, by parameter name)
+            xb, arena = step._xb, model.arena()
+            recv = xb["recv_d"].cpu().numpy().reshape(world, -1)
+            names = {id(p): k for k, p in model.named_parameters()}
+            local = {}
+            for p, off, n in arena["spans"]:
+                if p.requires_grad:
+                    local[names[id(p)]] = recv[:, off:off + n].reshape((world,) + tuple(p.shape)).copy()
+            np.savez(os.path.join(out_dir, f"received_rank{rank}.npz"), **local)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -33,8 +33,10 @@ def run_workers(mode, case, world, extra=(), env_extra=None):
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, case, out, *extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    for p, log in zip(procs, logs):
-        assert p.returncode == 0, log[-3000:]
+    failed = [(r, log) for r, (p, log) in enumerate(zip(procs, logs)) if p.returncode != 0]
+    # the rank that failed FIRST is the interesting one: the others die of "Connection closed by peer"
+    failed.sort(key=lambda rl: "Connection closed by peer" in rl[1] or "Connection reset" in rl[1])
+    assert not failed, f"{len(failed)} rank(s) failed; rank {failed[0][0]}:\n{failed[0][1][-3000:]}"
     return out
 
 
@@ -55,8 +57,39 @@ def test_two_ranks_full_hip_step(name, world, limit):
     on cuda:0, gloo) runs the split backward, both all-gathers and the sort-free merge at the world size of a full
     node against the reference's 8-shard DataParallel result."""
     out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),))
-    got = np.load(os.path.join(out, "state1.npz"))
     c = Case(name)
+    # 0. what the ranks sent each other: every rank received the same bytes, and rank r's local gradient arena is the
+    #    oracle's gradient of the local mean loss on shard r (locates a failure: a rank's kernels, or the exchange)
+    from _golden import make_oracle
+    recv = [np.load(os.path.join(out, f"received_rank{r}.npz")) for r in range(world)]
+    for r in range(1, world):
+        for k in recv[0].files:
+            assert np.array_equal(recv[r][k], recv[0][k]), f"rank {r} received different bytes for {k}"
+    x, y = c.batch(0)
+    sh = len(y) // world
+    for r in range(world):
+        _, _, og = make_oracle(c).loss_and_grads({k: v[r * sh:(r + 1) * sh] for k, v in x.items()}, y[r * sh:(r + 1) * sh])
+        for k in recv[0].files:
+            scale = max(1e-6, float(np.abs(og[k]).max()))
+            np.testing.assert_allclose(recv[0][k][r], og[k], rtol=0, atol=2e-4 * scale + 3e-7,
+                                       err_msg=f"local gradient of rank {r}: {k}")
+    # 1. the exchanged gradients (what the optimizer consumed) against the reference's summed replica gradients
+    grads = [np.load(os.path.join(out, f"grads_rank{r}.npz")) for r in range(world)]
+    want = c.group("grad")
+    assert set(grads[0].files) == set(want)
+    for k, g in want.items():
+        scale = max(1e-6, float(np.abs(g).max()))
+        np.testing.assert_allclose(grads[0][k], g, rtol=0, atol=2e-4 * scale + 3e-7, err_msg="grad " + k)
+    # 2. replicas are bitwise equal: gradients and every parameter (BatchNorm running statistics are per shard)
+    states = [np.load(os.path.join(out, "state1.npz" if r == 0 else f"state1_rank{r}.npz")) for r in range(world)]
+    for r in range(1, world):
+        for k in grads[0].files:
+            assert np.array_equal(grads[r][k], grads[0][k]), f"rank {r} gradient {k} differs from rank 0"
+        for k in states[0].files:
+            if "running_" not in k and "num_batches_tracked" not in k:
+                assert np.array_equal(states[r][k], states[0][k]), f"rank {r} state {k} differs from rank 0"
+    # 3. rank 0's state after the step (rank 0's running statistics are the model's, ctr_trainer.py:45-47)
+    got = states[0]
     for k, v in c.group("state1").items():
         if k.endswith("num_batches_tracked"):
             assert int(got[k]) == int(v)
