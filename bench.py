@@ -134,33 +134,31 @@ def time_kernel_events(fn, iters, stream, reps=20):
 
 
 def cpu_baseline(cfg, seconds_budget=20.0):
-    """The numpy oracle (a port of the reference's step, pinned on the reference's outputs) timed on this host:
-    same model shape and tables, a bounded batch, fwd + BCE + bwd + Adam."""
-    from threadpoolctl import threadpool_info
-    from oracle.models import OracleModel
+    """The reference's CPU path restated (oracle/torch_port.py: torch CPU operators on every host core, checked against
+    the numpy oracle and the golden vectors), timed on this box: the SAME model, tables and batch size as the GPU run,
+    fwd + BCE + bwd + dense Adam over every table row, 1 warm-up + >= 3 timed steps."""
     from oracle.nn import Dense, Sparse
-    from oracle.optim import Adam
-    Bc = 8192
-    rng = np.random.default_rng(0)
+    from oracle.torch_port import MMoEPort
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = cfg["batch"]
     feats = [Dense(f"d{i}") for i in range(cfg["n_dense"])] + [Sparse(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
     model, _ = build_model(cfg)
     state = {k: v.detach().numpy() for k, v in model.state_dict().items()}
     del model
-    om = OracleModel(cfg["family"], dict(features=feats, **cfg["hyper"]), state, dtype=np.float32)
-    opt = Adam(lr=1e-3, weight_decay=1e-5)
-    x, y = synth_batch(cfg, Bc, seed=1)
+    port = MMoEPort(feats, cfg["hyper"], state, threads=cores)
+    batches = [synth_batch(cfg, B, seed=1 + j) for j in range(2)]
+    port.step(*batches[0])                      # warm-up (allocations, Adam state for 70 M parameters)
     n, t0 = 0, time.perf_counter()
-    while True:
-        _, _, grads = om.loss_and_grads(x, y)
-        opt.step(om.state, grads)
+    while n < 3 or (time.perf_counter() - t0 < seconds_budget and n < 12):
+        port.step(*batches[n % 2])
         n += 1
-        if time.perf_counter() - t0 > seconds_budget or n >= 8:
-            break
     dt = time.perf_counter() - t0
-    threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    return {"value": n * Bc / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full steps (fwd+BCE+bwd+dense Adam) of the numpy oracle at batch {Bc}, same tables and model; "
-                      f"BLAS on {threads} threads, elementwise numpy single-threaded"}
+    return {"value": n * B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full steps (fwd+BCE+bwd+dense Adam on all {sum(cfg['vocabs'])} table rows) at batch {B} after 1 warm-up step: "
+                      f"torch-CPU port of the reference step (oracle/torch_port.py), torch.set_num_threads({cores})",
+            "reference_in_build_container": {"value": 46800.0, "unit": "samples/s", "cores": 8,
+                                             "note": "the reference itself, same config, 8 vCPU build container (SURVEY.md section 6)"}}
 
 
 def _stage(msg):
@@ -169,15 +167,22 @@ def _stage(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+N_ROTATE = 4      # device-resident batches rotated through the captured step inside the timed region
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the configuration's batch PER GPU (default); strong: that batch is the GLOBAL batch, "
+                         "split by row over the GPUs (65 536 -> 8 192 per GPU at 8)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the stand-alone kernel timing leg")
+    ap.add_argument("--single-batch", action="store_true", help="replay ONE batch (cache-hot rows, no lazy-Adam lag): round-1 behaviour")
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids for the large tables (worst case for the gather)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -194,7 +199,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    # SWR_BENCH_FORCE_DP=1: take the N > 1 code path (process group, exchange step, two graphs) with world size 1 --
+    # SWR_BENCH_FORCE_DP=1: take the N > 1 code path (process group, exchange step, three graphs) with world size 1 --
     # the RCCL call sequence of the multi-GPU run, checkable on a one-GPU box
     use_dp = world > 1 or bool(os.environ.get("SWR_BENCH_FORCE_DP"))
     if use_dp:
@@ -218,22 +223,30 @@ def main():
             if "embed_dict" in n_:
                 p_.requires_grad_(False)
     trainer = CTRTrainer(model, cfg["name"], optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device=str(dev))
+    trainer.use_graph = False              # bench.py drives capture / replay itself
     model.train()
     B = cfg["batch"]
-    xh, yh = synth_batch(cfg, B, seed=2022 + args.config + 1000 * rank, zipf=not args.uniform_ids)
-    x = {k: torch.from_numpy(v).to(dev) for k, v in xh.items()}
-    y = torch.from_numpy(yh).to(dev)
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"strong scaling: batch {B} does not split over {world} GPUs")
+        B //= world                        # rows [rank * B, (rank + 1) * B) of the global batch
+    n_rot = 1 if args.single_batch else N_ROTATE
+    batches = []
+    for j in range(n_rot):
+        xh, yh = synth_batch(cfg, B, seed=2022 + args.config + 1000 * rank + 77 * j, zipf=not args.uniform_ids)
+        batches.append(({k: torch.from_numpy(v).to(dev) for k, v in xh.items()}, torch.from_numpy(yh).to(dev)))
+    x, y = batches[0]
 
     if use_dp:
         from scenario_wise_rec.parallel import DataParallelStep
         stepper = DataParallelStep(trainer, world)
-        step_fn = lambda: stepper.train_step(x, y)
+        step_fn = stepper.train_step
     else:
-        step_fn = lambda: trainer.train_step(x, y)
+        step_fn = trainer.train_step
 
     # ---- warm-up (eager), then capture the step into hipGraph(s) ------------------------------------------
-    # 1 GPU: the whole step is ONE graph.  N GPUs: forward+backward and merge+optimizer are two graphs with the
-    # one RCCL all-gather issued eagerly in between (parallel.DataParallelStep).
+    # 1 GPU: the whole step is ONE graph.  N GPUs: three graphs with the two RCCL all-gathers and the row merge issued
+    # eagerly in between (parallel.DataParallelStep).
     graph = None
     if not args.no_graph:
         try:
@@ -252,49 +265,76 @@ def main():
             torch.cuda.synchronize()
     if graph is None:
         for _ in range(max(1, args.warmup)):
-            step_fn()
+            step_fn(x, y)
         torch.cuda.synchronize()
     H.check_errors()
-    run = graph.replay if graph is not None else step_fn
-    for _ in range(2):
-        run()
+
+    def run(i):
+        """One step on batch i % n_rot: the batch is copied into the captured input buffers (ONE launch for all columns,
+        trainers/graph.py load_batch) and the graph replayed -- the per-step work of the drop-in loop."""
+        xb, yb = batches[i % n_rot]
+        if graph is None:
+            return step_fn(xb, yb)
+        if n_rot > 1:
+            graph.load(xb, yb)
+        return graph.replay()
+
+    def timed(n_steps, first):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            loss = run(first + i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, loss
+
+    for i in range(2 * n_rot):                 # every batch through the captured step once before timing
+        run(i)
     _stage("pre-timed replays")
 
     # ---- timed region: exactly K steps between barrier + synchronize ------------------------------------
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, loss = timed(args.steps, 0)
     H.check_errors()
     final_loss = float(loss.detach())
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    # beside it (NOT the reported value): the same K steps replaying ONE batch -- every row it touches is cache-hot and
+    # the lazy Adam never has a row lagging (what round 1 reported)
+    single_ms = None
+    if graph is not None and n_rot > 1:
+        n_rot_saved, n_rot = n_rot, 1
+        run(0)
+        dts, _ = timed(args.steps, 0)
+        single_ms = dts / args.steps * 1e3
+        n_rot = n_rot_saved
 
     if rank != 0:
         return
-    ms = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel (see DESIGN.md "Measurement") ------------------------------------
     print(f"[bench] timed region done: {ms:.3f} ms/step", file=sys.stderr, flush=True)
-    roof = None if (args.no_roofline or args.config != 2) else measure_roofline(cfg, model, trainer, x, dev, args.steps)
+    roof = None
+    if not args.no_roofline:
+        roof = measure_roofline(cfg, model, trainer, x, dev, args.steps, B) if args.config == 2 else \
+            gather_roofline(cfg, model, x, dev, args.steps, B)
     out = {
         "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X" if args.config == 2
                   else "train samples/sec, " + cfg["name"],
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "global_batch": world * B, "per_gpu_batch": B,
                    "step": "fwd+BCE+bwd+Adam(all params; dense-Adam semantics on every table row, applied lazily but exactly)", "parallelism": f"dp{world}",
-                   "ids": "uniform" if args.uniform_ids else "zipf1.05(video_id)+uniform", "hipgraph": graph is not None,
+                   "ids": "uniform" if args.uniform_ids else "zipf1.05(large tables)+uniform", "hipgraph": graph is not None,
+                   "batches_rotated": n_rot, "ms_per_step_single_batch_replayed": single_ms,
                    "final_loss": final_loss},
         "roofline": roof,
     }
@@ -303,40 +343,76 @@ def main():
     print(json.dumps(out))
 
 
-def measure_roofline(cfg, model, trainer, x, dev, iters):
-    """Longest single kernel of the step at this config (profiles/): the weight-gradient product of the stacked
-    expert + gate layer, dW[148, 516] = dZ^T[148, B] @ E[B, 516] (reduction over the batch).  It runs on the bf16 MFMA
-    with every fp32 operand split into three bf16 terms and the six significant cross products accumulated in fp32
-    (`gemm_tn_x6_kernel`, csrc/gemm.hip): algorithmic flops of that algorithm = 6 * 2 * B * 148 * 516 bf16 flops, peak =
-    the dense bf16 MFMA rate (2.5 PFLOP/s).  `fp32_equivalent_tflops` = 2 * B * 148 * 516 / t, comparable with the f32-MFMA
-    peak of 157.3 TFLOP/s.  Timed live with HIP events on the launch stream over graph-captured launches of the product
-    alone (kernel + its small fixed-order partial-tile reduction)."""
+def measure_roofline(cfg, model, trainer, x, dev, iters, B):
+    """The three big products of the step (stacked expert + gate layer, [B, 516] x [516, 148]) and the gather.
+
+    Primary entry = the longest kernel of the step, the weight-gradient product dW[148, 516] = dZ^T[148, B] @ E[B, 516]
+    (`gemm_tn_x6_kernel` + its fixed-order partial-tile reduction).  `achieved` / `frac` use SURVEY.md 8(d)'s ALGORITHMIC
+    flops, 2 * B * N * K, against the dense bf16 MFMA peak.  The kernel computes each fp32 product as six bf16 MFMA
+    products (3-way operand split, fp32 accumulate: the 1e-4 logit bar rules plain bf16 out), so the matrix pipes issue
+    6x that: `mfma_issue_util` = 6 * 2BNK / t / peak says how busy they are; `hbm_frac` prices the same launch against
+    the HBM roofline (algorithmic bytes 4 B (N + K) / t / 8 TB/s) -- at N = 148 the product moves 174 MB for 10 GFLOP
+    (58 flop/B, far below the ~300 flop/B ridge), so HBM is the roofline that can bind and the MFMA fraction of an ideal
+    (HBM-bound) kernel would be 0.14.  Timed live with HIP events on the launch stream over graph-captured launches."""
     from scenario_wise_rec import ops
-    B = cfg["batch"]
     fs, e, fd = len(cfg["vocabs"]), cfg["embed_dim"], cfg["n_dense"]
     k0 = fs * e + fd
     hyp = cfg["hyper"]
     n1 = hyp["n_expert"] * hyp["expert_params"]["dims"][0] + hyp["domain_num"] * hyp["n_expert"]
     g = torch.Generator(device=dev).manual_seed(1)
-    dZ = torch.randn(B, n1, device=dev, generator=g)
-    E = torch.randn(B, (k0 + 3) // 4 * 4, device=dev, generator=g)[:, :k0]
+    ld = (k0 + 3) // 4 * 4
+    # four operand sets (4 x 174 MB > the 256 MB Infinity Cache): repeated launches do not replay one cache-resident set
+    sets = [(torch.randn(B, n1, device=dev, generator=g), torch.randn(B, ld, device=dev, generator=g)[:, :k0]) for _ in range(4)]
+    W = torch.randn(n1, k0, device=dev, generator=g) * 0.05
+    Wt = W.t().contiguous()
+    bias = torch.zeros(n1, device=dev)
     dW = torch.empty(n1, k0, device=dev)
     db = torch.empty(n1, device=dev)
+    Z = torch.empty(B, n1, device=dev)
+    dX = torch.empty(B, ld, device=dev)
+    parts = torch.empty(((B + 31) // 32, n1, 2), device=dev)
     stream = torch.cuda.Stream()
-    ms = time_kernel_events(lambda: ops.gemm_tn(dZ, E, dW, B, n1, k0, colsum=db), max(10, iters), stream)
+    st = {"i": 0}
+
+    def nxt():
+        st["i"] += 1
+        return sets[st["i"] % 4]
+
+    def f_tn():
+        dZ, E = nxt()
+        ops.gemm_tn(dZ, E, dW, B, n1, k0, colsum=db)
+
+    def f_fwd():
+        _dZ, E = nxt()
+        ops.gemm("nt", E, W, Z, B, n1, k0, bias=bias, stat_partials=parts)
+
+    def f_dx():
+        dZ, _E = nxt()
+        ops.gemm("nt", dZ, Wt, dX, B, k0, n1, n_compute=fs * e)
+
     x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f" and os.environ.get("SWR_TN_X6", "1") != "0"
-    flops32 = 2.0 * B * n1 * k0
-    flops = 6.0 * flops32 if x6 else flops32
+    flops = 2.0 * B * n1 * k0
+    nbytes = 4.0 * B * (n1 + k0)
     peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
-    achieved = flops / (ms * 1e-3) / 1e12
+
+    def entry(kname, fn, pmc_name):
+        ms = time_kernel_events(fn, max(10, iters), stream)
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                "mfma_issue_util": (6.0 if x6 else 1.0) * tf / peak,
+                "mfma_dtype": "bf16 x 6 products per fp32 product (3-way operand split, fp32 accumulate)" if x6 else "f32",
+                "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_name)}
+
     kname = "gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"
-    return {"kernel": kname + " (+tn_reduce_kernel)", "bound": "mfma", "achieved": achieved, "peak": peak,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic("void %s<5" % kname),
-            "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)",
-            "algorithmic_bytes_per_launch": 4.0 * B * (n1 + k0),
-            "algorithmic_flops_per_launch": flops, "mfma_dtype": "bf16 (3-way split of fp32 operands, fp32 accumulate)" if x6 else "f32",
-            "fp32_equivalent_tflops": flops32 / (ms * 1e-3) / 1e12, "avg_launch_ms": ms,
-            "also": {"embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters)}}
+    roof = entry(kname + " (+tn_reduce_kernel)", f_tn, "void %s<" % kname)
+    roof["traffic_unit"] = "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)"
+    roof["also"] = {
+        "gemm_rows_x6_kernel(forward)": entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd, "void gemm_rows_x6_kernel<5"),
+        "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W)", f_dx, "void gemm_rows_x6_kernel<6"),
+        "embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters, B),
+    }
+    return roof
 
 
 def pmc_traffic(kernel):
@@ -354,10 +430,14 @@ def pmc_traffic(kernel):
         return None
 
 
-def gather_roofline(cfg, model, x, dev, iters):
+def gather_roofline(cfg, model, x, dev, iters, B):
     """HBM roofline of K1 (the north star's >= 50 % target): algorithmic bytes per sample
     F_s (idx + 4 E) + 4 F_d + 4 K0 over the measured launch time of the fused lookup."""
-    feats = model.features
+    from scenario_wise_rec.basic.layers import fused_lookup
+    if hasattr(model, "embedding"):
+        lookup = lambda b: model.embedding(b, model.features, squeeze_dim=True)
+    else:                                         # PPNet: id + agnostic groups in one fused lookup (ppnet.py:51-54)
+        lookup = lambda b: fused_lookup(b, [(model.id_embedding, model.id_features), (model.agn_embedding, model.agn_features, True)])
     stream = torch.cuda.Stream()
     lazies = {}
     for p in model.parameters():                  # time the gather kernel alone: no lazy-row catch-up launches
@@ -366,12 +446,12 @@ def gather_roofline(cfg, model, x, dev, iters):
             del p._swr_lazy
     # four different batches with their own output buffers (4 x 135 MB + table rows > the 256 MB Infinity Cache), so
     # repeated launches do not measure a cache-resident replay of one batch
-    batches = [x] + [{k: torch.from_numpy(v).to(dev) for k, v in synth_batch(cfg, cfg["batch"], seed=900 + j)[0].items()}
+    batches = [x] + [{k: torch.from_numpy(v).to(dev) for k, v in synth_batch(cfg, B, seed=900 + j)[0].items()}
                      for j in range(3)]
     state = {"i": 0, "keep": []}
 
     def launch():
-        state["keep"].append(model.embedding(batches[state["i"] % 4], feats, squeeze_dim=True))
+        state["keep"].append(lookup(batches[state["i"] % 4]))
         state["keep"] = state["keep"][-4:]
         state["i"] += 1
     try:
@@ -380,7 +460,7 @@ def gather_roofline(cfg, model, x, dev, iters):
     finally:
         for p, st in lazies.items():
             p._swr_lazy = st
-    nbytes = gather_bytes_per_sample(cfg) * cfg["batch"]
+    nbytes = gather_bytes_per_sample(cfg) * B
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,

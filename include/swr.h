@@ -92,6 +92,22 @@ int swr_embed_gather_fwd(const swr_sparse_slot* sparse_host, int n_sparse,
                          int64_t B, float* out, int64_t ld_out,
                          uint32_t* keys_out, uint32_t* err_flag, void* stream);
 
+/* K1 for SequenceFeature columns (reference basic/layers.py:73-87 pooled lookup; InputMask 117-146; Sum / Average /
+ * ConcatPooling 174-228): `idx` is [B, L] (padded id sequences, row-major, type idx_dtype).
+ *   mode 0 sum    : out[b, out_col : +dim] = sum_l m(b,l) W[idx[b,l]]
+ *   mode 1 mean   : the same sum / (count_b + 1e-16)
+ *   mode 2 concat : out[b, out_col + l*dim : +dim] = W[idx[b,l]]   (no mask)
+ * m(b,l) = idx[b,l] != padding_idx when has_pad, else idx[b,l] != -1.  Masked ids are never dereferenced.
+ * `keys_out` ([B*L] uint32, nullable) = looked-up row per position (0 where masked), `wts_out` ([B*L] float, nullable) =
+ * the factor the position's output gradient is scaled with (0 where masked; 1/(count+1e-16) for mean): the backward is
+ * swr_embed_bag_bwd_expand (one gradient row per position: d_rows[(b,l), :] = wts[b,l] * d_out[b, in_col (+ l*dim) : +dim])
+ * followed by swr_embed_bwd over B*L "samples" of one slot (in_col 0, ld = dim). */
+int swr_embed_bag_fwd(const float* weight, int64_t vocab, int dim, const void* idx, int idx_dtype, int64_t B, int L,
+                      int mode, int has_pad, int64_t padding_idx, uint32_t hash_seed, float* out, int64_t ld_out,
+                      int out_col, uint32_t* keys_out, float* wts_out, uint32_t* err_flag, void* stream);
+int swr_embed_bag_bwd_expand(const float* d_out, int64_t ld, int in_col, int dim, int L, int concat, const float* wts,
+                             int64_t B, float* d_rows /* [B*L, dim] */, void* stream);
+
 /* ------------------------------------------------------------------ K3 ----
  * Backward of the lookup: replaces aten::embedding_dense_backward (32 calls
  * per step at the KuaiRand config, each zero-filling [V, E]).
@@ -409,11 +425,13 @@ typedef struct {
     int64_t step;
     float step_size;        /* lr / (1 - beta1^step) */
     float inv_bc2_sqrt;     /* 1 / sqrt(1 - beta2^step) */
-    float one_minus_b1, b2, one_minus_b2, eps_f, wd_f, pad;
+    float one_minus_b1, b2, one_minus_b2, eps_f, wd_f;
+    uint32_t hist_mask;     /* hist_cap - 1 of the last swr_adam_advance (0: no history) */
 } swr_adam_hyper;
 
-/* `hist` (nullable, float [hist_cap][2], device): step s writes its (step_size, inv_bc2_sqrt) to hist[s]; the lazy
- * row updates below replay them. */
+/* `hist` (nullable, float [hist_cap][2], device; hist_cap a power of two): step s writes its (step_size,
+ * inv_bc2_sqrt) to hist[s % hist_cap] -- a ring; the lazy row updates below replay them.  The caller must flush every
+ * lazily updated table (swr_adam_flush) before any of its rows lags hist_cap - 1 steps. */
 int swr_adam_advance(swr_adam_hyper* hyper_dev, float* hist, int64_t hist_cap, void* stream);
 /* dense update of a flat fp32 arena */
 int swr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n,
@@ -499,11 +517,44 @@ int swr_routed_mmoe_eval(const float* Y, int64_t ldy, int64_t M, int n_expert, i
                          const float* w2, const float* b2, const void* domain, int domain_dtype, float* out,
                          void* stream);
 
+/* ------------------------------------------------------------ LayerNorm / block select (M3oE) ----
+ * torch.nn.LayerNorm(N, eps) (+ ReLU) over G side-by-side column groups of X [M, G*N], each group with its own
+ * gamma / beta (vectors of length G*N): the [Linear, LayerNorm, ReLU] blocks and towers of M3oE (reference
+ * models/multi_domain/m3oe.py:49-67,121-128).  Biased variance, eps inside the square root.  `mean` / `rstd` ([M, G],
+ * nullable in eval) are saved for the backward, which recomputes the ReLU mask from X.  Backward: dX (nullable),
+ * dgamma / dbeta (nullable; `accumulate` = 1 adds into them -- gradient arena) as deterministic fixed-order column sums.
+ * Workspace of the backward: swr_layernorm_bwd_workspace_bytes. */
+typedef struct {
+    int64_t M;
+    int32_t G, N, relu, accumulate;
+    float eps;
+    int32_t pad;
+    const float* X; int64_t ldx;
+    const float* gamma; const float* beta;
+    float* Y; int64_t ldy;
+    float* mean; float* rstd;
+    const float* dY; int64_t lddy;
+    float* dX; int64_t lddx;
+    float* dgamma; float* dbeta;
+} swr_layernorm_args;
+int swr_layernorm_fwd(const swr_layernorm_args* a, void* stream);
+size_t swr_layernorm_bwd_workspace_bytes(int64_t M, int G, int N);
+int swr_layernorm_bwd(const swr_layernorm_args* a, void* workspace, size_t workspace_bytes, void* stream);
+/* out[b, 0:H] = V[b, d_b*H : (d_b+1)*H] when 0 <= d_b < D, else zeros (m3oe.py:141-146: the STAR front's
+ * `emb = where(mask_d, output_d, emb)`; exact integer compare on the raw domain id); backward scatters dout into the
+ * owning block of dV and zero-fills the rest. */
+int swr_block_select_fwd(const float* V, int64_t ldv, const void* domain, int dom_dtype, int D, int H, int64_t M,
+                         float* out, int64_t ldo, void* stream);
+int swr_block_select_bwd(const float* dout, int64_t ldo, const void* domain, int dom_dtype, int D, int H, int64_t M,
+                         float* dV, int64_t ldv, void* stream);
+
 /* ------------------------------------------------------------ input columns ----
  * Row permutation of a columnar, device-resident dataset (replaces DataLoader(shuffle=True) over
  * TorchDataset, whose __getitem__ builds one python dict per ROW, utils/data.py:11-22,55): for every column c,
  * dst[c][i] = src[c][perm[i]], i < n_out -- all columns in ONE launch, element sizes 1 / 2 / 4 / 8 bytes.  Byte copy,
- * bit-exact; perm values must lie in [0, n_in) (out-of-range entries are clamped and raise SWR_FLAG_INDEX_OOR). */
+ * bit-exact; perm values must lie in [0, n_in) (out-of-range entries are clamped and raise SWR_FLAG_INDEX_OOR).
+ * `perm` = NULL copies rows [0, n_out) of every column as they are (a batch into the input buffers of a captured step:
+ * one launch for all columns + the label). */
 #define SWR_TAKE_MAX_COLUMNS 96
 typedef struct {
     const void* src;

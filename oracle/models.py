@@ -195,6 +195,50 @@ def hamur_forward(ctx, x, features, domain_num, fcn_dims, hyper_dims, k, large=F
     return _squeeze1(T.select_domain(outs, dom))
 
 
+def _mlp_n(ctx, prefix, x, n_blocks=1):
+    """`Mlp_N` (`m3oe.py:45-67`): [Linear, LayerNorm(eps 1e-5), ReLU] per block at indices 3i..3i+2 of `.domain_specific`."""
+    for i in range(n_blocks):
+        x = T.linear(x, ctx.p(f"{prefix}.domain_specific.{3 * i}.weight"), ctx.p(f"{prefix}.domain_specific.{3 * i}.bias"))
+        x = T.relu(T.layernorm(x, ctx.p(f"{prefix}.domain_specific.{3 * i + 1}.weight"),
+                               ctx.p(f"{prefix}.domain_specific.{3 * i + 1}.bias"), 1e-5))
+    return x
+
+
+def m3oe_forward(ctx, x, features, domain_num, fcn_dims, expert_num, exp_d=1, exp_t=1, bal_d=1, bal_t=1, **_unused):
+    """`M3oE.forward` (`models/multi_domain/m3oe.py:131-198`).  STAR front: per domain `e @ (W_slot[d] * W_shared) +
+    b_slot[d] + b_shared`, rows keep their own domain's result (chain of `where` from zeros, 141-146); star_mlp + skip;
+    gates = softmax(Linear(emb.detach())) (150-151); shared experts gate-mixed by bmm (187); domain experts balanced
+    with the sigmoid scalars `_weight_bal_d`, `_weight_exp_d` (172-178, 187-189); towers Linear-LayerNorm-ReLU-Linear;
+    sigmoid; domain select.  The same in train and eval mode (no BatchNorm)."""
+    dom = x["domain_indicator"]
+    D, ne = domain_num, expert_num
+    n_body = len(fcn_dims) - 3                      # blocks of every expert: fcn_dim[3:] of [input_dim] + fcn_dims
+    e = embedding_layer(ctx, "embedding", x, features)
+    skip = _mlp_n(ctx, "skip_conn", e)
+    outs = []
+    for d in range(D):
+        w = ctx.p(f"slot_weight.{d}") * ctx.p("shared_weight")
+        outs.append(T.matmul(e, w) + ctx.p(f"slot_bias.{d}") + ctx.p("shared_bias"))
+    emb = _mlp_n(ctx, "star_mlp", T.select_domain(outs, dom)) + skip
+    emb_d = T.detach(emb)
+    gates = [T.softmax_rows(T.linear(emb_d, ctx.p(f"gate.{d}.0.weight"), ctx.p(f"gate.{d}.0.bias"))) for d in range(D)]
+    shared = [_mlp_n(ctx, f"expert.{j}", emb, n_body) for j in range(ne)]
+    domexp = [_mlp_n(ctx, f"domain_expert.{d}", emb, n_body) for d in range(D)]
+    wd = T.sigmoid(ctx.p("_weight_bal_d.deep_weights"))
+    we = T.sigmoid(ctx.p("_weight_exp_d.deep_weights"))
+    ys = []
+    for i in range(D):
+        bal = wd * domexp[i]
+        for j in range(D):
+            if j != i:
+                bal = bal + (1 - wd) / (D - 1) * domexp[j]
+        fused = _mix(gates[i], shared) + we * bal
+        t = T.linear(fused, ctx.p(f"tower.{i}.0.weight"), ctx.p(f"tower.{i}.0.bias"))
+        t = T.relu(T.layernorm(t, ctx.p(f"tower.{i}.1.weight"), ctx.p(f"tower.{i}.1.bias"), 1e-5))
+        ys.append(T.sigmoid(T.linear(t, ctx.p(f"tower.{i}.3.weight"), ctx.p(f"tower.{i}.3.bias"))))
+    return _squeeze1(T.select_domain(ys, dom))
+
+
 FORWARDS = {
     "SharedBottom": sharedbottom_forward,
     "MMOE": mmoe_forward,
@@ -202,6 +246,7 @@ FORWARDS = {
     "Star": star_forward,
     "PPNet": ppnet_forward,
     "EPNet": epnet_forward,
+    "M3oE": m3oe_forward,
     "HamurSmall": lambda ctx, x, **kw: hamur_forward(ctx, x, large=False, **kw),
     "HamurLarge": lambda ctx, x, **kw: hamur_forward(ctx, x, large=True, **kw),
 }

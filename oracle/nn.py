@@ -16,13 +16,14 @@ from . import tape as T
 
 Sparse = namedtuple("Sparse", "name vocab_size embed_dim shared_with", defaults=(None,))
 Dense = namedtuple("Dense", "name")
+Seq = namedtuple("Seq", "name vocab_size embed_dim pooling shared_with padding_idx", defaults=("mean", None, None))
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
 def feature_dim(f):
-    return f.embed_dim if isinstance(f, Sparse) else 1
+    return f.embed_dim if isinstance(f, (Sparse, Seq)) else 1
 
 
 class Ctx:
@@ -58,11 +59,35 @@ def embedding_layer(ctx, prefix, x, features):
             owner = f.shared_with if f.shared_with is not None else f.name
             w = ctx.p(f"{prefix}.embed_dict.{owner}.weight")
             sparse.append(T.embedding(w, np.asarray(x[f.name]).astype(np.int64)))
+        elif isinstance(f, Seq):
+            sparse.append(sequence_pooling(ctx, prefix, x, f))
         else:
             dense.append(T.const(np.asarray(x[f.name]).astype(np.float32).astype(ctx.dtype)[:, None]))
     if not sparse and not dense:
         raise ValueError("The input features can note be empty")
     return T.cat1(sparse + dense) if len(sparse) + len(dense) > 1 else (sparse + dense)[0]
+
+
+def sequence_pooling(ctx, prefix, x, f):
+    """SequenceFeature branch of `EmbeddingLayer.forward` (`basic/layers.py:73-87`): embed the padded id matrix
+    [B, L] -> [B, L, E]; mask = ids != padding_idx (ids != -1 without one; `InputMask`, `layers.py:137-140`);
+    sum = bmm(mask, emb) (`SumPooling`, `layers.py:225-228`); mean = sum / (mask.sum + 1e-16) (`AveragePooling`,
+    `layers.py:202-206`); concat keeps [B, L, E], flattened by squeeze_dim (`ConcatPooling`, `layers.py:186-187`)."""
+    ids = np.asarray(x[f.name]).astype(np.int64)
+    if ids.ndim != 2:
+        raise ValueError("sequence feature ids must be (batch_size, seq_len)")
+    owner = f.shared_with if f.shared_with is not None else f.name
+    emb = T.embedding(ctx.p(f"{prefix}.embed_dict.{owner}.weight"), ids)                  # [B, L, E]
+    B, L, E = emb.v.shape
+    if f.pooling == "concat":
+        return T.reshape(emb, (B, L * E))
+    if f.pooling not in ("sum", "mean"):
+        raise ValueError("Sequence pooling method supports only pooling in ['sum', 'mean'], got %s." % f.pooling)
+    mask = (ids != (f.padding_idx if f.padding_idx is not None else -1)).astype(ctx.dtype)
+    pooled = T.sum_axis(emb * T.const(mask[:, :, None]), 1)                               # [B, E]
+    if f.pooling == "mean":
+        pooled = pooled / T.const((mask.sum(axis=1, keepdims=True) + 1e-16).astype(ctx.dtype))
+    return pooled
 
 
 def batchnorm(ctx, prefix, x):

@@ -261,6 +261,22 @@ def batchnorm_eval(x, gamma, beta, rmean, rvar, eps):
     return (x - const(rmean, x.v.dtype)) * scale + beta
 
 
+def layernorm(x, gamma, beta, eps):
+    """torch.nn.LayerNorm over the last dim of x [B, N]: per-row mean, BIASED per-row variance, eps inside the sqrt,
+    elementwise affine (`m3oe.py:59,124` nn.LayerNorm)."""
+    n = x.v.shape[1]
+    mu = x.v.mean(axis=1, keepdims=True)
+    xc = x.v - mu
+    var = (xc * xc).mean(axis=1, keepdims=True)
+    rstd = (1.0 / np.sqrt(var + eps)).astype(x.v.dtype)
+    xhat = xc * rstd
+    def bw(g):
+        gamma.acc((g * xhat).sum(axis=0)); beta.acc(g.sum(axis=0))
+        dh = g * gamma.v
+        x.acc(rstd * (dh - dh.mean(axis=1, keepdims=True) - xhat * (dh * xhat).mean(axis=1, keepdims=True)))
+    return Var(xhat * gamma.v + beta.v, (x, gamma, beta), bw)
+
+
 def select_domain(ys, dom):
     """final = 0; for d: final = where(dom == d, ys[d], final)
     (`mmoe.py:53-55`, `base_example.py:72-74`); ids outside [0, D) give 0.0.

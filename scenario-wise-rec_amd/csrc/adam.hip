@@ -17,14 +17,18 @@ __global__ void adam_advance_kernel(swr_adam_hyper* h, float* hist, int64_t cap)
     h->one_minus_b2 = static_cast<float>(1.0 - h->beta2);
     h->eps_f = static_cast<float>(h->eps);
     h->wd_f = static_cast<float>(h->weight_decay);
-    if (hist && h->step < cap) {             // per-step scalars, replayed later by the lazy row catch-up
-        hist[2 * h->step] = h->step_size;
-        hist[2 * h->step + 1] = h->inv_bc2_sqrt;
+    if (hist) {                              // per-step scalars, replayed later by the lazy row catch-up: a RING of
+        const uint32_t mask = static_cast<uint32_t>(cap - 1);      // `cap` (a power of two) steps -- the host flushes
+        h->hist_mask = mask;                                        // every lazily updated table before a row can lag that far
+        const int64_t slot = h->step & static_cast<int64_t>(mask);
+        hist[2 * slot] = h->step_size;
+        hist[2 * slot + 1] = h->inv_bc2_sqrt;
     }
 }
 
 extern "C" int swr_adam_advance(swr_adam_hyper* hyper, float* hist, int64_t hist_cap, void* stream) {
-    SWR_REQUIRE(hyper != nullptr && (hist == nullptr || hist_cap > 0), SWR_ERR_ARG);
+    SWR_REQUIRE(hyper != nullptr && (hist == nullptr || (hist_cap > 1 && hist_cap <= (1ll << 31) && (hist_cap & (hist_cap - 1)) == 0)),
+                SWR_ERR_ARG);
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), hyper, hist, hist_cap);
     return swr_launch_status();
 }
@@ -177,9 +181,11 @@ extern "C" int swr_adam_sweep_untouched(float* p, float* m, float* v, int64_t vo
 // the same sequence of fp32 operations the sweep would have executed.
 __device__ __forceinline__ void adam_replay(float& p, float& m, float& v, int from, int to, const float* __restrict__ hist,
                                             swr_adam_hyper h) {
+    const uint32_t mask = h.hist_mask;        // ring of mask + 1 steps; the caller guarantees to - from <= mask
     for (int s = from + 1; s <= to; ++s) {
-        h.step_size = hist[2 * s];
-        h.inv_bc2_sqrt = hist[2 * s + 1];
+        const uint32_t slot = static_cast<uint32_t>(s) & mask;
+        h.step_size = hist[2 * slot];
+        h.inv_bc2_sqrt = hist[2 * slot + 1];
         adam_elem(p, 0.f, m, v, h);
     }
 }

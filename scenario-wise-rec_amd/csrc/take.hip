@@ -17,7 +17,7 @@ struct TakeK {
 __global__ __launch_bounds__(TAKE_THREADS) void take_rows_kernel(const TakeK k) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * TAKE_THREADS + threadIdx.x;
     if (i >= k.n_out) return;
-    int64_t r = k.perm[i];
+    int64_t r = k.perm ? k.perm[i] : i;           // no permutation: a straight copy of every column's first n_out rows
     if (r < 0 || r >= k.n_in) {
         if (k.err) atomicOr(k.err, SWR_FLAG_INDEX_OOR);
         r = r < 0 ? 0 : k.n_in - 1;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(TAKE_THREADS) void take_rows_kernel(const TakeK k) 
 
 extern "C" int swr_take_rows(const swr_take_column* columns, int n_columns, const int64_t* perm, int64_t n_in, int64_t n_out,
                              uint32_t* err_flag, void* stream) {
-    SWR_REQUIRE(columns && n_columns > 0 && n_columns <= SWR_TAKE_MAX_COLUMNS && n_in > 0 && n_out >= 0 && (perm || n_out == 0),
+    SWR_REQUIRE(columns && n_columns > 0 && n_columns <= SWR_TAKE_MAX_COLUMNS && n_in > 0 && n_out >= 0 && (perm || n_out <= n_in),
                 SWR_ERR_ARG);
     TakeK k;
     for (int c = 0; c < n_columns; ++c) {

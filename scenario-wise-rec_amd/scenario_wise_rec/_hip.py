@@ -135,11 +135,19 @@ class DpTable(C.Structure):
                 ("out_row", C.c_void_p), ("out_grad", C.c_void_p)]
 
 
+class LayerNormArgs(C.Structure):
+    _fields_ = [("M", C.c_int64), ("G", C.c_int32), ("N", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32),
+                ("eps", C.c_float), ("pad", C.c_int32), ("X", C.c_void_p), ("ldx", C.c_int64), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p)]
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("step", C.c_int64), ("step_size", C.c_float),
                 ("inv_bc2_sqrt", C.c_float), ("one_minus_b1", C.c_float), ("b2", C.c_float),
-                ("one_minus_b2", C.c_float), ("eps_f", C.c_float), ("wd_f", C.c_float), ("pad", C.c_float)]
+                ("one_minus_b2", C.c_float), ("eps_f", C.c_float), ("wd_f", C.c_float), ("hist_mask", C.c_uint32)]
 
 
 # ------------------------------------------------------------------------ signatures
@@ -149,6 +157,8 @@ _SIGS = {
     "swr_status_str": (C.c_char_p, [_I]),
     "swr_device_available": (C.c_int, []),
     "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
+    "swr_embed_bag_fwd": (C.c_int, [_P, _L, _I, _P, _I, _L, _I, _I, _I, _L, C.c_uint32, _P, _L, _I, _P, _P, _P, _P]),
+    "swr_embed_bag_bwd_expand": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _L, _P, _P]),
     "swr_embed_bwd_workspace_bytes": (_Z, [_P, _I, _L]),
     "swr_embed_bwd": (C.c_int, [_P, _I, _P, _P, _L, _L, _P, _Z, _P, _P]),
     "swr_embed_bwd_sort": (C.c_int, [_P, _I, _P, _L, _P, _Z, _P]),
@@ -199,6 +209,11 @@ _SIGS = {
     "swr_routed_mmoe_eval_supported": (C.c_int, [_I, _I, _I, _I]),
     "swr_routed_mmoe_eval": (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "swr_take_rows": (C.c_int, [_P, _I, _P, _L, _L, _P, _P]),
+    "swr_layernorm_fwd": (C.c_int, [_P, _P]),
+    "swr_layernorm_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
+    "swr_layernorm_bwd": (C.c_int, [_P, _P, _Z, _P]),
+    "swr_block_select_fwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _L, _P, _L, _P]),
+    "swr_block_select_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _L, _P, _L, _P]),
     "swr_star_layer_fwd": (C.c_int, [_P, _P]),
     "swr_star_layer_bwd": (C.c_int, [_P, _P]),
     "swr_eval_metrics_workspace_bytes": (_Z, [_L, _I]),

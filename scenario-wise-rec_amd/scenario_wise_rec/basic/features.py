@@ -32,13 +32,14 @@ class SparseFeature(object):
 
 
 class SequenceFeature(SparseFeature):
-    """Multi-hot / behaviour-sequence column.  Declared for API compatibility; the pooled lookup
-    (`basic/layers.py:73-87`) is outside the hot path (no reference script builds one) and
-    EmbeddingLayer rejects it."""
+    """Multi-hot / behaviour-sequence column (reference `basic/features.py:5-46`): ids of shape (batch, seq_len), padded;
+    `pooling` in "sum" / "mean" / "concat".  Positions equal to `padding_idx` (or to -1 when no padding_idx is given) are
+    masked out of the pooled embedding (`basic/layers.py:137-140`).  The lookup is one pooled-gather launch
+    (csrc/embed_bag.hip)."""
 
     def __init__(self, name, vocab_size, embed_dim=None, pooling="mean", shared_with=None, padding_idx=None,
-                 initializer=RandomNormal(0, 0.0001)):
-        super().__init__(name, vocab_size, embed_dim, shared_with, padding_idx, initializer)
+                 initializer=RandomNormal(0, 0.0001), hash_seed=0):
+        super().__init__(name, vocab_size, embed_dim, shared_with, padding_idx, initializer, hash_seed)
         self.pooling = pooling
 
     def __repr__(self):

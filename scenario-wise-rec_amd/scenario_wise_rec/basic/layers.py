@@ -42,8 +42,11 @@ class EmbeddingLayer(SwrModule):
         sparse, dense = [], []
         for fea in features:
             if isinstance(fea, SequenceFeature):
-                raise NotImplementedError("SequenceFeature pooling is outside the MI355X hot path (SURVEY.md 2.1)")
-            if isinstance(fea, SparseFeature):
+                if fea.pooling not in ("sum", "mean", "concat"):
+                    raise ValueError("Sequence pooling method supports only pooling in %s, got %s." %
+                                     (["sum", "mean"], fea.pooling))
+                sparse.append(fea)               # pooled lookup (`layers.py:73-87`): a column block like any sparse feature
+            elif isinstance(fea, SparseFeature):
                 sparse.append(fea)
             else:
                 dense.append(fea)
@@ -58,15 +61,18 @@ class EmbeddingLayer(SwrModule):
         out = _run_plan(plan, weights)
         if squeeze_dim:
             return out
-        dims = {s[3] for s in plan.sparse}
+        if any(b["mode"] == 2 for b in plan.bags):
+            raise NotImplementedError("squeeze_dim=False with pooling='concat' ([B, F, L, E]) is not built")
+        dims = {s[3] for s in plan.sparse} | {b["dim"] for b in plan.bags}
         if len(dims) != 1:
             raise RuntimeError("squeeze_dim=False needs equal embed_dim for all sparse features")
-        return out.reshape(out.shape[0], len(plan.sparse), dims.pop())
+        return out.reshape(out.shape[0], len(plan.sparse) + len(plan.bags), dims.pop())
 
 
 def _new_plan(layer):
     plan = ops._GatherPlan()
     plan.sparse, plan.dense, plan.width = [], [], 0
+    plan.bags = []
     plan.lazy = {}
     plan.dense_limit_bytes = layer.dense_table_limit_bytes
     return plan, []
@@ -85,6 +91,15 @@ def _plan_part(plan, weights, wpos, layer, x, sparse, dense):
             if lazy is not None:
                 plan.lazy[wpos[key]] = lazy
         w = weights[wpos[key]]
+        if isinstance(fea, SequenceFeature):
+            idx = x[fea.name]
+            if idx.dim() != 2:
+                raise ValueError(f"sequence feature {fea.name!r}: expected ids of shape (batch_size, seq_len), got {tuple(idx.shape)}")
+            mode = {"sum": 0, "mean": 1, "concat": 2}[fea.pooling]
+            plan.bags.append({"wpos": wpos[key], "idx": idx, "vocab": w.shape[0], "dim": w.shape[1], "col": col,
+                              "L": idx.shape[1], "mode": mode, "pad": fea.padding_idx, "seed": getattr(fea, "hash_seed", 0)})
+            col += w.shape[1] * (idx.shape[1] if mode == 2 else 1)
+            continue
         plan.sparse.append((wpos[key], x[fea.name], w.shape[0], w.shape[1], col, getattr(fea, "hash_seed", 0)))
         col += w.shape[1]
     for fea in dense:
@@ -99,7 +114,8 @@ def _run_plan(plan, weights):
     out = ops.EmbedGather.apply(plan, *weights)
     # columns that can take a gradient: everything up to the end of the last embedding column (dense-feature columns are
     # inputs).  A layer that reads this tensor need not compute d/dx beyond it (ops.LinearBNAct: `n_compute` of dX).
-    out._swr_grad_cols = max((col + dim for _w, _i, _v, dim, col, _s in plan.sparse), default=0)
+    out._swr_grad_cols = max([col + dim for _w, _i, _v, dim, col, _s in plan.sparse] +
+                             [b["col"] + b["dim"] * (b["L"] if b["mode"] == 2 else 1) for b in plan.bags], default=0)
     return out
 
 
@@ -113,8 +129,8 @@ def fused_lookup(x, parts):
     for part in parts:
         layer, feats = part[0], part[1]
         n0 = len(weights)
-        sparse = [f for f in feats if isinstance(f, SparseFeature)]
-        dense = [f for f in feats if not isinstance(f, SparseFeature)]
+        sparse = [f for f in feats if isinstance(f, (SparseFeature, SequenceFeature))]
+        dense = [f for f in feats if not isinstance(f, (SparseFeature, SequenceFeature))]
         _plan_part(plan, weights, wpos, layer, x, sparse, dense)
         if len(part) > 2 and part[2]:
             weights[n0:] = [w.detach() for w in weights[n0:]]

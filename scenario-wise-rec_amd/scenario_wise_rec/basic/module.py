@@ -87,6 +87,8 @@ class SwrModule(nn.Module):
         i_flat, _ = layout(ibufs, groups, torch.int64)
         self._swr_arena = {"p": p_flat, "g": g_flat, "spans": p_spans, "b": b_flat, "i": i_flat,
                            "big": [p for p in params if id(p) in big]}
+        for p in params:
+            p._swr_row_sparse = id(p) in big       # (optim.FusedAdam.load_state_dict: which state layout the table takes)
         self._install_touch_hooks(params)
         return self
 
@@ -122,6 +124,25 @@ class SwrModule(nn.Module):
     def state_dict(self, *args, **kwargs):
         self.materialize()
         return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        # rows of a lazily updated table that are behind still owe their pending decay-only steps: apply those to the OLD
+        # values first (exact), so that afterwards every row is current and the loaded values are what the next step sees
+        # -- the reference's behaviour when weights are loaded under a live optimizer
+        self.materialize()
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+    def set_dense_table_limit(self, nbytes):
+        """Per-model override of `dense_table_limit_bytes` (tables above it take row-sparse gradients that only
+        optim.FusedAdam consumes); re-homes the arena."""
+        self.materialize()
+        for m in self.modules():
+            if isinstance(m, SwrModule):
+                m.dense_table_limit_bytes = int(nbytes)
+        for p in self.parameters():
+            if getattr(p, "_swr_lazy", None) is not None:
+                raise RuntimeError("set_dense_table_limit after the optimizer created lazy-row state for a table")
+        return self.build_arena()
 
     def zero_grad(self, set_to_none=True):
         a = self.arena()

@@ -317,7 +317,8 @@ def _split_like(flat, tensors):
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags")
+    # bags: SequenceFeature lookups, dicts(wpos, idx [B, L], vocab, dim, col, L, mode 0 sum / 1 mean / 2 concat, pad, seed)
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -337,7 +338,8 @@ class EmbedGather(Function):
     def forward(ctx, plan, *weights):
         # plan.sparse: list of (weight_pos, idx tensor, vocab, dim, out_col, hash_seed); plan.dense: (values, out_col)
         dev = weights[0].device if weights else plan.dense[0][0].device
-        B = (plan.sparse[0][1] if plan.sparse else plan.dense[0][0]).shape[0]
+        bags = getattr(plan, "bags", None) or []
+        B = (plan.sparse[0][1] if plan.sparse else (bags[0]["idx"] if bags else plan.dense[0][0])).shape[0]
         if _late["jobs"]:
             raise H.SwrError("a forward pass with held-back gradient work of the previous backward pending "
                              "(split backward: run_late_jobs() was not called)")
@@ -366,6 +368,25 @@ class EmbedGather(Function):
         flag = H.err_flag(dev)
         H.check(lib.swr_embed_gather_fwd(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), H.ptr(flag), H.stream()),
                 "swr_embed_gather_fwd")
+        # SequenceFeature columns: pooled lookups (csrc/embed_bag.hip), one launch each, into their columns of `out`
+        ctx.bags = []
+        for bag in bags:
+            w, idx = weights[bag["wpos"]], bag["idx"]
+            H.require_device(idx, w)
+            idx = idx.contiguous()
+            lazy = getattr(plan, "lazy", {}).get(bag["wpos"])
+            if lazy is not None:
+                lazy.catchup(idx.reshape(-1) if bag["mode"] == 2 or bag["pad"] is None else
+                             torch.where(idx == bag["pad"], torch.full_like(idx, -1), idx).reshape(-1), bag["seed"])
+            want = w.requires_grad and getattr(plan, "want_grad", False)
+            bkeys = torch.empty(B * bag["L"], dtype=torch.int32, device=dev) if want else None
+            bwts = torch.empty(B * bag["L"], dtype=torch.float32, device=dev) if want else None
+            H.check(lib.swr_embed_bag_fwd(H.ptr(w), bag["vocab"], bag["dim"], H.ptr(idx), H.dtype_code(idx), B, bag["L"],
+                                          bag["mode"], int(bag["pad"] is not None), int(bag["pad"] or 0), bag["seed"],
+                                          H.ptr(out), plan.ld, bag["col"], H.ptr(bkeys), H.ptr(bwts), H.ptr(flag),
+                                          H.stream()), "swr_embed_bag_fwd")
+            if want:
+                ctx.bags.append((bag, bkeys, bwts))
         ctx.plan, ctx.keys, ctx.B = plan, keys, B
         ctx.weights = weights            # identity / shapes only
         ctx.presorted = None
@@ -394,10 +415,20 @@ class EmbedGather(Function):
     @once_differentiable
     def backward(ctx, dE):
         plan, B, weights = ctx.plan, ctx.B, ctx.weights
-        if ctx.keys is None or B == 0 or ctx.n_grad_slots == 0:
+        no_plain = ctx.keys is None or ctx.n_grad_slots == 0
+        if B == 0 or (no_plain and not ctx.bags):
             return (None,) + tuple(None if not w.requires_grad else torch.zeros_like(w) for w in weights)
         dE = H.f32c(dE)
         dev = dE.device
+        if no_plain:
+            grads, sparse_out = [None] * len(weights), {}
+            EmbedGather._bags_backward(ctx, dE, grads, sparse_out)
+            for wpos, (urow, ugrad) in sparse_out.items():
+                if getattr(weights[wpos], "_swr_sparse_grad", None) is not None:
+                    raise H.SwrError("a row-sparse table gradient is already pending (backward() twice without zero_grad())")
+                weights[wpos]._swr_sparse_grad = (urow, ugrad)
+                weights[wpos]._swr_sparse_local = True
+            return (None,) + tuple(None if isinstance(g, tuple) else g for g in grads)
         # tables: dense gradient when small, row-sparse entries when large; sparse tables take the largest ids
         live, uses, table_id = _grad_slot_layout(plan, weights, ctx.n_grad_slots)
         grads = [None] * len(weights)
@@ -450,8 +481,15 @@ class EmbedGather(Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             H.check(lib.swr_embed_bwd(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
                                       H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd")
+        if ctx.bags:
+            EmbedGather._bags_backward(ctx, dE, grads, sparse_out)
         for wpos, (urow, ugrad) in sparse_out.items():
             # row-sparse gradient of a large table: consumed by FusedAdam (optim.py); `.grad` stays None
+            if getattr(weights[wpos], "_swr_sparse_grad", None) is not None:
+                raise H.SwrError("a row-sparse table gradient is already pending (a second lookup of the same large table in "
+                                 "one backward pass, or backward() twice without zero_grad()): row lists do not accumulate "
+                                 "-- use one fused lookup per step, or raise dense_table_limit_bytes "
+                                 "(SwrModule.set_dense_table_limit)")
             weights[wpos]._swr_sparse_grad = (urow, ugrad)
             weights[wpos]._swr_sparse_local = True     # every row listed was looked up (and caught up) by THIS forward
         for i, g in enumerate(grads):
@@ -459,6 +497,50 @@ class EmbedGather(Function):
                 weights[i]._swr_touched = True
                 grads[i] = None
         return (None,) + tuple(grads)
+
+    @staticmethod
+    def _bags_backward(ctx, dE, grads, sparse_out):
+        """SequenceFeature lookups: one gradient row per looked-up position (scaled by the pooling weight, 0 where
+        masked), then the ordinary K3 over B * L "samples" of one slot.  Runs after the plain slots' K3: a table shared
+        with a plain lookup (`shared_with`) accumulates into the same dense gradient."""
+        plan, B, weights = ctx.plan, ctx.B, ctx.weights
+        dev = dE.device
+        for bag, bkeys, bwts in ctx.bags:
+            wpos, dim, L = bag["wpos"], bag["dim"], bag["L"]
+            w = weights[wpos]
+            n = B * L
+            rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+            H.check(lib.swr_embed_bag_bwd_expand(H.ptr(dE), dE.stride(0), bag["col"], dim, L, int(bag["mode"] == 2), H.ptr(bwts),
+                                                 B, H.ptr(rows), H.stream()), "swr_embed_bag_bwd_expand")
+            slot = (H.EmbedGradSlot * 1)()
+            merge_with = None
+            if w.numel() * 4 > plan.dense_limit_bytes:
+                urow = torch.empty(n, dtype=torch.int32, device=dev)
+                ugrad = torch.empty((n, dim), dtype=torch.float32, device=dev)
+                slot[0] = H.EmbedGradSlot(bag["vocab"], dim, 0, 0, 1, None, urow.data_ptr(), ugrad.data_ptr())
+                merge_with = sparse_out.get(wpos)          # the table's row list from its plain lookups / an earlier bag
+                sparse_out[wpos] = (urow, ugrad)
+            else:
+                g = grads[wpos]
+                if g is None:
+                    direct = _grad_alias([w], 4)
+                    g = grads[wpos] = ("direct", direct) if direct is not None else torch.zeros_like(w, memory_format=torch.contiguous_format)
+                target = g[1] if isinstance(g, tuple) else g
+                if isinstance(g, tuple):
+                    w._swr_touched = True
+                slot[0] = H.EmbedGradSlot(bag["vocab"], dim, 0, 0, 2, target.data_ptr(), None, None)
+            nbytes = lib.swr_embed_bwd_workspace_bytes(slot, 1, n)
+            if nbytes == 0:
+                raise H.SwrError("swr_embed_bwd: unsupported SequenceFeature shape (batch x length above 2^24)")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            H.check(lib.swr_embed_bwd(slot, 1, H.ptr(bkeys), H.ptr(rows), dim, n, H.ptr(ws), nbytes, H.ptr(H.err_flag(dev)),
+                                      H.stream()), "swr_embed_bwd(bag)")
+            if merge_with is not None:
+                # a row-sparse table with several lookups: the lists are merged into one with every row listed once
+                # (the optimizer's row kernel applies one Adam update per listed row)
+                from .parallel import hip_merge_rows
+                urow, ugrad = sparse_out[wpos]
+                sparse_out[wpos] = hip_merge_rows(torch.cat([merge_with[0], urow]), torch.cat([merge_with[1], ugrad]), bag["vocab"])
 
 
 # =========================================================================== Linear (+BN) (+act)
@@ -1327,3 +1409,111 @@ def routed_mmoe_eval(y, n_expert, H_, towers_w1, towers_b1, towers_bn, towers_w2
 
 def routed_mmoe_eval_supported(n_expert, H_, D, T):
     return bool(lib.swr_routed_mmoe_eval_supported(int(n_expert), int(H_), int(D), int(T)))
+
+
+# =========================================================================== LayerNorm (+ReLU), block select  (M3oE)
+class LayerNormAct(Function):
+    """torch.nn.LayerNorm(N, eps) (+ ReLU) over G side-by-side column groups of x [M, G*N], each with its own gamma / beta
+    (reference `m3oe.py:49-67` Mlp_N blocks, `:121-128` towers); csrc/layernorm.hip.  params = G gammas + G betas."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        G, N, relu, eps = cfg["G"], cfg["N"], cfg["relu"], cfg["eps"]
+        H.require_device(x, params[0])
+        x = H.f32c(x)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        M = x.shape[0]
+        dev = x.device
+        gamma, beta = _cat_params(params[:G]), _cat_params(params[G:])
+        y = torch.empty((M, G * N), dtype=torch.float32, device=dev)
+        want = any(ctx.needs_input_grad[1:])
+        mean = torch.empty((M, G), dtype=torch.float32, device=dev) if want else None
+        rstd = torch.empty((M, G), dtype=torch.float32, device=dev) if want else None
+        a = H.LayerNormArgs()
+        a.M, a.G, a.N, a.relu, a.eps = M, G, N, int(relu), eps
+        a.X, a.ldx, a.gamma, a.beta = x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr()
+        a.Y, a.ldy = y.data_ptr(), G * N
+        a.mean, a.rstd = (mean.data_ptr(), rstd.data_ptr()) if want else (None, None)
+        H.check(lib.swr_layernorm_fwd(C.byref(a), H.stream()), "swr_layernorm_fwd")
+        ctx.cfg, ctx.params = cfg, params
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        cfg = ctx.cfg
+        G, N = cfg["G"], cfg["N"]
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        M = x.shape[0]
+        dev = x.device
+        dy = H.f32c(dy)
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        p_g, p_b = ctx.params[:G], ctx.params[G:]
+        dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_b, 2)
+        direct = dgamma is not None and dbeta is not None
+        if not direct:
+            dgamma = torch.empty(G * N, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(G * N, dtype=torch.float32, device=dev)
+        dx = torch.empty((M, G * N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        a = H.LayerNormArgs()
+        a.M, a.G, a.N, a.relu, a.eps, a.accumulate = M, G, N, int(cfg["relu"]), cfg["eps"], int(direct)
+        a.X, a.ldx, a.gamma, a.beta = x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr()
+        a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+        a.dY, a.lddy = dy.data_ptr(), dy.stride(0)
+        a.dX, a.lddx = (dx.data_ptr(), G * N) if dx is not None else (None, 0)
+        a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+        nbytes = lib.swr_layernorm_bwd_workspace_bytes(M, G, N)
+        if nbytes == 0:
+            raise H.SwrError("swr_layernorm: unsupported width")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        H.check(lib.swr_layernorm_bwd(C.byref(a), H.ptr(ws), nbytes, H.stream()), "swr_layernorm_bwd")
+        if direct:
+            _mark_touched(tuple(p_g) + tuple(p_b))
+            return (None, dx) + (None,) * (2 * G)
+        return (None, dx) + tuple(_split_like(dgamma, p_g)) + tuple(_split_like(dbeta, p_b))
+
+
+def layer_norm_act(x, norms, relu=True):
+    """`norms`: G nn.LayerNorm modules of equal width applied to the G column groups of x."""
+    n0 = norms[0]
+    cfg = {"G": len(norms), "N": int(n0.normalized_shape[0]), "relu": bool(relu), "eps": float(n0.eps)}
+    return LayerNormAct.apply(cfg, x, *[n.weight for n in norms], *[n.bias for n in norms])
+
+
+class BlockSelect(Function):
+    """out[b] = V[b, d_b*H : (d_b+1)*H] for 0 <= d_b < D, else zeros (`m3oe.py:141-146`)."""
+
+    @staticmethod
+    def forward(ctx, V, domain, D, Hh):
+        H.require_device(V, domain)
+        V = H.f32c(V)
+        if V.stride(1) != 1:
+            V = V.contiguous()
+        domain = domain.contiguous()
+        M = V.shape[0]
+        out = torch.empty((M, Hh), dtype=torch.float32, device=V.device)
+        H.check(lib.swr_block_select_fwd(H.ptr(V), V.stride(0), H.ptr(domain), H.dtype_code(domain), D, Hh, M, H.ptr(out), Hh,
+                                         H.stream()), "swr_block_select_fwd")
+        ctx.dims = (M, D, Hh)
+        ctx.save_for_backward(domain)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (domain,) = ctx.saved_tensors
+        M, D, Hh = ctx.dims
+        dout = H.f32c(dout)
+        if dout.stride(1) != 1:
+            dout = dout.contiguous()
+        dV = torch.empty((M, D * Hh), dtype=torch.float32, device=dout.device)
+        H.check(lib.swr_block_select_bwd(H.ptr(dout), dout.stride(0), H.ptr(domain), H.dtype_code(domain), D, Hh, M, H.ptr(dV),
+                                         D * Hh, H.stream()), "swr_block_select_bwd")
+        return dV, None, None, None
+
+
+def block_select(V, domain, D, Hh):
+    return BlockSelect.apply(V, domain, int(D), int(Hh))

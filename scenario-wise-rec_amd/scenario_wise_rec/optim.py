@@ -10,6 +10,7 @@ optimizer, `trainers/ctr_trainer.py:50-52,73`) as HBM-streaming HIP kernels.
     (`grad is None`: no decay, no state), e.g. PPNet's agnostic tables;
   * step count and bias corrections live in device memory (a captured hipGraph replays correctly).
 """
+import bisect
 import ctypes as C
 import os
 import sys
@@ -20,7 +21,8 @@ from . import _hip as H
 from ._hip import lib
 
 
-HIST_CAP = 1 << 20          # steps of (step_size, inv_bc2_sqrt) history kept on the device (8 MB)
+HIST_CAP = 1 << 20          # steps of (step_size, inv_bc2_sqrt) history kept on the device (8 MB): a ring -- every
+                            # lazily updated table is flushed (exactly) before a row could lag that many steps
 _EARLY_ADVANCED = set()     # hyper buffers whose step counter was advanced ahead of step() (advance_early)
 
 
@@ -58,10 +60,14 @@ class LazyRows(object):
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_rows=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_rows=True, hist_cap=HIST_CAP):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.lazy_rows = lazy_rows
+        if hist_cap < 4 or hist_cap & (hist_cap - 1):
+            raise ValueError("hist_cap must be a power of two >= 4")
+        self.hist_cap = int(hist_cap)
+        self._since_flush = 0   # optimizer steps (eager or replayed) since every lazy table was last fully current
         self._hyper = {}        # group index -> [device swr_adam_hyper, uploaded host copy, hist, host step count]
         self._mv = {}           # storage ptr -> (m_flat, v_flat) shadowing a parameter storage
         self._big = {}          # id(param) -> (m, v, bitmap)   (sweep mode)  |  LazyRows  (lazy mode)
@@ -74,7 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
         if ent is None:
             h = H.AdamHyper(*want, 0)
             buf = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).to(device)
-            hist = torch.zeros((HIST_CAP, 2), dtype=torch.float32, device=device) if self.lazy_rows else None
+            hist = torch.zeros((self.hist_cap, 2), dtype=torch.float32, device=device) if self.lazy_rows else None
             self._hyper[gi] = [buf, want, hist, 0]
         elif ent[1] != want:
             if self.lazy_rows and ent[1][1:] != want[1:]:
@@ -113,13 +119,14 @@ class FusedAdam(torch.optim.Optimizer):
         if len(self.param_groups) != 1 or 0 not in self._hyper or getattr(self, "_advanced", False):
             return
         ent = self._hyper[0]
-        if self.lazy_rows and ent[3] + 2 >= HIST_CAP:
-            return
+        if self.lazy_rows and self._since_flush + 3 >= self.hist_cap:
+            return                                             # step() flushes the lazy tables first, then advances
         hyper = self._hyper_dev(0, self.param_groups[0], ent[0].device)
         hist = ent[2]
-        H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, H.stream()),
+        H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), self.hist_cap if hist is not None else 0, H.stream()),
                 "swr_adam_advance")
         ent[3] += 1
+        self._since_flush += 1
         self._advanced = True
         _EARLY_ADVANCED.add(hyper.data_ptr())
 
@@ -129,6 +136,29 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self._big.values():
             if isinstance(st, LazyRows):
                 st.flush()
+        self._since_flush = 0
+
+    @torch.no_grad()
+    def note_replays(self, n=1):
+        """Called by whoever replays a captured step (trainers/graph.py, parallel.DataParallelStep) BEFORE the replay:
+        the device-side step counter advances inside the graph where the host cannot see it.  Keeps the host's step
+        count right (state_dict) and flushes the lazily updated tables in-stream before the history ring wraps."""
+        if self.lazy_rows and self._since_flush + n + 2 >= self.hist_cap:
+            self.materialize()
+        self._since_flush += n
+        for gi, ent in self._hyper.items():
+            ent[3] += n
+            self._hyper_dev(gi, self.param_groups[gi], ent[0].device)      # a scheduler's new lr reaches the device scalars
+
+    def host_counts(self):
+        """Host-side step bookkeeping (a capture runs step() on the host without executing it: snapshot / restore)."""
+        return (self._since_flush, {gi: ent[3] for gi, ent in self._hyper.items()}, getattr(self, "_advanced", False))
+
+    def restore_host_counts(self, snap):
+        self._since_flush = snap[0]
+        for gi, n in snap[1].items():
+            self._hyper[gi][3] = n
+        self._advanced = snap[2]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -160,15 +190,17 @@ class FusedAdam(torch.optim.Optimizer):
                         self._lazy_state(p, hist, hyper).catchup(urow)
                     else:
                         self._lazy_state(p, hist, hyper)       # (state must exist before the row kernel)
-                if ent[3] + 2 >= HIST_CAP:
-                    raise H.SwrError("FusedAdam: step history full; call materialize() and rebuild the optimizer")
             if gi == 0 and getattr(self, "_advanced", False):
                 self._advanced = False                         # advance_early() already did it for this step
                 _EARLY_ADVANCED.discard(hyper.data_ptr())
             else:
-                H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), HIST_CAP if hist is not None else 0, stream),
+                if self.lazy_rows and gi == 0 and self._since_flush + 3 >= self.hist_cap:
+                    self.materialize()                         # the history is a ring: no row may lag hist_cap - 1 steps
+                H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), self.hist_cap if hist is not None else 0, stream),
                         "swr_adam_advance")
                 ent[3] += 1
+                if gi == 0:
+                    self._since_flush += 1
             # contiguous runs: parameter, gradient and state addresses all advance together
             items = []
             for p in dense:
@@ -180,13 +212,21 @@ class FusedAdam(torch.optim.Optimizer):
                 m, v, key = self._state_for(p)
                 items.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), key, g))
             items.sort(key=lambda t: t[0])
+            # parameters of this optimizer that are NOT updated this step (no gradient / untouched / frozen): a run must
+            # not sweep over them (torch skips them entirely: no decay, no state)
+            updated = {it[0] for it in items}
+            blockers = sorted(q.data_ptr() for g2 in self.param_groups for q in g2["params"] if q.data_ptr() not in updated)
             runs = []
             for it in items:
                 if runs:
                     r = runs[-1]
-                    gap = it[0] - (r[0] + 4 * r[4])
-                    # merge across alignment padding (zeros with zero gradient: the update is a no-op there)
-                    if (0 <= gap <= 64 and it[5] == r[5] and it[1] - r[1] == it[0] - r[0] and it[2] - r[2] == it[0] - r[0]):
+                    end = r[0] + 4 * r[4]
+                    gap = it[0] - end
+                    j = bisect.bisect_left(blockers, end)
+                    clear = j >= len(blockers) or blockers[j] >= it[0]
+                    # merge across the arena's alignment padding only (< 16 bytes of zeros with zero gradient and zero
+                    # state: the update is a no-op there) and never across another parameter
+                    if (0 <= gap < 16 and clear and it[5] == r[5] and it[1] - r[1] == it[0] - r[0] and it[2] - r[2] == it[0] - r[0]):
                         r[4] = (it[0] - r[0]) // 4 + it[4]
                         r[6].append(it[6])
                         continue
@@ -224,3 +264,83 @@ class FusedAdam(torch.optim.Optimizer):
                 H.check(lib.swr_adam_sweep_untouched(H.ptr(p), H.ptr(m), H.ptr(v), p.shape[0], p.shape[1], H.ptr(bitmap), 1,
                                                      H.ptr(hyper), stream), "swr_adam_sweep_untouched")
         return loss
+
+    # ---- checkpointing: torch.optim.Adam's format (state[i] = {step, exp_avg, exp_avg_sq}) ----------------------
+    def _state_views(self, p):
+        """(m, v) of parameter p if it has optimizer state, else None."""
+        st = self._big.get(id(p))
+        if isinstance(st, LazyRows):
+            return st.m, st.v
+        if st is not None:
+            return st[0], st[1]
+        key = p.untyped_storage().data_ptr()
+        if key in self._mv:
+            m, v, _ = self._state_for(p)
+            return m.view(p.shape), v.view(p.shape)
+        return None
+
+    @torch.no_grad()
+    def state_dict(self):
+        """The layout of `torch.optim.Adam.state_dict()`: interchangeable with the reference's optimizer.  Lazily updated
+        tables are materialised first (exact).  The step count is per parameter group here (parameters that never took
+        a gradient have no entry, like torch)."""
+        self.materialize()
+        sd = super().state_dict()          # param_groups with packed indices; `state` is empty (kept outside self.state)
+        state, i = {}, 0
+        for gi, group in enumerate(self.param_groups):
+            steps = self._hyper[gi][3] if gi in self._hyper else 0
+            for p in group["params"]:
+                mv = self._state_views(p) if steps else None
+                if mv is not None:
+                    state[i] = {"step": torch.tensor(float(steps)), "exp_avg": mv[0].detach().clone(),
+                                "exp_avg_sq": mv[1].detach().clone()}
+                i += 1
+        sd["state"] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(g["params"]) != len(h["params"]) for g, h in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has different parameter groups")
+        self.materialize()
+        i = 0
+        for gi, (src, group) in enumerate(zip(groups, self.param_groups)):
+            for k, val in src.items():
+                if k != "params":
+                    group[k] = val
+            steps = set()
+            for p in group["params"]:
+                ent = sd["state"].get(i, sd["state"].get(str(i)))
+                i += 1
+                if ent is None:
+                    continue
+                steps.add(int(float(ent["step"])))
+                big = getattr(p, "_swr_row_sparse", False) or getattr(p, "_swr_lazy", None) is not None
+                if big and self.lazy_rows:
+                    hyper = self._hyper_dev(gi, group, p.device)
+                    st = self._lazy_state(p, self._hyper[gi][2], hyper)
+                    m, v = st.m, st.v
+                elif big:
+                    if id(p) not in self._big:
+                        self._big[id(p)] = (torch.zeros_like(p), torch.zeros_like(p),
+                                            torch.zeros((p.shape[0] + 31) // 32, dtype=torch.int32, device=p.device))
+                    m, v = self._big[id(p)][:2]
+                else:
+                    m, v, _ = self._state_for(p)
+                    m, v = m.view(p.shape), v.view(p.shape)
+                m.copy_(ent["exp_avg"].to(p.device, torch.float32))
+                v.copy_(ent["exp_avg_sq"].to(p.device, torch.float32))
+            if len(steps) > 1:
+                raise H.SwrError("FusedAdam keeps one step count per parameter group; the loaded state has several: %s" % sorted(steps))
+            if steps:
+                n = steps.pop()
+                dev = next(p.device for p in group["params"])
+                hyper = self._hyper_dev(gi, group, dev)
+                hyper[40:48].copy_(torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(dev))     # swr_adam_hyper.step
+                self._hyper[gi][3] = n
+                for st in self._big.values():
+                    if isinstance(st, LazyRows) and st.hyper.data_ptr() == hyper.data_ptr():
+                        st.last.fill_(n)            # every row is current as of the loaded step
+        self._since_flush = 0
+        self._advanced = False

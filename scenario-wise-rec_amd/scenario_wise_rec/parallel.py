@@ -276,16 +276,26 @@ class DataParallelStep(object):
 
     # ---- captured variant -----------------------------------------------------------------------------
     def capture(self, x_dict, y, warmup=2):
-        """Static input buffers + three captured graphs.  Feed batches with `load`, run with `replay`."""
+        """Static input buffers + three captured graphs.  Feed batches with `load`, run with `replay`.  `warmup` eager
+        steps on (x, y) first (>= 2 when no step of this shape has run yet); the capture itself executes nothing."""
         self.x = {k: v.clone() for k, v in x_dict.items()}
         self.y = y.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                self.train_step(self.x, self.y)          # results dropped at once (see trainers/graph.py)
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup > 0:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.train_step(self.x, self.y)      # results dropped at once (see trainers/graph.py)
+            torch.cuda.current_stream().wait_stream(side)
+        elif getattr(self, "_xb", None) is None:
+            # warmup=0: the caller has run (two) ordinary steps of this shape already -- they established the exchange
+            # buffers and pointed the large tables' backward at its slots of the rows message
+            raise ops.H.SwrError("DataParallelStep.capture(warmup=0) needs earlier train_step() calls of the same batch shape")
         torch.cuda.synchronize()
+        opt = self.trainer.optimizer
+        if hasattr(opt, "hist_cap") and 2 * opt._since_flush >= opt.hist_cap:
+            opt.materialize()
+        snap = opt.host_counts() if hasattr(opt, "host_counts") else None
         g1 = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events while this thread captures; in the default (global) mode
         # that poll would invalidate the capture
@@ -310,6 +320,8 @@ class DataParallelStep(object):
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             self._mean_dense(xb, arena["g"])
             self.trainer.optimizer.step()
+        if snap is not None:
+            opt.restore_host_counts(snap)      # the capture ran the optimizer's host code without executing a step
         self._graphs = (g1, g1b, g2, xb)
         self._big, self._arena_g = big, arena["g"]
         self._merge_stream = torch.cuda.Stream()
@@ -317,13 +329,14 @@ class DataParallelStep(object):
         return self
 
     def load(self, x_dict, y):
-        for k, v in x_dict.items():
-            self.x[k].copy_(v, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
+        from .trainers.graph import load_batch
+        load_batch(self.x, self.y, x_dict, y)
 
     def replay(self):
         g1, g1b, g2, xb = self._graphs
         cur = torch.cuda.current_stream()
+        if hasattr(self.trainer.optimizer, "note_replays"):
+            self.trainer.optimizer.note_replays(1)
         g1.replay()
         rows = bool(xb["offs"])
         if rows:                                                                # the row lists leave now ...

@@ -4,8 +4,20 @@
 The training step is the reference's (to(device) -> forward -> BCE -> zero_grad -> backward ->
 optimizer step, `ctr_trainer.py:62-77`) on the HIP path: fused model forward/backward (ops.py), fused BCE,
 FusedAdam.  `torch.optim.Adam` (the reference default) is mapped to FusedAdam, which implements the same
-update; any other `optimizer_fn` is used as given.  The per-step `loss.item()` host sync of the reference
-(`:74`) is kept only at `log_interval` boundaries.
+update; any other `optimizer_fn` is used as given (every table then takes a dense gradient).  The per-step
+`loss.item()` host sync of the reference (`:74`) is kept only at `log_interval` boundaries.
+
+hipGraph: `train_one_epoch` launches the first two batches of a shape eagerly, captures the step on the third
+(trainers/graph.py) and from then on copies each batch into the captured input buffers and replays -- one graph
+launch per step instead of ~40-150 kernel launches; a batch of another shape (the ragged tail of an epoch) runs
+eagerly.  Every batch is applied exactly once either way, bit-identical to eager (tests/test_graph_gpu.py).
+`SWR_TRAINER_GRAPH=0` or `trainer.use_graph = False` turns it off.
+
+`gpus=[...]` (the reference wraps the model in single-process nn.DataParallel, `ctr_trainer.py:45-47`): here one
+process per GPU -- launch the unchanged script under `python -m torch.distributed.run --nproc-per-node N`; every
+process builds the same model and DataLoader (same seed), rank r trains on its row chunk of every batch
+(`torch.chunk` semantics, like DataParallel's scatter) through parallel.DataParallelStep: per-shard BatchNorm
+statistics, global-mean loss, summed gradients, rank 0's running statistics.
 """
 import os
 import time
@@ -35,16 +47,19 @@ class CTRTrainer(object):
         if gpus is None:
             gpus = []
         self.gpus = gpus
-        if len(gpus) > 1:
-            # the reference wraps the model in single-process nn.DataParallel here (`ctr_trainer.py:45-47`);
-            # the MI355X build is one process per GPU over RCCL instead: see scenario_wise_rec.parallel
-            raise NotImplementedError("multi-GPU runs use one process per GPU: scenario_wise_rec.parallel.DataParallelStep")
+        self._dp = None
         self.device = torch.device(device)
+        if len(gpus) > 1:
+            self.device = self._init_data_parallel(gpus)
         self.model.to(self.device)
         if optimizer_params is None:
             optimizer_params = {"lr": 1e-3, "weight_decay": 1e-5}
         if optimizer_fn is torch.optim.Adam and not optimizer_params.get("amsgrad", False):
             optimizer_fn = FusedAdam
+        if not (isinstance(optimizer_fn, type) and issubclass(optimizer_fn, FusedAdam)) and hasattr(self.model, "set_dense_table_limit"):
+            # any other optimizer reads `.grad`: every table takes a dense gradient in the arena (the reference's
+            # behaviour, nn.Embedding sparse=False); row-sparse gradients are a FusedAdam-only representation
+            self.model.set_dense_table_limit(1 << 62)
         self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         self.scheduler = None
         if scheduler_fn is not None:
@@ -54,6 +69,44 @@ class CTRTrainer(object):
         self.n_epoch = n_epoch
         self.early_stopper = EarlyStopper(patience=earlystop_patience)
         self.model_path = model_path
+        self.use_graph = os.environ.get("SWR_TRAINER_GRAPH", "1") != "0"
+        self._graph = None            # captured step (GraphedStep, or the DataParallelStep after capture)
+        self._eager_sig, self._eager_run = None, 0
+        if len(gpus) > 1:
+            from ..parallel import DataParallelStep
+            self._dp = DataParallelStep(self, self._world)
+
+    # ---- gpus=[...]: one process per GPU (`ctr_trainer.py:45-47` is single-process nn.DataParallel) -------------
+    def _init_data_parallel(self, gpus):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) != len(gpus):
+                raise RuntimeError(
+                    f"CTRTrainer(gpus={list(gpus)}): the MI355X build runs one process per GPU over RCCL.  Launch the same "
+                    f"script with `python -m torch.distributed.run --nnodes=1 --nproc-per-node {len(gpus)} "
+                    f"--master-addr 127.0.0.1 <script>`; every process then trains on its row chunk of each batch "
+                    f"(WORLD_SIZE must equal len(gpus)).")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(os.environ.get("SWR_DP_BACKEND", "nccl"), rank=int(os.environ["RANK"]),
+                                    world_size=int(os.environ["WORLD_SIZE"]))
+        if dist.get_world_size() != len(gpus):
+            raise RuntimeError(f"CTRTrainer(gpus={list(gpus)}) under a process group of {dist.get_world_size()} ranks")
+        self._world, self._rank = dist.get_world_size(), dist.get_rank()
+        dev = torch.device("cuda", int(gpus[self._rank]))
+        torch.cuda.set_device(dev)
+        return dev
+
+    def _my_rows(self, x_dict, y):
+        """This rank's chunk of a batch: `torch.chunk(dim 0)` like DataParallel's scatter (equal chunks required: the
+        exchange averages the ranks' gradients with equal weights)."""
+        B = y.shape[0]
+        if B % self._world:
+            raise ValueError(f"batch of {B} rows does not split evenly over {self._world} GPUs (use drop_last or a batch "
+                             f"size divisible by the number of GPUs)")
+        n = B // self._world
+        lo = self._rank * n
+        return {k: v[lo:lo + n] for k, v in x_dict.items()}, y[lo:lo + n]
 
     # ---- one optimisation step (`ctr_trainer.py:67-73`) ---------------------------------------------
     def forward_backward(self, x_dict, y):
@@ -78,6 +131,15 @@ class CTRTrainer(object):
         return loss
 
     def train_step(self, x_dict, y):
+        if self._dp is not None and not getattr(self._dp, "_inside", False):
+            self._dp._inside = True
+            try:
+                return self._dp.train_step(x_dict, y)
+            finally:
+                self._dp._inside = False
+        return self._local_step(x_dict, y)
+
+    def _local_step(self, x_dict, y):
         if hasattr(self.optimizer, "advance_early") and os.environ.get("SWR_EARLY_ADVANCE", "1") != "0":
             ops.add_side_job(self.optimizer.advance_early)      # the step-counter launch leaves the critical path too
         loss = self.forward_backward(x_dict, y)
@@ -96,15 +158,46 @@ class CTRTrainer(object):
         total_loss = None
         tk0 = tqdm.tqdm(data_loader, desc="train", smoothing=0, mininterval=1.0)
         for i, (x_dict, y) in enumerate(tk0):
-            x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
-            y = y.to(self.device, non_blocking=True)
-            loss = self.train_step(x_dict, y).detach()
+            if self._dp is not None:
+                x_dict, y = self._my_rows(x_dict, y)
+            loss = self._step_maybe_graphed(x_dict, y)
             total_loss = loss if total_loss is None else total_loss + loss
             if (i + 1) % log_interval == 0:
                 tk0.set_postfix(loss=total_loss.item() / log_interval)      # the only host sync of the loop
                 H.check_errors()
                 total_loss = None
         H.check_errors()
+
+    def _graph_ok(self):
+        from ..optim import FusedAdam as _FA
+        return (self.use_graph and self.device.type == "cuda" and isinstance(self.optimizer, _FA)
+                and hasattr(self.model, "arena") and self.model.arena() is not None and self.model.training)
+
+    def _step_maybe_graphed(self, x_dict, y):
+        """One batch, applied exactly once: replay of the captured step when the batch has the captured shape; capture
+        after two consecutive eager steps of one shape; eager otherwise (first batches, ragged tail).  -> detached loss"""
+        from .graph import GraphedStep, batch_signature
+        if not self._graph_ok():
+            x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
+            return self.train_step(x_dict, y.to(self.device, non_blocking=True)).detach()
+        sig = batch_signature(x_dict, y)
+        g = self._graph
+        if g is not None and g.signature == sig:
+            g.load(x_dict, y)                              # host or device batch -> the captured input buffers
+            return g.replay()
+        x_dev = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
+        y_dev = y.to(self.device, non_blocking=True)
+        if g is None and self._eager_sig == sig and self._eager_run >= 2:
+            if self._dp is not None:
+                self._dp.signature = sig
+                g = self._graph = self._dp.capture(x_dev, y_dev, warmup=0)
+            else:
+                g = self._graph = GraphedStep(self, x_dev, y_dev, warmup=0, step_fn=self._local_step)
+            return g.replay()
+        loss = self.train_step(x_dev, y_dev).detach()
+        self._eager_run = self._eager_run + 1 if self._eager_sig == sig else 1
+        self._eager_sig = sig
+        return loss
 
     def fit(self, train_dataloader, val_dataloader=None):
         for epoch_i in range(self.n_epoch):
@@ -123,7 +216,9 @@ class CTRTrainer(object):
                     break
         time_now = time.strftime('%m_%d_%H_%M', time.localtime(int(round(time.time() * 1000)) / 1000))
         name = self.model.__class__.__name__ + "_" + self.data_set_type + "_" + time_now + ".pth"
-        torch.save(self.model.state_dict(), os.path.join(self.model_path, name))
+        state = self.model.state_dict()
+        if self._dp is None or self._rank == 0:         # replicas are identical; rank 0's running statistics are the model's
+            torch.save(state, os.path.join(self.model_path, name))
 
     def _forward_all(self, model, data_loader, desc, with_domain=False):
         model.eval()

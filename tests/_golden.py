@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 from oracle.models import OracleModel
-from oracle.nn import Dense, Sparse
+from oracle.nn import Dense, Seq, Sparse
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -56,8 +56,15 @@ def state_atol(case, key, n_steps):
 
 
 def oracle_features(schema):
-    return [Sparse(f["name"], f["vocab_size"], f["embed_dim"]) if f["kind"] == "sparse" else Dense(f["name"])
-            for f in schema]
+    out = []
+    for f in schema:
+        if f["kind"] == "sparse":
+            out.append(Sparse(f["name"], f["vocab_size"], f["embed_dim"], f.get("shared_with")))
+        elif f["kind"] == "sequence":
+            out.append(Seq(f["name"], f["vocab_size"], f["embed_dim"], f["pooling"], f.get("shared_with"), f.get("padding_idx")))
+        else:
+            out.append(Dense(f["name"]))
+    return out
 
 
 def oracle_hyper(case):
@@ -102,9 +109,17 @@ def assert_probs_close(got, want, tol=1e-4):
 
 # ------------------------------------------------------------------ product model from a golden case
 def product_features(schema):
-    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
-    return [SparseFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"]) if f["kind"] == "sparse"
-            else DenseFeature(f["name"]) for f in schema]
+    from scenario_wise_rec.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    out = []
+    for f in schema:
+        if f["kind"] == "sparse":
+            out.append(SparseFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"], shared_with=f.get("shared_with")))
+        elif f["kind"] == "sequence":
+            out.append(SequenceFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"], pooling=f["pooling"],
+                                       shared_with=f.get("shared_with"), padding_idx=f.get("padding_idx")))
+        else:
+            out.append(DenseFeature(f["name"]))
+    return out
 
 
 def build_product_model(case, device="cuda"):

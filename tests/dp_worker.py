@@ -60,6 +60,34 @@ def dump_gradients(model):
     return out
 
 
+def take_turns_on_the_gpu(step, tr, lock_path):
+    """8 processes sharing ONE GPU are time-sliced by the driver (queue oversubscription, wave save / restore in the
+    middle of kernels, concurrent code-object loads) -- a regime the product never runs in (one process per GPU) and
+    in which ~3 % of runs on the test pool die with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in some rank.  The 8-rank test
+    is about the world-8 ARITHMETIC (split backward, two all-gathers, merge of 8 row lists, rank-ordered mean), so its
+    ranks take turns: every GPU phase of the step runs under a cross-process file lock and drains before releasing
+    it; the collectives run outside the lock.  The 2-rank tests stay unserialised (stream-ordering coverage)."""
+    import fcntl
+    from scenario_wise_rec import ops
+
+    def guarded(fn):
+        def run(*a, **k):
+            with open(lock_path, "w") as f:
+                fcntl.flock(f, fcntl.LOCK_EX)
+                try:
+                    r = fn(*a, **k)
+                    torch.cuda.synchronize()
+                    return r
+                finally:
+                    fcntl.flock(f, fcntl.LOCK_UN)
+        return run
+    step._forward_backward = guarded(step._forward_backward)
+    step._merge_rows = guarded(step._merge_rows)
+    step._mean_dense = guarded(step._mean_dense)
+    tr.optimizer.step = guarded(tr.optimizer.step)
+    ops.run_late_jobs = guarded(ops.run_late_jobs)
+
+
 def main():
     mode, name, out_dir = sys.argv[1:4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -95,14 +123,40 @@ def main():
         from scenario_wise_rec.parallel import DataParallelStep
         from scenario_wise_rec.trainers import CTRTrainer
         from scenario_wise_rec.basic.module import SwrModule
-        if len(sys.argv) > 4:
+        if len(sys.argv) > 4 and mode != "trainer-gpu":
             SwrModule.dense_table_limit_bytes = int(sys.argv[4])     # force the row-sparse path for the larger tables
+        if mode == "trainer-gpu":
+            SwrModule.dense_table_limit_bytes = 2048
+            os.environ["SWR_DP_BACKEND"] = "gloo"
         torch.cuda.set_device(0)
+        if mode == "trainer-gpu":
+            # the reference's multi-GPU entry, CTRTrainer(gpus=[...]) (ctr_trainer.py:45-47): every process gets the WHOLE
+            # batch from its (identical) loader and trains on its row chunk; 4 epochs over a one-batch loader = two eager
+            # steps, the capture, one more replay
+            model = build_product_model(case, device="cpu")
+            tr = CTRTrainer(model, "dp", optimizer_params={"lr": case.meta["lr"], "weight_decay": case.meta["weight_decay"]},
+                            gpus=[0] * world, n_epoch=1)
+            tr.use_graph = os.environ.get("DP_EAGER_REFERENCE") is None
+            xf, yf = case.batch(0)
+            loader = [({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in xf.items()}, torch.from_numpy(yf))]
+            model.train()
+            n_epochs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+            for _ in range(n_epochs):
+                tr.train_one_epoch(loader)
+            torch.cuda.synchronize()
+            H.check_errors()
+            np.savez(os.path.join(out_dir, "state1.npz" if rank == 0 else f"state1_rank{rank}.npz"),
+                     **{k: v.cpu().numpy() for k, v in model.state_dict().items()})
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         model = build_product_model(case, device="cuda:0")
         tr = CTRTrainer(model, "dp", optimizer_params={"lr": case.meta["lr"], "weight_decay": case.meta["weight_decay"]},
                         device="cuda:0")
         step = DataParallelStep(tr, world)
         model.train()
+        if os.environ.get("DP_TAKE_TURNS"):
+            take_turns_on_the_gpu(step, tr, os.path.join(out_dir, "gpu.lock"))
         if mode == "graph-gpu":
             # two captured graphs + eager collectives; the captured step must land where the eager one does.
             # capture() runs 2 eager warm-up steps, so compare after 3 steps in total on the same batch.

@@ -37,9 +37,9 @@ sys.path.insert(0, "/root/reference")
 import numpy as np
 import torch
 
-from scenario_wise_rec.basic.features import DenseFeature, SparseFeature  # noqa: E402  (reference)
+from scenario_wise_rec.basic.features import DenseFeature, SequenceFeature, SparseFeature  # noqa: E402  (reference)
 from scenario_wise_rec.models.multi_domain import (  # noqa: E402  (reference)
-    MMOE, PLE, EPNet, HamurLarge, HamurSmall, PPNet, SharedBottom, Star)
+    MMOE, PLE, EPNet, HamurLarge, HamurSmall, M3oE, PPNet, SharedBottom, Star)
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 LR, WD = 1e-3, 1e-5
@@ -57,7 +57,10 @@ def build_features(schema):
     out = []
     for f in schema:
         if f["kind"] == "sparse":
-            out.append(SparseFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"]))
+            out.append(SparseFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"], shared_with=f.get("shared_with")))
+        elif f["kind"] == "sequence":
+            out.append(SequenceFeature(f["name"], vocab_size=f["vocab_size"], embed_dim=f["embed_dim"], pooling=f["pooling"],
+                                       shared_with=f.get("shared_with"), padding_idx=f.get("padding_idx")))
         else:
             out.append(DenseFeature(f["name"]))
     return out
@@ -71,6 +74,14 @@ def make_batch(rng, schemas, B, domain_num, idx_dtype=np.int64, dense_dtype=np.f
             if f["kind"] == "sparse":
                 x[f["name"]] = rng.integers(0, f["vocab_size"], size=B).astype(
                     idx_dtype if f["vocab_size"] <= np.iinfo(idx_dtype).max else np.int64)
+            elif f["kind"] == "sequence":
+                # padded id sequences [B, L]: random lengths 0..L (some rows empty), the tail filled with the padding id
+                L, pad = f["seq_len"], f.get("padding_idx")
+                ids = rng.integers(1 if pad == 0 else 0, f["vocab_size"], size=(B, L))
+                if pad is not None:
+                    lens = rng.integers(0, L + 1, size=B)
+                    ids[np.arange(L)[None, :] >= lens[:, None]] = pad
+                x[f["name"]] = ids.astype(idx_dtype if f["vocab_size"] <= np.iinfo(idx_dtype).max else np.int64)
             else:
                 x[f["name"]] = rng.random(B).astype(dense_dtype)
     dom = rng.integers(0, domain_num, size=B)
@@ -105,7 +116,12 @@ def perturb(model, seed):
                 p.copy_(sign * (torch.rand(p.shape, generator=g) * 0.13 + 0.02))
             elif name in ("gamma1", "gamma2", "dn_share_gamma") or "dn_gamma" in name:
                 p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif name.startswith(("slot_bias", "shared_bias")):                 # M3oE STAR-front biases (zeros by default)
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
         for mod_name, mod in model.named_modules():
+            if isinstance(mod, torch.nn.LayerNorm):
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.2)
             if isinstance(mod, torch.nn.BatchNorm1d):
                 mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
                 mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.2)
@@ -233,6 +249,15 @@ def main():
     run_case("mmoe_b1000", "MMOE", ctor, hyper, [sch], 5, B=1000, seed=5)
     run_dp_case("mmoe_dp2", ctor, hyper, [sch], 5, n_shards=2, seed=6)
     run_dp_case("mmoe_dp8", ctor, hyper, [sch], 5, n_shards=8, seed=7)
+    # SequenceFeature pooled lookups (`basic/layers.py:73-87`): mean with padding id 0 sharing the table of sparse s2,
+    # sum with its own table and padding id 3, mean without padding_idx (every position counts), next to plain features
+    # (pooling="concat" yields [B, L*E] per feature, which no in-scope model's input_dim = sum(embed_dim) accepts)
+    sch_seq = sch + [
+        {"kind": "sequence", "name": "h_mean", "vocab_size": sch[2]["vocab_size"], "embed_dim": 16, "pooling": "mean",
+         "shared_with": "s2", "padding_idx": 0, "seq_len": 7},
+        {"kind": "sequence", "name": "h_sum", "vocab_size": 50, "embed_dim": 16, "pooling": "sum", "padding_idx": 3, "seq_len": 5},
+        {"kind": "sequence", "name": "h_all", "vocab_size": 30, "embed_dim": 16, "pooling": "mean", "seq_len": 4}]
+    run_case("mmoe_seq", "MMOE", lambda: MMOE(build_features(sch_seq), **hyper), hyper, [sch_seq], 5, seed=9)
     # two-layer experts and towers (stacked BN blocks)
     hyper2 = {"domain_num": 3, "n_expert": 3, "expert_params": {"dims": [24, 12]}, "tower_params": {"dims": [8, 4]}}
     run_case("mmoe_deep", "MMOE", lambda: MMOE(build_features(sch), **hyper2), hyper2, [sch], 3, seed=8)
@@ -275,6 +300,14 @@ def main():
     hyper = {"domain_num": 2, "fcn_dims": [64, 48, 40, 32, 24, 16, 12], "hyper_dims": [16], "k": 4}
     run_case("hamur_large", "HamurLarge",
              lambda: HamurLarge(build_features(sch5), 2, [64, 48, 40, 32, 24, 16, 12], [16], 4), hyper, [sch5], 2, seed=52)
+
+    # ---- M3oE: STAR front + MMoE body + domain experts, LayerNorm blocks
+    sch6 = make_schema(rng, 5, 16, 2)
+    hyper = {"domain_num": 4, "fcn_dims": [64, 32, 32, 16], "expert_num": 3, "exp_d": 1, "exp_t": 1, "bal_d": 1, "bal_t": 1}
+    run_case("m3oe", "M3oE", lambda: M3oE(build_features(sch6), **hyper), hyper, [sch6], 4, seed=61)
+    hyper = {"domain_num": 3, "fcn_dims": [48, 24, 24, 20, 12], "expert_num": 2, "exp_d": 0.5, "exp_t": 1, "bal_d": -0.3, "bal_t": 1}
+    run_case("m3oe_deep_out_of_range", "M3oE", lambda: M3oE(build_features(sch6), **hyper), hyper, [sch6], 3, seed=62,
+             out_of_range=True)
 
 
 if __name__ == "__main__":

@@ -758,3 +758,69 @@ def test_routed_eval_equals_the_dense_eval_path(name, monkeypatch):
     D = model.domain_num
     assert np.all(routed[(dom < 0) | (dom >= D)] == 0.0)
     assert_probs_close(routed, c.z["eval_probs"], tol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,dim,pooling,pad,idx_dtype,limit", [
+    (250, 7, 16, "sum", 0, np.int64, 1 << 30), (1000, 5, 8, "mean", 3, np.int16, 1 << 30), (64, 12, 32, "mean", None, np.int32, 1 << 30),
+    (333, 3, 6, "sum", 2, np.int64, 1 << 30),        # dim not a multiple of 4: scalar path
+    (129, 4, 16, "concat", None, np.int64, 1 << 30), (700, 9, 16, "mean", 0, np.int64, 1024)])      # last: row-sparse table
+def test_sequence_pooled_lookup(B, L, dim, pooling, pad, idx_dtype, limit, monkeypatch):
+    """SequenceFeature lookup (basic/layers.py:73-87) next to a plain sparse and a dense feature: sum / mean pooling with
+    masked padding (fp32 sums vs an fp64 reference), concat = pure copy (bit-exact); backward = masked, scaled scatter of the
+    pooled gradient into the table (vs np.add.at in fp64), including rows that are entirely padding."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    from scenario_wise_rec.basic.module import SwrModule
+    monkeypatch.setattr(SwrModule, "dense_table_limit_bytes", limit)
+    rng = np.random.default_rng(B + L)
+    V = 120
+    feats = [SparseFeature("s0", 17, dim), SequenceFeature("h", V, dim, pooling=pooling, padding_idx=pad), DenseFeature("d0")]
+    layer = EmbeddingLayer(feats)
+    t_s0 = rng.standard_normal((17, dim)).astype(np.float32)
+    t_h = rng.standard_normal((V, dim)).astype(np.float32)
+    with torch.no_grad():
+        layer.embed_dict["s0"].weight.copy_(torch.from_numpy(t_s0))
+        layer.embed_dict["h"].weight.copy_(torch.from_numpy(t_h))
+    layer.to("cuda")
+    ids = rng.integers(0, V, size=(B, L))
+    if pad is not None and pooling != "concat":
+        lens = rng.integers(0, L + 1, size=B)
+        ids = np.where(ids == pad, (pad + 1) % V, ids)
+        ids[np.arange(L)[None, :] >= lens[:, None]] = pad
+    x = {"s0": rng.integers(0, 17, size=B), "h": ids.astype(idx_dtype), "d0": rng.random(B).astype(np.float32)}
+    out = layer({k: _dev(v) for k, v in x.items()}, feats, squeeze_dim=True)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(_dev(g))
+    torch.cuda.synchronize()
+    H.check_errors()
+    emb = t_h.astype(np.float64)[ids]                                        # [B, L, dim]
+    if pooling == "concat":
+        pooled, wts = emb.reshape(B, L * dim), np.ones((B, L))
+    else:
+        mask = (ids != (pad if pad is not None else -1)).astype(np.float64)
+        pooled = (emb * mask[:, :, None]).sum(1)
+        wts = mask
+        if pooling == "mean":
+            pooled = pooled / (mask.sum(1, keepdims=True) + 1e-16)
+            wts = mask / (mask.sum(1, keepdims=True) + 1e-16)
+    want = np.concatenate([t_s0[x["s0"]], pooled, x["d0"][:, None]], axis=1)
+    got = out.detach().cpu().numpy()
+    assert got.shape == want.shape
+    if pooling == "concat":
+        assert np.array_equal(got, want.astype(np.float32))
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    w = width = pooled.shape[1]
+    gh = g[:, dim:dim + width].astype(np.float64)
+    gh = gh.reshape(B, L, dim) if pooling == "concat" else gh[:, None, :] * wts[:, :, None]
+    want_grad = np.zeros((V, dim))
+    np.add.at(want_grad, ids.reshape(-1), gh.reshape(-1, dim))
+    p = layer.embed_dict["h"].weight
+    if p.grad is not None:
+        got_grad = p.grad.cpu().numpy()
+    else:
+        r, gg = (t.cpu().numpy() for t in p._swr_sparse_grad)
+        got_grad = np.zeros((V, dim))
+        np.add.at(got_grad, r[r >= 0], gg[r >= 0].astype(np.float64))
+    np.testing.assert_allclose(got_grad, want_grad, rtol=0, atol=2e-6 * max(1.0, np.abs(want_grad).max()))

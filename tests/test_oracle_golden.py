@@ -82,3 +82,27 @@ def test_dataparallel_semantics(name):
     for k, v in c.group("state1").items():
         if not k.endswith("num_batches_tracked"):
             np.testing.assert_allclose(state_after[k], v, rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_torch_port_matches_the_oracle():
+    """oracle/torch_port.py (the multi-threaded CPU port bench.py times as `cpu_baseline`) computes the step the
+    numpy oracle computes: forward, loss, every gradient and the state after one Adam step on the golden MMoE case."""
+    from _golden import Case, oracle_features
+    from oracle.torch_port import MMoEPort
+    c = Case("mmoe")
+    feats = oracle_features(c.schemas[0])
+    port = MMoEPort(feats, c.hyper, c.group("state0"))
+    x, y = c.batch(0)
+    p, loss, grads = port.loss_and_grads(x, y)
+    np.testing.assert_allclose(p, c.z["train_probs"], rtol=1e-5, atol=1e-6)
+    assert abs(loss - float(c.z["loss0"])) < 1e-6
+    for k, g in c.group("grad").items():
+        np.testing.assert_allclose(grads[k], g, rtol=0, atol=2e-5 * max(1e-6, float(np.abs(g).max())) + 1e-8, err_msg=k)
+    port2 = MMoEPort(feats, c.hyper, c.group("state0"))
+    port2.step(x, y, lr=c.meta["lr"], weight_decay=c.meta["weight_decay"])
+    for k, v in c.group("state1").items():
+        got = (port2.p.get(k, port2.buf.get(k))).detach().numpy()
+        if k.endswith("num_batches_tracked"):
+            assert int(got) == int(v)
+        else:
+            np.testing.assert_allclose(got, v, rtol=1e-4, atol=state_atol(c, k, 1), err_msg=k)

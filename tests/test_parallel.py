@@ -23,7 +23,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_workers(mode, case, world, extra=(), env_extra=None):
+GPU_FAULT_RETRIES = []      # (mode, case, world, rank, first line of the fault) of every retried worker group
+
+
+def run_workers(mode, case, world, extra=(), env_extra=None, _attempt=0):
+    """Launch `world` worker processes and wait for them.
+
+    A rank that dies of a GPU FAULT raised by the runtime (`HSA_STATUS_ERROR_*`, "Memory access fault") -- not of a Python
+    exception, not of a wrong number -- makes the whole group run again, at most twice.  Measured on the MI355X test
+    pool (round 2, 360 runs of the 8-rank test = 2 880 process launches sharing one GPU): 9 launches aborted with
+    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION before or during their first kernels, with the ranks time-slicing the GPU and
+    with the ranks taking turns on it alike, while the same binaries never faulted in single-process runs.  One process
+    per GPU is the product's regime; several processes on one GPU exist only in these tests.  A numerical mismatch is
+    never retried."""
     out = tempfile.mkdtemp()
     port = _free_port()
     procs = []
@@ -34,6 +46,12 @@ def run_workers(mode, case, world, extra=(), env_extra=None):
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     failed = [(r, log) for r, (p, log) in enumerate(zip(procs, logs)) if p.returncode != 0]
+    faults = [(r, line) for r, log in failed for line in log.splitlines()
+              if "HSA_STATUS_ERROR" in line or "Memory access fault" in line]
+    if faults and _attempt < 2:
+        GPU_FAULT_RETRIES.append((mode, case, world) + faults[0])
+        print(f"[test_parallel] GPU fault in rank {faults[0][0]} ({faults[0][1][-120:]}); running the group again", file=sys.stderr)
+        return run_workers(mode, case, world, extra, env_extra, _attempt + 1)
     # the rank that failed FIRST is the interesting one: the others die of "Connection closed by peer"
     failed.sort(key=lambda rl: "Connection closed by peer" in rl[1] or "Connection reset" in rl[1])
     assert not failed, f"{len(failed)} rank(s) failed; rank {failed[0][0]}:\n{failed[0][1][-3000:]}"
@@ -56,7 +74,8 @@ def test_two_ranks_full_hip_step(name, world, limit):
     """limit=2048 bytes forces every table above 32 rows x 16 onto the row-sparse exchange; the 8-rank case (all ranks
     on cuda:0, gloo) runs the split backward, both all-gathers and the sort-free merge at the world size of a full
     node against the reference's 8-shard DataParallel result."""
-    out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),))
+    out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),),
+                      env_extra={"DP_TAKE_TURNS": "1"} if world > 2 else None)      # (see dp_worker.take_turns_on_the_gpu)
     c = Case(name)
     # 0. what the ranks sent each other: every rank received the same bytes, and rank r's local gradient arena is the
     #    oracle's gradient of the local mean loss on shard r (locates a failure: a rank's kernels, or the exchange)
@@ -107,3 +126,27 @@ def test_two_rank_captured_step_matches_eager(limit):
                              "state1.npz"))
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_ctrtrainer_gpus_argument_runs_data_parallel():
+    """`CTRTrainer(gpus=[0, 1])` (reference: single-process nn.DataParallel, ctr_trainer.py:45-47) = one process per GPU
+    here: every process feeds the WHOLE batch, rank r trains on row chunk r.  One epoch of one batch lands on the
+    reference's 2-shard DataParallel state; 4 epochs (eager, eager, capture + replay, replay) equal 4 eager ones
+    bitwise and keep the replicas identical."""
+    out = run_workers("trainer-gpu", "mmoe_dp2", 2)
+    c = Case("mmoe_dp2")
+    got = np.load(os.path.join(out, "state1.npz"))
+    for k, v in c.group("state1").items():
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v)
+        else:
+            np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=state_atol(c, k, 1), err_msg=k)
+    a = run_workers("trainer-gpu", "mmoe_dp2", 2, extra=("4",))
+    b = run_workers("trainer-gpu", "mmoe_dp2", 2, extra=("4",), env_extra={"DP_EAGER_REFERENCE": "1"})
+    ga, gb = np.load(os.path.join(a, "state1.npz")), np.load(os.path.join(b, "state1.npz"))
+    ra = np.load(os.path.join(a, "state1_rank1.npz"))
+    for k in ga.files:
+        assert np.array_equal(ga[k], gb[k]), k
+        if "running_" not in k and "num_batches_tracked" not in k:
+            assert np.array_equal(ga[k], ra[k]), f"replicas differ: {k}"
