@@ -91,6 +91,30 @@ int swr_embed_gather_fwd(const swr_sparse_slot* sparse_host, int n_sparse,
                          const swr_dense_slot* dense_host, int n_dense,
                          int64_t B, float* out, int64_t ld_out,
                          uint32_t* keys_out, uint32_t* err_flag, void* stream);
+/* The same lookup, plus a ONE-HOT block of the small tables behind the concat (training only; no reference
+ * counterpart -- it restructures the backward of `embedding -> Linear`, basic/layers.py:64-105 + 253): columns
+ * [oh_col, oh_col + oh_width) of `out`, slot s with oh_off[s] >= 0 owns columns oh_col + oh_off[s] + v, v < vocab_s, and
+ * out[b, oh_col + oh_off[s] + v] = (row_s(b) == v) ? 1 : 0; unowned columns of the block and the alignment columns
+ * [pad_col, oh_col) are zeros.  With the block in place, the weight-gradient product of the layer that consumes the
+ * concat, dZ^T [out | one-hot] (swr_gemm_tn with a second destination), also yields S[v, :] = sum of dZ over the samples
+ * whose row is v -- and the gradient of a small table is S W_t (swr_onehot_table_grads): its columns of dX are
+ * never computed and it skips K3.  oh_width, oh_col multiples of 4, oh_width <= 256, n_sparse <= 64. */
+int swr_embed_gather_fwd_onehot(const swr_sparse_slot* sparse_host, int n_sparse,
+                                const swr_dense_slot* dense_host, int n_dense,
+                                int64_t B, float* out, int64_t ld_out, uint32_t* keys_out,
+                                const int32_t* oh_off_host /* [n_sparse], -1 = none */, int pad_col, int oh_col, int oh_width,
+                                uint32_t* err_flag, void* stream);
+/* grad_t[v, e] (+)= sum_n S_t[n, oh_off_t + v] * W[n, w_col_t + e] for every listed small table t: S_t = the second
+ * destination of the weight-gradient product ([N, >= oh columns], leading dimension lds), W = the layer's stacked
+ * weights [N, K] (ldw).  Fixed summation order (deterministic). */
+typedef struct {
+    float* grad;           /* [vocab, dim] */
+    int32_t vocab, dim;
+    int32_t oh_off;        /* first column of the table's block in S */
+    int32_t w_col;         /* first column of the table's embedding in W */
+} swr_onehot_table;
+int swr_onehot_table_grads(const float* S, int64_t lds, const float* W, int64_t ldw, int N,
+                           const swr_onehot_table* tables_host, int n_tables, int accumulate, void* stream);
 
 /* K1 for SequenceFeature columns (reference basic/layers.py:73-87 pooled lookup; InputMask 117-146; Sum / Average /
  * ConcatPooling 174-228): `idx` is [B, L] (padded id sequences, row-major, type idx_dtype).
@@ -227,6 +251,13 @@ typedef struct {
     int32_t accumulate;
     int32_t groups;
     int64_t gsA, gsB, gsC, gsColsum;
+    /* optional second destination (one group only): columns >= c2_from of the product are written to
+     * C2[k1, k2 - c2_from] (leading dimension ldc2; always overwritten) instead of C -- the weight-gradient product over
+     * an embedding concat that carries one-hot columns behind the embeddings (swr_embed_gather_fwd `oh_*`) yields dW
+     * and the per-row segment sums of dZ in one launch.  C2 = NULL: everything goes to C. */
+    float* C2;
+    int64_t ldc2;
+    int64_t c2_from;
 } swr_gemm_tn_args;
 
 size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args_host);

@@ -19,6 +19,9 @@
 #define MAX_DENSE 64
 #define FUSED_DENSE 32   // dense columns written by the gather kernel itself (kernarg budget: 4 KiB)
 
+#define OH_MAX 256         // widest one-hot block (columns)
+#define OH_NONE 255
+
 struct GatherArgs {
     swr_sparse_slot sparse[MAX_SPARSE];
     swr_dense_slot dense[FUSED_DENSE];
@@ -30,6 +33,10 @@ struct GatherArgs {
     int64_t ld;
     uint32_t* keys;
     uint32_t* err;
+    // one-hot block behind the concat (see swr_embed_gather_fwd_onehot): columns [oh_col, oh_col + oh_width) of `out`,
+    // slot s owns columns oh_col + oh_off[s] .. + vocab (oh_off < 0: not a one-hot slot); [pad_col, oh_col) is zeroed
+    int oh_col, oh_width, pad_col;
+    int16_t oh_off[MAX_SPARSE];
 };
 
 struct DenseArgs {
@@ -57,6 +64,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void embed_gather_kernel(const Gath
     __shared__ int s_col[MAX_SPARSE];
     __shared__ uint16_t s_unit_slot[2048];
     __shared__ uint16_t s_unit_q[2048];
+    __shared__ uint8_t s_oh_slot[OH_MAX];
+    __shared__ uint16_t s_oh_val[OH_MAX];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -83,6 +92,17 @@ __global__ __launch_bounds__(GATHER_THREADS) void embed_gather_kernel(const Gath
             s_w[s] = sl.weight;
             s_dim[s] = sl.dim;
             s_col[s] = sl.out_col;
+        }
+    }
+    if (a.oh_width > 0) {                              // column of the one-hot block -> (slot, row value)
+        for (int c = tid; c < a.oh_width; c += GATHER_THREADS) s_oh_slot[c] = OH_NONE;
+    }
+    __syncthreads();
+    if (a.oh_width > 0 && tid < a.n_sparse && a.oh_off[tid] >= 0) {
+        const int v = static_cast<int>(a.sparse[tid].vocab);
+        for (int j = 0; j < v; ++j) {
+            s_oh_slot[a.oh_off[tid] + j] = static_cast<uint8_t>(tid);
+            s_oh_val[a.oh_off[tid] + j] = static_cast<uint16_t>(j);
         }
     }
     // unit map (a unit = VEC consecutive floats of one table row): thread s lays out slot s
@@ -124,6 +144,24 @@ __global__ __launch_bounds__(GATHER_THREADS) void embed_gather_kernel(const Gath
         const int r = t / a.n_dense, s = t - r * a.n_dense;
         a.out[(b0 + r) * a.ld + a.dense[s].out_col] = swr_load_value(a.dense[s].values, a.dense[s].dtype, b0 + r);
     }
+    // one-hot block of the small tables: out[b, oh_col + off_s + v] = (row_s(b) == v); 16-byte stores, 4 columns per lane
+    if (a.oh_width > 0) {
+        const int upr4 = a.oh_width / 4;
+        for (int t = tid; t < rows * upr4; t += GATHER_THREADS) {
+            const int r = t / upr4, q = t - r * upr4;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * q + j;
+                const int sl = s_oh_slot[c];
+                v[j] = (sl != OH_NONE && s_row[sl][r] == s_oh_val[c]) ? 1.f : 0.f;
+            }
+            *reinterpret_cast<float4*>(a.out + (b0 + r) * a.ld + a.oh_col + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        const int npad = a.oh_col - a.pad_col;          // alignment columns between the concat and the block: zeros
+        for (int t = tid; t < rows * npad; t += GATHER_THREADS)
+            a.out[(b0 + t / npad) * a.ld + a.pad_col + t % npad] = 0.f;
+    }
 }
 
 __global__ __launch_bounds__(GATHER_THREADS) void dense_cast_kernel(const DenseArgs a) {
@@ -139,7 +177,23 @@ __global__ __launch_bounds__(GATHER_THREADS) void dense_cast_kernel(const DenseA
 extern "C" int swr_embed_gather_fwd(const swr_sparse_slot* sparse, int n_sparse, const swr_dense_slot* dense,
                                     int n_dense, int64_t B, float* out, int64_t ld_out, uint32_t* keys_out,
                                     uint32_t* err_flag, void* stream) {
+    return swr_embed_gather_fwd_onehot(sparse, n_sparse, dense, n_dense, B, out, ld_out, keys_out, nullptr, 0, 0, 0, err_flag,
+                                       stream);
+}
+
+extern "C" int swr_embed_gather_fwd_onehot(const swr_sparse_slot* sparse, int n_sparse, const swr_dense_slot* dense,
+                                           int n_dense, int64_t B, float* out, int64_t ld_out, uint32_t* keys_out,
+                                           const int32_t* oh_off, int pad_col, int oh_col, int oh_width,
+                                           uint32_t* err_flag, void* stream) {
     SWR_REQUIRE(B >= 0 && n_sparse >= 0 && n_dense >= 0 && out != nullptr && ld_out > 0, SWR_ERR_ARG);
+    if (oh_width > 0) {
+        SWR_REQUIRE(oh_off && n_sparse <= MAX_SPARSE && n_sparse > 0 && oh_width <= OH_MAX && oh_width % 4 == 0 && oh_col % 4 == 0 &&
+                        pad_col >= 0 && pad_col <= oh_col && oh_col - pad_col < 4 && oh_col + oh_width <= ld_out && ld_out % 4 == 0 &&
+                        swr_aligned16(out), SWR_ERR_ARG);
+        for (int s = 0; s < n_sparse; ++s)
+            SWR_REQUIRE(oh_off[s] < 0 || (sparse[s].hash_seed == 0 && sparse[s].vocab <= 0xFFFF &&
+                                          oh_off[s] + sparse[s].vocab <= oh_width), SWR_ERR_ARG);
+    }
     SWR_REQUIRE((n_sparse == 0 || sparse) && (n_dense == 0 || dense), SWR_ERR_ARG);
     if (B == 0) return SWR_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -172,6 +226,11 @@ extern "C" int swr_embed_gather_fwd(const swr_sparse_slot* sparse, int n_sparse,
             for (int s = 0; s < a.n_dense; ++s) a.dense[s] = dense[s];
             dense_done = a.n_dense;
         }
+        a.oh_width = 0; a.oh_col = 0; a.pad_col = 0;
+        if (oh_width > 0) {                              // (n_sparse <= MAX_SPARSE: one launch)
+            a.oh_width = oh_width; a.oh_col = oh_col; a.pad_col = pad_col;
+            for (int s = 0; s < a.n_sparse; ++s) a.oh_off[s] = static_cast<int16_t>(oh_off[s]);
+        }
         a.B = B;
         a.out = out;
         a.ld = ld_out;
@@ -193,6 +252,68 @@ extern "C" int swr_embed_gather_fwd(const swr_sparse_slot* sparse, int n_sparse,
         const int64_t n = B * d.n_dense;
         hipLaunchKernelGGL(dense_cast_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, GATHER_THREADS))),
                            dim3(GATHER_THREADS), 0, st, d);
+    }
+    return swr_launch_status();
+}
+
+
+// ---- gradients of the small (one-hot) tables from the segment sums of dZ: grad_t[v, e] (+)= sum_n S[n, off_t + v] W[n, col_t + e]
+#define OHT_MAX 64
+struct OhtK {
+    swr_onehot_table tab[OHT_MAX];
+    int first[OHT_MAX + 1];          // first output element of each table
+    int n_tables, N, accumulate;
+    const float* S; int64_t lds;
+    const float* W; int64_t ldw;
+};
+
+// one output element per 16 consecutive lanes: lane j of the group takes n = j, j + 16, ... (independent loads in flight,
+// fused multiply-adds in ascending n), then a fixed butterfly over the 16 partials -- deterministic
+#define OHT_LANES 16
+__global__ __launch_bounds__(GATHER_THREADS) void onehot_table_grads_kernel(const OhtK k) {
+    const int gidx = (blockIdx.x * GATHER_THREADS + threadIdx.x) / OHT_LANES;
+    const int j0 = threadIdx.x % OHT_LANES;
+    const int total = k.first[k.n_tables];
+    const bool live = gidx < total;
+    const int i = live ? gidx : total - 1;
+    int t = 0;
+    while (i >= k.first[t + 1]) ++t;
+    const swr_onehot_table& T = k.tab[t];
+    const int j = i - k.first[t];
+    const int v = j / T.dim, e = j - v * T.dim;
+    const float* s = k.S + T.oh_off + v;
+    const float* w = k.W + T.w_col + e;
+    float acc = 0.f;
+    for (int n = j0; n < k.N; n += OHT_LANES) acc = fmaf(s[n * k.lds], w[n * k.ldw], acc);
+#pragma unroll
+    for (int o = 1; o < OHT_LANES; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (live && j0 == 0) {
+        float* dst = T.grad + static_cast<int64_t>(v) * T.dim + e;
+        *dst = k.accumulate ? *dst + acc : acc;
+    }
+}
+
+extern "C" int swr_onehot_table_grads(const float* S, int64_t lds, const float* W, int64_t ldw, int N,
+                                      const swr_onehot_table* tables, int n_tables, int accumulate, void* stream) {
+    SWR_REQUIRE(S && W && tables && N > 0 && n_tables >= 0 && lds > 0 && ldw > 0, SWR_ERR_ARG);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int t0 = 0; t0 < n_tables; t0 += OHT_MAX) {
+        OhtK k;
+        k.n_tables = n_tables - t0 < OHT_MAX ? n_tables - t0 : OHT_MAX;
+        k.N = N; k.accumulate = accumulate; k.S = S; k.lds = lds; k.W = W; k.ldw = ldw;
+        int pos = 0;
+        for (int t = 0; t < k.n_tables; ++t) {
+            const swr_onehot_table& T = tables[t0 + t];
+            SWR_REQUIRE(T.grad && T.vocab > 0 && T.dim > 0 && T.oh_off >= 0 && T.w_col >= 0, SWR_ERR_ARG);
+            k.tab[t] = T;
+            k.first[t] = pos;
+            pos += T.vocab * T.dim;
+        }
+        k.first[k.n_tables] = pos;
+        if (pos == 0) continue;
+        hipLaunchKernelGGL(onehot_table_grads_kernel,
+                           dim3(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(pos) * OHT_LANES, GATHER_THREADS))),
+                           dim3(GATHER_THREADS), 0, st, k);
     }
     return swr_launch_status();
 }

@@ -1190,8 +1190,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
     for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off);
     if (j < n && sub == 0) {
         const int64_t r = j / a.K2, c = j - r * a.K2;
-        float* dst = a.C + g * a.gsC + r * a.ldc + c;
-        *dst = a.accumulate ? *dst + sum : sum;
+        if (a.C2 && c >= a.c2_from) {
+            a.C2[r * a.ldc2 + (c - a.c2_from)] = sum;                    // second destination: always overwritten
+        } else {
+            float* dst = a.C + g * a.gsC + r * a.ldc + c;
+            *dst = a.accumulate ? *dst + sum : sum;
+        }
     }
     float cs = 0.f;
     if (kk.part_cs && j < a.K1) cs = lane_sum(kk.part_cs + static_cast<int64_t>(g) * nparts * a.K1 + j, a.K1);
@@ -1259,16 +1263,23 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
     SWR_REQUIRE(args != nullptr, SWR_ERR_ARG);
     const swr_gemm_tn_args& a = *args;
     SWR_REQUIRE(a.M >= 0 && a.K1 > 0 && a.K2 > 0 && a.A && a.B && a.C && a.groups >= 1, SWR_ERR_ARG);
-    SWR_REQUIRE(a.lda >= a.K1 && a.ldb >= a.K2 && a.ldc >= a.K2, SWR_ERR_ARG);
+    SWR_REQUIRE(a.lda >= a.K1 && a.ldb >= a.K2, SWR_ERR_ARG);
+    if (a.C2) SWR_REQUIRE(a.groups == 1 && a.c2_from > 0 && a.c2_from < a.K2 && a.ldc >= a.c2_from && a.ldc2 >= a.K2 - a.c2_from, SWR_ERR_ARG);
+    else SWR_REQUIRE(a.ldc >= a.K2, SWR_ERR_ARG);
     hipStream_t st = static_cast<hipStream_t>(stream);
     TnK kk;
     kk.a = a;
+    if (a.M == 0 && a.C2) {
+        for (int r = 0; r < a.K1; ++r)
+            if (hipMemsetAsync(a.C2 + static_cast<int64_t>(r) * a.ldc2, 0, sizeof(float) * (a.K2 - a.c2_from), st) != hipSuccess)
+                return SWR_ERR_LAUNCH;
+    }
     if (a.M == 0) {
         // empty batch: the gradient is zero
         if (a.accumulate) return SWR_OK;
         for (int g = 0; g < a.groups; ++g) {
             for (int r = 0; r < a.K1; ++r)
-                if (hipMemsetAsync(a.C + g * a.gsC + static_cast<int64_t>(r) * a.ldc, 0, sizeof(float) * a.K2, st) != hipSuccess)
+                if (hipMemsetAsync(a.C + g * a.gsC + static_cast<int64_t>(r) * a.ldc, 0, sizeof(float) * (a.C2 ? a.c2_from : a.K2), st) != hipSuccess)
                     return SWR_ERR_LAUNCH;
             if (a.colsum && hipMemsetAsync(a.colsum + g * a.gsColsum, 0, sizeof(float) * a.K1, st) != hipSuccess)
                 return SWR_ERR_LAUNCH;

@@ -79,7 +79,8 @@ class GemmTnArgs(C.Structure):
                 ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("colsum", C.c_void_p),
                 ("accumulate", C.c_int32), ("groups", C.c_int32),
-                ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsColsum", C.c_int64)]
+                ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsColsum", C.c_int64),
+                ("C2", C.c_void_p), ("ldc2", C.c_int64), ("c2_from", C.c_int64)]
 
 
 class ActRange(C.Structure):
@@ -143,6 +144,10 @@ class LayerNormArgs(C.Structure):
                 ("dbeta", C.c_void_p)]
 
 
+class OnehotTable(C.Structure):
+    _fields_ = [("grad", C.c_void_p), ("vocab", C.c_int32), ("dim", C.c_int32), ("oh_off", C.c_int32), ("w_col", C.c_int32)]
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("step", C.c_int64), ("step_size", C.c_float),
@@ -157,6 +162,8 @@ _SIGS = {
     "swr_status_str": (C.c_char_p, [_I]),
     "swr_device_available": (C.c_int, []),
     "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
+    "swr_embed_gather_fwd_onehot": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P]),
+    "swr_onehot_table_grads": (C.c_int, [_P, _L, _P, _L, _I, _P, _I, _I, _P]),
     "swr_embed_bag_fwd": (C.c_int, [_P, _L, _I, _P, _I, _L, _I, _I, _I, _L, C.c_uint32, _P, _L, _I, _P, _P, _P, _P]),
     "swr_embed_bag_bwd_expand": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _L, _P, _P]),
     "swr_embed_bwd_workspace_bytes": (_Z, [_P, _I, _L]),

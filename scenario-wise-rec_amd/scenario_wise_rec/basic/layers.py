@@ -38,7 +38,10 @@ class EmbeddingLayer(SwrModule):
             elif isinstance(fea, DenseFeature):
                 self.n_dense += 1
 
-    def forward(self, x, features, squeeze_dim=False):
+    def forward(self, x, features, squeeze_dim=False, onehot=False):
+        """`onehot=True` (training, squeeze_dim): the caller promises that the returned tensor is consumed by exactly ONE
+        ops.linear_bn_act / LayerBank call -- the lookup may then append a one-hot block of its small tables and that
+        layer's backward produces their gradients itself (ops.OneHotInfo)."""
         sparse, dense = [], []
         for fea in features:
             if isinstance(fea, SequenceFeature):
@@ -57,6 +60,7 @@ class EmbeddingLayer(SwrModule):
                 "If keep the original shape:[batch_size, num_features, embed_dim], expected %s in feature list, got %s" %
                 ("SparseFeatures", features))
         plan, weights = _new_plan(self)
+        plan.onehot = bool(onehot and squeeze_dim and self.training)
         _plan_part(plan, weights, {}, self, x, sparse, dense if squeeze_dim else [])
         out = _run_plan(plan, weights)
         if squeeze_dim:
@@ -73,6 +77,7 @@ def _new_plan(layer):
     plan = ops._GatherPlan()
     plan.sparse, plan.dense, plan.width = [], [], 0
     plan.bags = []
+    plan.onehot, plan.oh, plan.ctx = False, None, None
     plan.lazy = {}
     plan.dense_limit_bytes = layer.dense_table_limit_bytes
     return plan, []
@@ -112,11 +117,43 @@ def _run_plan(plan, weights):
     plan.ld = (plan.width + 3) // 4 * 4
     plan.want_grad = torch.is_grad_enabled()       # Function.forward itself always runs with grad mode off
     out = ops.EmbedGather.apply(plan, *weights)
+    if plan.oh:
+        # hand the one-hot block to the consuming layer (ops.OneHotInfo): which tables it covers, and the compact column
+        # layout of the dX that layer owes the remaining (K3) slots
+        info = ops.OneHotInfo()
+        info.ctx, info.oh_col = plan.ctx, (plan.width + 3) // 4 * 4
+        info.oh_width = plan.ld - info.oh_col
+        info.tables_p = [(weights[wpos], vocab, dim, off, col) for _i, wpos, vocab, dim, off, col in plan.oh]
+        info.params = tuple({id(t[0]): t[0] for t in info.tables_p}.values())
+        info.tables = None
+        cols, compact, pos = [], [], 0
+        for _wpos, _idx, _vocab, dim, col, _seed in plan.sparse[:plan.ctx.n_k3_slots]:
+            compact.append(pos)
+            cols.extend(range(col, col + dim))
+            pos += dim
+        pad = (-pos) % 4
+        cols.extend([cols[-1]] * pad if cols else [])              # (16-byte rows for the product; the pad columns are never read)
+        info.compact, info.n_sel = compact, len(cols)
+        info.sel = _sel_tensor(tuple(cols), out.device) if cols else None
+        out._swr_onehot = info
     # columns that can take a gradient: everything up to the end of the last embedding column (dense-feature columns are
     # inputs).  A layer that reads this tensor need not compute d/dx beyond it (ops.LinearBNAct: `n_compute` of dX).
     out._swr_grad_cols = max([col + dim for _w, _i, _v, dim, col, _s in plan.sparse] +
                              [b["col"] + b["dim"] * (b["L"] if b["mode"] == 2 else 1) for b in plan.bags], default=0)
     return out
+
+
+_SEL_CACHE = {}
+
+
+def _sel_tensor(cols, device):
+    """Column index list on the device, cached: built once per (layout, device) -- an upload per step would be a host
+    sync and cannot be captured into a hipGraph."""
+    key = (cols, str(device))
+    t = _SEL_CACHE.get(key)
+    if t is None:
+        t = _SEL_CACHE[key] = torch.tensor(cols, dtype=torch.int64, device=device)
+    return t
 
 
 def fused_lookup(x, parts):

@@ -56,7 +56,9 @@ class MMOE(SwrModule):
 
     def forward(self, x):
         domain_id = x["domain_indicator"]
-        embed_x = self.embedding(x, self.features, squeeze_dim=True)           # [B, K0]
+        # [B, K0]; when the experts and gates are ONE stacked layer (the only reader of the lookup) the small tables ride
+        # that layer's backward (ops.OneHotInfo)
+        embed_x = self.embedding(x, self.features, squeeze_dim=True, onehot=self._fusable())
         ne, D = self.n_expert, self.domain_num
         experts, gates = list(self.experts), list(self.gates)
         if self._fusable():

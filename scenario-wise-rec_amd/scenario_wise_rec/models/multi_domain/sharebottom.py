@@ -26,7 +26,8 @@ class SharedBottom(SwrModule):
 
     def forward(self, x):
         domain_id = x["domain_indicator"]
-        h = self.bottom_mlp(self.embedding(x, self.features, squeeze_dim=True))
+        # (the bottom MLP's first layer is the only reader of the lookup: ops.OneHotInfo)
+        h = self.bottom_mlp(self.embedding(x, self.features, squeeze_dim=True, onehot=self.bottom_mlp.n_blocks > 0))
         # all towers read the same h: their first layers are one stacked product, the rest grouped
         logits = mlp_bank_forward(list(self.towers), h, shared_input=True)          # [B, D]
         return ops.domain_select(logits, domain_id, apply_sigmoid=True)

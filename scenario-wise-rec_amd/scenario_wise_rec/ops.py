@@ -63,9 +63,12 @@ def split_weights(W, want_t):
 
 
 def gemm_tn(A, B, C_out, M, K1, K2, colsum=None, accumulate=False, groups=1, gsA=0, gsB=0, gsC=0, gsColsum=0,
-            lda=None, ldb=None, ldc=None):
-    """C[k1,k2] = sum_m A[m,k1] B[m,k2] (+ colsum[k1] = sum_m A[m,k1]); deterministic split over m."""
+            lda=None, ldb=None, ldc=None, C2=None, c2_from=0):
+    """C[k1,k2] = sum_m A[m,k1] B[m,k2] (+ colsum[k1] = sum_m A[m,k1]); deterministic split over m.
+    `C2` (with `c2_from`): columns k2 >= c2_from go to C2[k1, k2 - c2_from] instead (overwritten)."""
     a = H.GemmTnArgs()
+    if C2 is not None:
+        a.C2, a.ldc2, a.c2_from = C2.data_ptr(), C2.stride(0), int(c2_from)
     a.M, a.K1, a.K2 = M, K1, K2
     a.A, a.lda = A.data_ptr(), lda if lda is not None else _ld(A)
     a.B, a.ldb = B.data_ptr(), ldb if ldb is not None else _ld(B)
@@ -193,7 +196,10 @@ def _fork_extras():
     _side["epoch"] += 1
     run_side_jobs()
     for ent in _side["wt"].values():
-        ent["buf"].copy_(ent["src"].t())
+        if ent.get("sel") is not None:
+            torch.index_select(ent["src"].t(), 0, ent["sel"], out=ent["buf"])
+        else:
+            ent["buf"].copy_(ent["src"].t())
         ent["epoch"] = _side["epoch"]
 
 
@@ -207,6 +213,20 @@ def _transposed_weight(W):
     Wt = W.t().contiguous()
     if SIDE_STREAM and len(_side["wt"]) < 64:
         _side["wt"][key] = {"src": W.detach(), "buf": torch.empty_like(Wt), "epoch": -1}
+    return Wt
+
+
+def _selected_wt(W, sel):
+    """Rows `sel` of W^T (contiguous [len(sel), N]): the operand of a dX product restricted to the columns `sel` of x.
+    Prepared by this step's forward-time fork when one is registered (like _transposed_weight)."""
+    key = (W.data_ptr(), W.shape[0], W.shape[1], sel.data_ptr())
+    ent = _side["wt"].get(key)
+    if ent is not None and ent["epoch"] == _side["epoch"] and SIDE_STREAM:
+        join_side_streams()
+        return ent["buf"]
+    Wt = W.t().index_select(0, sel)
+    if SIDE_STREAM and len(_side["wt"]) < 64:
+        _side["wt"][key] = {"src": W.detach(), "buf": torch.empty_like(Wt), "epoch": -1, "sel": sel}
     return Wt
 
 
@@ -317,8 +337,24 @@ def _split_like(flat, tensors):
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx")
+    # onehot: the caller promises that ONE LinearBNAct consumes the lookup (see OneHotInfo); oh: the block laid out by forward
     # bags: SequenceFeature lookups, dicts(wpos, idx [B, L], vocab, dim, col, L, mode 0 sum / 1 mean / 2 concat, pad, seed)
+
+
+ONEHOT = os.environ.get("SWR_ONEHOT", "1") != "0"
+ONEHOT_MAX_VOCAB = int(os.environ.get("SWR_ONEHOT_MAX_VOCAB", "16"))
+ONEHOT_MAX_WIDTH = int(os.environ.get("SWR_ONEHOT_MAX_WIDTH", "128"))
+
+
+class OneHotInfo(object):
+    """One-hot block of the small tables behind an embedding concat (csrc/embed_fwd.hip, swr_embed_gather_fwd_onehot),
+    handed from the lookup to the ONE layer that consumes it (LinearBNAct), whose backward then
+      * takes the small tables' gradients from its own weight-gradient product: dZ^T [E | one-hot] gives dW and the
+        per-row segment sums S of dZ in one launch; grad_t = S_t W_t (swr_onehot_table_grads) -- no K3 for them;
+      * computes dX only for the columns of the other tables (`sel`), compactly, and passes it to the lookup's backward
+        through `ctx` (autograd carries a zero-stride placeholder)."""
+    __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact")
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -346,8 +382,34 @@ class EmbedGather(Function):
         # slots whose table takes a gradient first: the backward reduces exactly that prefix
         plan.sparse = sorted(plan.sparse, key=lambda s: not weights[s[0]].requires_grad)
         ctx.n_grad_slots = sum(1 for s in plan.sparse if weights[s[0]].requires_grad)
-        out = torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
         ns, nd = len(plan.sparse), len(plan.dense)
+        # one-hot block of the small tables (see OneHotInfo): only when the caller vouches for a single consuming layer
+        plan.oh, oh_off, oh_width, oh_col = None, None, 0, 0
+        if (ONEHOT and getattr(plan, "onehot", False) and getattr(plan, "want_grad", False) and not bags and 0 < ns <= 64):
+            off, tables = 0, []
+            for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse[:ctx.n_grad_slots]):
+                w = weights[wpos]
+                if (vocab <= ONEHOT_MAX_VOCAB and seed == 0 and off + vocab <= ONEHOT_MAX_WIDTH and dim % 4 == 0
+                        and w.numel() * 4 <= plan.dense_limit_bytes and _grad_alias([w], 4) is not None):
+                    tables.append((i, wpos, vocab, dim, off, col))
+                    off += vocab
+            if tables:
+                # one-hot slots go behind the other gradient-taking slots: K3 then handles a PREFIX of the slots (and of
+                # the keys, which are laid out in slot order)
+                pos = {t[0] for t in tables}
+                ng = ctx.n_grad_slots
+                plan.sparse = ([sl for i, sl in enumerate(plan.sparse[:ng]) if i not in pos] +
+                               [plan.sparse[t[0]] for t in tables] + plan.sparse[ng:])
+                first = ng - len(tables)
+                tables = [(first + j,) + t[1:] for j, t in enumerate(tables)]
+                oh_col = (plan.width + 3) // 4 * 4
+                oh_width = (off + 3) // 4 * 4
+                oh_off = (C.c_int32 * ns)(*([-1] * ns))
+                for i, _w, _v, _d, o, _c in tables:
+                    oh_off[i] = o
+                plan.ld = oh_col + oh_width
+                plan.oh = tables
+        out = torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
         sp = (H.SparseSlot * max(ns, 1))()
         for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse):
             H.require_device(idx, weights[wpos])
@@ -366,8 +428,12 @@ class EmbedGather(Function):
         need_keys = ctx.n_grad_slots > 0
         keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
         flag = H.err_flag(dev)
-        H.check(lib.swr_embed_gather_fwd(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), H.ptr(flag), H.stream()),
-                "swr_embed_gather_fwd")
+        if plan.oh:
+            H.check(lib.swr_embed_gather_fwd_onehot(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), oh_off, plan.width,
+                                                    oh_col, oh_width, H.ptr(flag), H.stream()), "swr_embed_gather_fwd_onehot")
+        else:
+            H.check(lib.swr_embed_gather_fwd(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), H.ptr(flag), H.stream()),
+                    "swr_embed_gather_fwd")
         # SequenceFeature columns: pooled lookups (csrc/embed_bag.hip), one launch each, into their columns of `out`
         ctx.bags = []
         for bag in bags:
@@ -390,15 +456,20 @@ class EmbedGather(Function):
         ctx.plan, ctx.keys, ctx.B = plan, keys, B
         ctx.weights = weights            # identity / shapes only
         ctx.presorted = None
+        ctx.fused_dx = None              # (compact dX, {position in plan.sparse: first compact column}) from the consuming layer
+        ctx.n_k3_slots = ctx.n_grad_slots - (len(plan.oh) if plan.oh else 0)      # without the one-hot tables
+        plan.ctx = ctx
         if need_keys and ns and B > 0 and SIDE_STREAM and getattr(plan, "want_grad", False):   # a backward may follow
             # the grouping of the large tables' entries by row needs only the keys: run it NOW on the side stream,
             # hidden behind the rest of the forward and backward pass; the backward joins before it reduces
-            live, _uses, table_id = _grad_slot_layout(plan, weights, ctx.n_grad_slots)
-            proto = (H.EmbedGradSlot * len(live))()
+            live, _uses, table_id = _grad_slot_layout(plan, weights, ctx.n_k3_slots)
+            proto = (H.EmbedGradSlot * max(1, len(live)))()
             for s, (wpos, idx, vocab, dim, col, seed) in enumerate(live):
                 mode = 1 if weights[wpos].numel() * 4 > plan.dense_limit_bytes else 0
                 proto[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], mode, None, None, None)
-            nbytes = lib.swr_embed_bwd_workspace_bytes(proto, len(live), B)
+            nbytes = lib.swr_embed_bwd_workspace_bytes(proto, len(live), B) if live else 0
+            if not live:
+                _defer_side(dev, _fork_extras)         # nothing to sort: the fork still carries zero_grad and the W^T copies
             if nbytes:
                 box = {"nbytes": nbytes}
 
@@ -418,7 +489,15 @@ class EmbedGather(Function):
         no_plain = ctx.keys is None or ctx.n_grad_slots == 0
         if B == 0 or (no_plain and not ctx.bags):
             return (None,) + tuple(None if not w.requires_grad else torch.zeros_like(w) for w in weights)
-        dE = H.f32c(dE)
+        fused = ctx.fused_dx
+        ctx.fused_dx = None
+        if fused is not None:
+            # the consuming layer computed dX only for the columns K3 needs, compactly (OneHotInfo); `dE` is a placeholder
+            dE, compact = fused
+            if ctx.n_k3_slots == 0:
+                return (None,) + (None,) * len(weights)
+        else:
+            dE, compact = H.f32c(dE), None
         dev = dE.device
         if no_plain:
             grads, sparse_out = [None] * len(weights), {}
@@ -430,11 +509,13 @@ class EmbedGather(Function):
                 weights[wpos]._swr_sparse_local = True
             return (None,) + tuple(None if isinstance(g, tuple) else g for g in grads)
         # tables: dense gradient when small, row-sparse entries when large; sparse tables take the largest ids
-        live, uses, table_id = _grad_slot_layout(plan, weights, ctx.n_grad_slots)
+        live, uses, table_id = _grad_slot_layout(plan, weights, ctx.n_k3_slots if compact is not None else ctx.n_grad_slots)
         grads = [None] * len(weights)
         sparse_out = {}
         slots = (H.EmbedGradSlot * len(live))()
         for s, (wpos, idx, vocab, dim, col, seed) in enumerate(live):
+            if compact is not None:
+                col = compact[s]                       # this slot's first column in the compact dX
             w = weights[wpos]
             sparse_mode = w.numel() * 4 > plan.dense_limit_bytes
             if sparse_mode:
@@ -645,6 +726,8 @@ class LinearBNAct(Function):
                                            Ntot, H.stream()), "swr_affine_act_fwd")
         ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
         ctx.grad_cols = getattr(x_in, "_swr_grad_cols", None)
+        oh = getattr(x_in, "_swr_onehot", None)
+        ctx.onehot = oh if (oh is not None and G == 1 and x.data_ptr() == x_in.data_ptr() and x.stride(0) == oh.oh_col + oh.oh_width) else None
         ctx.params = params
         ctx.training_bn = training
         ctx.mix = mix
@@ -721,7 +804,21 @@ class LinearBNAct(Function):
         if not direct_w:
             dW = torch.empty((Ntot, K), dtype=torch.float32, device=dev)
             db = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
+        oh = ctx.onehot if (ctx.onehot is not None and direct_w and ctx.needs_input_grad[1] and oh_ready(ctx.onehot)) else None
+
         def launch_dw():
+            if oh is not None:
+                # dZ^T [E | 0 | one-hot]: dW into the arena, the segment sums of dZ per small-table row into S, then the small
+                # tables' gradients S_t W_t straight into the arena (OneHotInfo)
+                K2 = oh.oh_col + oh.oh_width
+                S = torch.empty((Ntot, K2 - K), dtype=torch.float32, device=dev)
+                gemm_tn(dZ, x, dW, M, N, K2, colsum=db, accumulate=True, ldc=K, C2=S, c2_from=K)
+                tabs = (H.OnehotTable * len(oh.tables))()
+                for j, (g_t, vocab, dim, off, col) in enumerate(oh.tables):
+                    tabs[j] = H.OnehotTable(g_t.data_ptr(), vocab, dim, oh.oh_col - K + off, col)
+                H.check(lib.swr_onehot_table_grads(H.ptr(S), K2 - K, H.ptr(W), W.stride(0), Ntot, tabs, len(oh.tables), 1,
+                                                   H.stream()), "swr_onehot_table_grads")
+                return
             gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
                     gsC=N * K, gsColsum=N, ldc=K)
         side_dw = direct_w and SIDE_STREAM and (SIDE_DW or 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP)
@@ -731,7 +828,18 @@ class LinearBNAct(Function):
         elif not side_dw:
             launch_dw()
         dx = None
-        if ctx.needs_input_grad[1]:
+        if oh is not None:
+            # dX only for the columns of the tables that go through K3, compact; the lookup's backward picks it up from its
+            # ctx, autograd carries a zero-stride placeholder of the right shape
+            if oh.n_sel > 0:
+                dsel = torch.empty((M, oh.n_sel), dtype=torch.float32, device=dev)
+                gemm("nt", dZ, _selected_wt(W, oh.sel), dsel, M, oh.n_sel, Ntot)
+            else:
+                dsel = dZ
+            oh.ctx.fused_dx = (dsel, oh.compact)
+            _mark_touched(oh.params)
+            dx = _zero_scalar(dev).expand(M, K)
+        elif ctx.needs_input_grad[1]:
             if G > 1:
                 dx = torch.empty((M, G * K), dtype=torch.float32, device=dev)
                 gemm("nn", dZ, W, dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
@@ -773,6 +881,28 @@ class LinearBNAct(Function):
             else:
                 grads += [None] * (2 * cfg["n_bn"])
         return (None, dx) + tuple(grads)
+
+
+_ZEROS = {}
+
+
+def _zero_scalar(dev):
+    z = _ZEROS.get(str(dev))
+    if z is None:
+        z = _ZEROS[str(dev)] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return z
+
+
+def oh_ready(oh):
+    """The one-hot tables' gradients live in the gradient arena right now (zero_grad re-points them every step)."""
+    tabs = []
+    for p, vocab, dim, off, col in oh.tables_p:
+        g = _grad_alias([p], 4)
+        if g is None:
+            return False
+        tabs.append((g, vocab, dim, off, col))
+    oh.tables = tabs
+    return True
 
 
 def _pad4(n):

@@ -50,7 +50,8 @@ def test_struct_layouts_match_the_header():
                "swr_gemm_args": H.GemmArgs, "swr_gemm_tn_args": H.GemmTnArgs, "swr_act_range": H.ActRange,
                "swr_mix_desc": H.MixDesc, "swr_adam_hyper": H.AdamHyper,
                "swr_dp_table": H.DpTable, "swr_star_layer_args": H.StarLayerArgs,
-               "swr_take_column": H.TakeColumn, "swr_layernorm_args": H.LayerNormArgs}
+               "swr_take_column": H.TakeColumn, "swr_layernorm_args": H.LayerNormArgs,
+               "swr_onehot_table": H.OnehotTable}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "swr.h"', 'int main(void){']
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -824,3 +824,37 @@ def test_sequence_pooled_lookup(B, L, dim, pooling, pad, idx_dtype, limit, monke
         got_grad = np.zeros((V, dim))
         np.add.at(got_grad, r[r >= 0], gg[r >= 0].astype(np.float64))
     np.testing.assert_allclose(got_grad, want_grad, rtol=0, atol=2e-6 * max(1.0, np.abs(want_grad).max()))
+
+
+def test_gather_one_hot_block_of_small_tables():
+    """`onehot=True` (training): behind the concat, ONE-HOT columns of the tables with <= 16 rows -- out[b, oh + off_t + v]
+    = (id_t(b) == v), exact 0.0 / 1.0; the alignment column in between is zero; the embeddings themselves are unchanged."""
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(5)
+    B, vocabs = 333, [2, 200, 7, 16, 17, 3]
+    feats = [SparseFeature(f"s{i}", v, 16) for i, v in enumerate(vocabs)] + [DenseFeature("d0"), DenseFeature("d1"), DenseFeature("d2")]
+    layer = EmbeddingLayer(feats).to("cuda").train()
+    with torch.no_grad():
+        for i in range(len(vocabs)):
+            layer.embed_dict[f"s{i}"].weight.normal_(0, 0.3)
+    x = {f"s{i}": rng.integers(0, v, size=B) for i, v in enumerate(vocabs)}
+    x.update({f"d{i}": rng.random(B).astype(np.float32) for i in range(3)})
+    xd = {k: _dev(v) for k, v in x.items()}
+    plain = layer(xd, feats, squeeze_dim=True)
+    out = layer(xd, feats, squeeze_dim=True, onehot=True)
+    info = out._swr_onehot
+    assert torch.equal(out, plain) and out.shape[1] == 6 * 16 + 3
+    assert info.oh_col == 100 and info.oh_width == 28            # 2 + 7 + 16 + 3 = 28 one-hot columns behind column 99 (+1 pad)
+    wide = torch.as_strided(out.detach(), (B, info.oh_col + info.oh_width), (out.stride(0), 1)).cpu().numpy()
+    assert np.array_equal(wide[:, 99], np.zeros(B, np.float32))
+    want = np.zeros((B, 28), np.float32)
+    off = 0
+    for i, v in enumerate(vocabs):
+        if v <= 16:
+            want[np.arange(B), off + x[f"s{i}"]] = 1.0
+            off += v
+    assert np.array_equal(wide[:, 100:], want)
+    assert sorted(t[1] for t in info.tables_p) == [2, 3, 7, 16]
+    layer.eval()
+    assert getattr(layer(xd, feats, squeeze_dim=True, onehot=True), "_swr_onehot", None) is None
