@@ -1154,18 +1154,22 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     }
 }
 
-// fixed-order sum of the per-workgroup partial tiles: L lanes share one output element (lane l takes partials l, l+L,
-// ... in order, UNROLL loads in flight) and are combined with a fixed butterfly -> deterministic; L grows with the
-// number of partials so that the per-lane chain stays a few loads long (tower layers have hundreds of partials)
+// fixed-order sum of the per-workgroup partial tiles.  A workgroup owns 256 / L consecutive output elements; thread
+// (sub, o) adds partials sub, sub + L, ... of element o in order (UNROLL loads in flight), so the 64 lanes of a wave read
+// 64 CONSECUTIVE floats of one partial matrix (coalesced; with the L lanes of an element adjacent, as before, every lane
+// of a wave touched another partial matrix: 19 us for 24 MB at config 2); the L per-thread sums of an element are then
+// added in sub order through LDS -> deterministic.  L grows with the number of partials so that the per-thread chain
+// stays a few loads long (tower layers have hundreds of partials).
 template <int L>
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
+    constexpr int OUTS = 256 / L;                     // output elements per workgroup
+    __shared__ float red[256];
     const swr_gemm_tn_args& a = kk.a;
     const int g = blockIdx.y;
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
     const int64_t np = static_cast<int64_t>(a.K1) * kk.k2p;           // elements of one partial matrix (pitch k2p >= K2)
-    const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t j = tid / L;
-    const int sub = static_cast<int>(tid % L);
+    const int sub = threadIdx.x / OUTS, o = threadIdx.x % OUTS;
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * OUTS + o;
     const int nparts = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
     auto lane_sum = [&](const float* __restrict__ p, int64_t stride) {
         float sum = 0.f;
@@ -1186,24 +1190,31 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
         if (kk.tail_rep > 0 && c >= kk.tail_q0)                          // the other replicas of the tail tile, in order
             for (int b = 1; b < kk.tail_rep; ++b) sum += lane_sum(pj + 32 * b, np);
     }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (sub == 0 && j < n) {
+        float tot = red[o];
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off);
-    if (j < n && sub == 0) {
+        for (int q = 1; q < L; ++q) tot += red[q * OUTS + o];
         const int64_t r = j / a.K2, c = j - r * a.K2;
         if (a.C2 && c >= a.c2_from) {
-            a.C2[r * a.ldc2 + (c - a.c2_from)] = sum;                    // second destination: always overwritten
+            a.C2[r * a.ldc2 + (c - a.c2_from)] = tot;                    // second destination: always overwritten
         } else {
             float* dst = a.C + g * a.gsC + r * a.ldc + c;
-            *dst = a.accumulate ? *dst + sum : sum;
+            *dst = a.accumulate ? *dst + tot : tot;
         }
     }
+    __syncthreads();
     float cs = 0.f;
     if (kk.part_cs && j < a.K1) cs = lane_sum(kk.part_cs + static_cast<int64_t>(g) * nparts * a.K1 + j, a.K1);
+    red[threadIdx.x] = cs;
+    __syncthreads();
+    if (kk.part_cs && sub == 0 && j < a.K1) {
+        float tot = red[o];
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) cs += __shfl_xor(cs, off);
-    if (kk.part_cs && j < a.K1 && sub == 0) {
+        for (int q = 1; q < L; ++q) tot += red[q * OUTS + o];
         float* dst = a.colsum + g * a.gsColsum + j;
-        *dst = a.accumulate ? *dst + cs : cs;
+        *dst = a.accumulate ? *dst + tot : tot;
     }
 }
 
@@ -1324,8 +1335,8 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         const dim3 rblock(256);
 #define TN_RED(LV)                                                                                                      \
     hipLaunchKernelGGL(tn_reduce_kernel<LV>, dim3(static_cast<unsigned>(swr_ceil_div(n * LV, 256)), 1u), rblock, 0, st, kk)
-        if (n_splits > 64) TN_RED(32);
-        else if (n_splits > 16) TN_RED(8);
+        if (n_splits > 128) TN_RED(32);
+        else if (n_splits > 64) TN_RED(8);
         else TN_RED(4);
 #undef TN_RED
         return swr_launch_status();
