@@ -36,6 +36,12 @@ class PLE(SwrModule):
             outs = self.cgc_layers[i].forward_fused(embed_x if i == 0 else outs, shared=(i == 0))
         H_ = self.cgc_layers[-1].out_dim
         D = self.domain_num
+        if not self.training and ops.routed_eval_ok(outs):
+            # inference: a row's own tower only (the CGC levels mix experts across domains and stay whole-batch)
+            route = ops.DomainRouting(domain_id, D)
+            os_ = route.rows(outs)
+            return ops.routed_probs(route, [self.towers[d](route.segment(os_, d)[:, d * H_:(d + 1) * H_]) if route.count(d) else None
+                                            for d in range(D)])
         logits = mlp_bank_forward(list(self.towers), outs[:, :D * H_], shared_input=False)      # [B, D]
         return ops.domain_select(logits, domain_id, apply_sigmoid=True)
 

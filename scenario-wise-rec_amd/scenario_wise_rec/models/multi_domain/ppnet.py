@@ -24,11 +24,18 @@ class PPTowerBlock(SwrModule):
         self.final_layer = nn.Linear(self.dims[-1], 1)
         self.sig = activation_layer("sigmoid")
 
-    def forward(self, agn_emb, gate_input_emb):
+    def _hidden(self, gate_input_emb):
         hidden = gate_input_emb
         for i in range(len(self.mlp_layers)):
             hidden = ops.mul(self.mlp_layers[i](hidden), self.gate_layers[i](gate_input_emb))
-        return LayerBank([self.final_layer], None, ["sigmoid"])(hidden, self.training)
+        return hidden
+
+    def forward(self, agn_emb, gate_input_emb):
+        return LayerBank([self.final_layer], None, ["sigmoid"])(self._hidden(gate_input_emb), self.training)
+
+    def logits(self, gate_input_emb):
+        """forward() before its sigmoid (the routed inference path selects logits)."""
+        return LayerBank([self.final_layer], None, [None])(self._hidden(gate_input_emb), self.training)
 
 
 class PPNet(SwrModule):
@@ -76,6 +83,11 @@ class PPNet(SwrModule):
         T, L, D = list(self.domain_tower), self.n_layers, self.domain_num
         # cat(id_x, agn_x.detach()) (ppnet.py:54) as one lookup; the agnostic tables take no gradient
         gate_in = fused_lookup(x, [(self.id_embedding, self.id_features), (self.agn_embedding, self.agn_features, True)])
+        if not self.training and ops.routed_eval_ok(gate_in):
+            # inference: a row runs its own domain's tower only (PPTowerBlock.forward on that domain's rows)
+            route = ops.DomainRouting(domain_id, D)
+            gs = route.rows(gate_in)
+            return ops.routed_probs(route, [T[d].logits(route.segment(gs, d)) if route.count(d) else None for d in range(D)])
         dims = T[0].dims
         # two stacked products on the shared input: the D first tower layers (BN + ReLU) and the hidden
         # layers of all D*L GateNUs (ReLU)

@@ -28,6 +28,12 @@ class SharedBottom(SwrModule):
         domain_id = x["domain_indicator"]
         # (the bottom MLP's first layer is the only reader of the lookup: ops.OneHotInfo)
         h = self.bottom_mlp(self.embedding(x, self.features, squeeze_dim=True, onehot=self.bottom_mlp.n_blocks > 0))
+        if not self.training and ops.routed_eval_ok(h):
+            # inference: every row through its own domain's tower only (BatchNorm is a fixed affine in eval mode)
+            route = ops.DomainRouting(domain_id, self.domain_num)
+            hs = route.rows(h)
+            return ops.routed_probs(route, [self.towers[d](route.segment(hs, d)) if route.count(d) else None
+                                            for d in range(self.domain_num)])
         # all towers read the same h: their first layers are one stacked product, the rest grouped
         logits = mlp_bank_forward(list(self.towers), h, shared_input=True)          # [B, D]
         return ops.domain_select(logits, domain_id, apply_sigmoid=True)

@@ -85,6 +85,27 @@ class Star(SwrModule):
                   [b.running_var for b in bns], [b.num_batches_tracked for b in bns]]
         return g
 
+    def _routed_eval(self, h, domain_id, aux_out):
+        """Inference: the partitioned norm's statistics are whole-batch (computed above); everything after it is per row,
+        so a row runs the FCN stack of its own domain only -- 1/D of the dense evaluation's products."""
+        D = self.num_domains
+        route = ops.DomainRouting(domain_id, D)
+        hs = route.rows(h)
+        xs = [route.segment(hs, d) for d in range(D)]
+        for l in range(self.layer_num):
+            first = l == 0
+            params = [self.share_parm_w[l], self.share_parm_b[l]] + ([self.dn_share_gamma, self.dn_share_bias] if first else [])
+            params += [self.domain_specific_w[d][l] for d in range(D)] + [self.domain_specific_b[d][l] for d in range(D)]
+            if first:
+                params += list(self.domain_specific_dn_gamma) + list(self.domain_specific_dn_bias)
+            eff = ops.star_layer_weights(first, D, *params)
+            for d in range(D):
+                if route.count(d):
+                    xs[d] = ops.linear_bn_act(xs[d], [eff[d]], [eff[D + d]], bn=_bn_dict([self.domain_specific_bn[d][l]]),
+                                              acts="relu", groups=1, training=False)
+        sel = route.scatter([xs[d] if route.count(d) else None for d in range(D)])
+        return torch.sigmoid(sel + aux_out.reshape(-1))
+
     def forward(self, x):
         domain_id = x["domain_indicator"]
         emb = self.embedding(x, self.features, squeeze_dim=True)
@@ -92,6 +113,8 @@ class Star(SwrModule):
         D = self.num_domains
         # partitioned norm, shared part (identical for every domain, star.py:95-98): biased variance, eps 1e-6
         h = ops.batch_standardize(emb, self.eps)
+        if not self.training and D <= 8 and ops.routed_eval_ok(h):
+            return self._routed_eval(h, domain_id, aux_out)
         for l in range(self.layer_num):
             if D <= 8 and os.environ.get("SWR_STAR_FUSED", "1") != "0":
                 # effective weights of the layer for all domains: one launch each way (csrc/star.hip)

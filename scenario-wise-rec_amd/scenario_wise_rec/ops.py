@@ -1515,6 +1515,57 @@ def star_layer_weights(first, D, *params):
 
 
 # =========================================================================== routed inference
+ROUTED_EVAL = os.environ.get("SWR_ROUTED_EVAL", "1") != "0"
+
+
+def routed_eval_ok(x):
+    """Inference only: BatchNorm is a fixed affine there, so a row needs nothing but its own domain's branch."""
+    return ROUTED_EVAL and x.is_cuda and not torch.is_grad_enabled()
+
+
+class DomainRouting(object):
+    """Rows grouped by domain for inference: `rows(x)` = x with the rows of domain 0 first, then domain 1, ... (ids outside
+    [0, D) last); `segment(xs, d)` = the contiguous rows of domain d; `scatter(parts)` puts the per-domain results back in
+    batch order, zeros where the id is out of range (the reference's chain of `where` from zeros, mmoe.py:53-55).  The
+    reference evaluates every domain's branch on the whole batch and selects; in eval mode this is the same numbers
+    with 1/D of the tower work.  One host sync per batch (the segment bounds)."""
+
+    def __init__(self, domain_id, D):
+        d = domain_id.reshape(-1).long()
+        key = torch.where((d >= 0) & (d < D), d, torch.full_like(d, D))
+        self.perm = torch.argsort(key, stable=True)
+        self.bounds = [0] + torch.cumsum(torch.bincount(key, minlength=D + 1), 0).tolist()
+        self.D, self.B = D, d.numel()
+
+    def rows(self, x):
+        return x.index_select(0, self.perm)
+
+    def segment(self, xs, d):
+        return xs[self.bounds[d]:self.bounds[d + 1]]
+
+    def count(self, d):
+        return self.bounds[d + 1] - self.bounds[d]
+
+    def scatter(self, parts):
+        """parts[d]: [count(d)] or [count(d), 1] (None for an empty domain) -> [B]."""
+        vals = [p.reshape(-1) for p in parts if p is not None and p.numel()]
+        out = torch.zeros(self.B, dtype=torch.float32, device=self.perm.device)
+        if vals:
+            cat = torch.cat(vals)
+            out.index_copy_(0, self.perm[:cat.numel()], cat)
+        return out
+
+    def valid(self):
+        m = torch.zeros(self.B, dtype=torch.bool, device=self.perm.device)
+        m[self.perm[:self.bounds[self.D]]] = True
+        return m
+
+
+def routed_probs(route, logit_parts):
+    """sigmoid of the selected logits, exactly 0.0 for rows whose domain id is out of range."""
+    sel = route.scatter(logit_parts)
+    return torch.where(route.valid(), torch.sigmoid(sel), torch.zeros_like(sel))
+
 def routed_mmoe_eval(y, n_expert, H_, towers_w1, towers_b1, towers_bn, towers_w2, towers_b2, domain_id):
     """Eval-mode MMoE head, routed: every row mixes the experts with its own domain's gate probabilities and runs its
     own domain's tower (csrc/routed.hip) instead of every domain's on the whole batch followed by the select

@@ -199,3 +199,30 @@ def test_results_do_not_depend_on_stale_memory(name, rows):
         got = _one_step_bits(c, rows, bits)
         for k, v in ref.items():
             assert np.array_equal(got[k], v, equal_nan=True), f"{name}: {k} depends on stale memory (pattern {bits:#x})"
+
+
+@pytest.mark.parametrize("name", ["sharedbottom", "ple", "ple_2level", "star", "ppnet"])
+def test_routed_eval_equals_the_all_domains_eval(name, monkeypatch):
+    """Inference routes every row through its own domain's branch only; the reference evaluates all
+    branches on the whole batch and selects.  Same probabilities (BatchNorm is a fixed affine in eval mode), including
+    ids outside [0, D) -> exactly 0.0 (sigmoid(aux) for STAR) and an empty domain."""
+    from scenario_wise_rec import ops
+    c = Case(name)
+    model = build_product_model(c).eval()
+    x, _ = c.batch(0)
+    x = {k: v.copy() for k, v in x.items()}
+    D = c.meta["domain_num"]
+    dom = x["domain_indicator"]
+    dom[dom == D - 1] = 0                    # an empty domain
+    dom[::9] = D                             # out-of-range ids
+    dom[4::13] = -1
+    xd = to_device(x)
+    with torch.no_grad():
+        monkeypatch.setattr(ops, "ROUTED_EVAL", True)
+        routed = model(xd).cpu().numpy()
+        monkeypatch.setattr(ops, "ROUTED_EVAL", False)
+        dense = model(xd).cpu().numpy()
+    bad = (dom < 0) | (dom >= D)
+    if name != "star":
+        assert np.array_equal(routed[bad], np.zeros(bad.sum(), np.float32))
+    np.testing.assert_allclose(routed, dense, rtol=0, atol=2e-7)
