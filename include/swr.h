@@ -132,6 +132,24 @@ int swr_embed_bag_fwd(const float* weight, int64_t vocab, int dim, const void* i
 int swr_embed_bag_bwd_expand(const float* d_out, int64_t ld, int in_col, int dim, int L, int concat, const float* wts,
                              int64_t B, float* d_rows /* [B*L, dim] */, void* stream);
 
+/* ---- folded first layer (training; no reference counterpart: an algebraic restructuring of `embedding -> Linear`,
+ * basic/layers.py:64-105 + 253).  With the one-hot block O of the small tables next to the embeddings E_big of the
+ * other tables and the dense features x_d, the layer's product is
+ *     [E_small | E_big | x_d] W^T  =  [E_big | x_d | O] Wp^T,   Wp = [W_big | W_d | P],  P_t[:, v] = W_t emb_t[v]  (tiny)
+ * so the lookup writes only [E_big | x_d | O] (a slot with dim = 0 contributes nothing but its one-hot columns) and the
+ * products of the layer run over Kp + ohw columns instead of K.  Backward: dWp = dZ^T [E_big | x_d | O] (swr_gemm_tn),
+ * then swr_fold_first_layer_bwd scatters it back: dW[:, c] (+)= dWp[:, compact(c)] for the other tables' and the dense
+ * columns, dW[:, col_t + e] (+)= sum_v S_t[:, v] emb_t[v, e] with S = dWp[:, Kp:], and db (+)= dbp;
+ * swr_onehot_table_grads(S, W) gives the small tables' own gradients.
+ * src_col [Kp] (device): column of W behind compact column j (-1: zero padding); inv_col [K] (device): compact column
+ * of W's column c, or -1 - t for a column of small table t (index into `tables`).  tables[t].grad = emb_t here. */
+int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, int ohw, const int32_t* src_col,
+                             const int32_t* inv_col, const swr_onehot_table* tables_host, int n_tables, float* Wp,
+                             int64_t ldwp, void* stream);
+int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const float* dbp /* nullable */, int N, int K, int Kp, int ohw,
+                             const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables_host,
+                             int n_tables, float* dW, int64_t lddw, float* db /* nullable */, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------ K3 ----
  * Backward of the lookup: replaces aten::embedding_dense_backward (32 calls
  * per step at the KuaiRand config, each zero-filling [V, E]).

@@ -209,7 +209,9 @@ extern "C" int swr_embed_gather_fwd_onehot(const swr_sparse_slot* sparse, int n_
         bool vec = swr_aligned16(out) && (ld_out % 4 == 0);
         for (int s = 0; s < a.n_sparse; ++s) {
             const swr_sparse_slot& sl = sparse[s0 + s];
-            SWR_REQUIRE(sl.weight && sl.idx && sl.vocab > 0 && sl.dim > 0 && sl.out_col >= 0, SWR_ERR_ARG);
+            SWR_REQUIRE(sl.weight && sl.idx && sl.vocab > 0 && sl.out_col >= 0, SWR_ERR_ARG);
+            // dim == 0: the slot only feeds the one-hot block (its embedding is folded into the consuming layer's weights)
+            SWR_REQUIRE(sl.dim > 0 || (sl.dim == 0 && oh_width > 0 && oh_off[s0 + s] >= 0), SWR_ERR_ARG);
             SWR_REQUIRE(sl.vocab <= 0xFFFFFFFFll, SWR_ERR_UNSUPPORTED);
             SWR_REQUIRE(swr_is_index_dtype(sl.idx_dtype), SWR_ERR_DTYPE);
             vec = vec && (sl.dim % 4 == 0) && (sl.out_col % 4 == 0) && swr_aligned16(sl.weight);
@@ -315,5 +317,107 @@ extern "C" int swr_onehot_table_grads(const float* S, int64_t lds, const float* 
                            dim3(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(pos) * OHT_LANES, GATHER_THREADS))),
                            dim3(GATHER_THREADS), 0, st, k);
     }
+    return swr_launch_status();
+}
+
+
+// ---- first layer folded over the one-hot block (include/swr.h "folded first layer")
+struct FoldK {
+    swr_onehot_table tab[OHT_MAX];      // .grad = the table's weights here (forward) / dEmb is not touched by these kernels
+    int n_tables, N, Kp, ohw, K, accumulate;
+    const int32_t* src_col;             // [Kp]: column of W behind compact column j, -1 = zero padding
+    const int32_t* inv_col;             // [K] : compact column of W's column k, or -1 - t for a column of small table t
+    const float* W; int64_t ldw;
+    float* Wp; int64_t ldwp;            // forward: folded weights [N, Kp + ohw]
+    const float* dWp; int64_t lddwp;    // backward: gradient of the folded weights
+    const float* dbp;                   // backward: bias gradient (column sums of dZ), nullable
+    float* dW; int64_t lddw; float* db;
+};
+
+// Wp[n, j] = W[n, src_col[j]] (j < Kp);  Wp[n, Kp + off_t + v] = sum_e emb_t[v, e] W[n, col_t + e]
+__global__ __launch_bounds__(GATHER_THREADS) void fold_fwd_kernel(const FoldK k) {
+    const int width = k.Kp + k.ohw;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x;
+    if (i >= static_cast<int64_t>(k.N) * width) return;
+    const int n = static_cast<int>(i / width), j = static_cast<int>(i - static_cast<int64_t>(n) * width);
+    float v = 0.f;
+    if (j < k.Kp) {
+        const int c = k.src_col[j];
+        if (c >= 0) v = k.W[n * k.ldw + c];
+    } else {
+        const int o = j - k.Kp;
+        for (int t = 0; t < k.n_tables; ++t) {
+            const swr_onehot_table& T = k.tab[t];
+            if (o >= T.oh_off && o < T.oh_off + T.vocab) {
+                const float* e = T.grad + static_cast<int64_t>(o - T.oh_off) * T.dim;
+                const float* w = k.W + n * k.ldw + T.w_col;
+                for (int q = 0; q < T.dim; ++q) v = fmaf(e[q], w[q], v);
+                break;
+            }
+        }
+    }
+    k.Wp[n * k.ldwp + j] = v;
+}
+
+// dW[n, c] (+)= dWp[n, inv_col[c]]  or, for a column of small table t,  sum_v dWp[n, Kp + off_t + v] emb_t[v, c - col_t];
+// db (+)= dbp
+__global__ __launch_bounds__(GATHER_THREADS) void fold_bwd_kernel(const FoldK k) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x;
+    if (i < k.N && k.db && k.dbp) k.db[i] = k.accumulate ? k.db[i] + k.dbp[i] : k.dbp[i];
+    if (i >= static_cast<int64_t>(k.N) * k.K) return;
+    const int n = static_cast<int>(i / k.K), c = static_cast<int>(i - static_cast<int64_t>(n) * k.K);
+    const int m = k.inv_col[c];
+    float v = 0.f;
+    if (m >= 0) {
+        v = k.dWp[n * k.lddwp + m];
+    } else {
+        const swr_onehot_table& T = k.tab[-1 - m];
+        const int e = c - T.w_col;
+        const float* s = k.dWp + n * k.lddwp + k.Kp + T.oh_off;
+        for (int q = 0; q < T.vocab; ++q) v = fmaf(s[q], T.grad[static_cast<int64_t>(q) * T.dim + e], v);
+    }
+    float* dst = k.dW + n * k.lddw + c;
+    *dst = k.accumulate ? *dst + v : v;
+}
+
+static int fold_fill(FoldK& k, const swr_onehot_table* tables, int n_tables, int N, int K, int Kp, int ohw, const int32_t* src_col,
+                     const int32_t* inv_col, const float* W, int64_t ldw) {
+    SWR_REQUIRE(tables && n_tables > 0 && n_tables <= OHT_MAX && N > 0 && K > 0 && Kp >= 0 && ohw > 0 && src_col && inv_col &&
+                    (W == nullptr || ldw >= K), SWR_ERR_ARG);
+    for (int t = 0; t < n_tables; ++t) {
+        SWR_REQUIRE(tables[t].grad && tables[t].vocab > 0 && tables[t].dim > 0 && tables[t].oh_off >= 0 &&
+                        tables[t].oh_off + tables[t].vocab <= ohw && tables[t].w_col >= 0 && tables[t].w_col + tables[t].dim <= K,
+                    SWR_ERR_ARG);
+        k.tab[t] = tables[t];
+    }
+    k.n_tables = n_tables; k.N = N; k.K = K; k.Kp = Kp; k.ohw = ohw; k.src_col = src_col; k.inv_col = inv_col; k.W = W; k.ldw = ldw;
+    return SWR_OK;
+}
+
+extern "C" int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, int ohw, const int32_t* src_col,
+                                        const int32_t* inv_col, const swr_onehot_table* tables, int n_tables, float* Wp,
+                                        int64_t ldwp, void* stream) {
+    FoldK k;
+    int rc = fold_fill(k, tables, n_tables, N, K, Kp, ohw, src_col, inv_col, W, ldw);
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(W && Wp && ldwp >= Kp + ohw, SWR_ERR_ARG);
+    k.Wp = Wp; k.ldwp = ldwp;
+    const int64_t total = static_cast<int64_t>(N) * (Kp + ohw);
+    hipLaunchKernelGGL(fold_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(total, GATHER_THREADS))), dim3(GATHER_THREADS), 0,
+                       static_cast<hipStream_t>(stream), k);
+    return swr_launch_status();
+}
+
+extern "C" int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const float* dbp, int N, int K, int Kp, int ohw,
+                                        const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables,
+                                        int n_tables, float* dW, int64_t lddw, float* db, int accumulate, void* stream) {
+    FoldK k;
+    int rc = fold_fill(k, tables, n_tables, N, K, Kp, ohw, src_col, inv_col, nullptr, 0);   // (W is not read here)
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(dWp && dW && lddwp >= Kp + ohw && lddw >= K, SWR_ERR_ARG);
+    k.dWp = dWp; k.lddwp = lddwp; k.dbp = dbp; k.dW = dW; k.lddw = lddw; k.db = db; k.accumulate = accumulate;
+    const int64_t total = static_cast<int64_t>(N) * K;
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(total, GATHER_THREADS))), dim3(GATHER_THREADS), 0,
+                       static_cast<hipStream_t>(stream), k);
     return swr_launch_status();
 }

@@ -77,7 +77,7 @@ def _new_plan(layer):
     plan = ops._GatherPlan()
     plan.sparse, plan.dense, plan.width = [], [], 0
     plan.bags = []
-    plan.onehot, plan.oh, plan.ctx = False, None, None
+    plan.onehot, plan.oh, plan.ctx, plan.fold, plan.wide = False, None, None, None, None
     plan.lazy = {}
     plan.dense_limit_bytes = layer.dense_table_limit_bytes
     return plan, []
@@ -121,7 +121,8 @@ def _run_plan(plan, weights):
         # hand the one-hot block to the consuming layer (ops.OneHotInfo): which tables it covers, and the compact column
         # layout of the dX that layer owes the remaining (K3) slots
         info = ops.OneHotInfo()
-        info.ctx, info.oh_col = plan.ctx, (plan.width + 3) // 4 * 4
+        info.ctx = plan.ctx
+        info.oh_col = plan.fold["col0"] + plan.fold["Kp"] if plan.fold is not None else (plan.width + 3) // 4 * 4
         info.oh_width = plan.ld - info.oh_col
         info.tables_p = [(weights[wpos], vocab, dim, off, col) for _i, wpos, vocab, dim, off, col in plan.oh]
         info.params = tuple({id(t[0]): t[0] for t in info.tables_p}.values())
@@ -135,6 +136,19 @@ def _run_plan(plan, weights):
         cols.extend([cols[-1]] * pad if cols else [])              # (16-byte rows for the product; the pad columns are never read)
         info.compact, info.n_sel = compact, len(cols)
         info.sel = _sel_tensor(tuple(cols), out.device) if cols else None
+        info.fold, info.wide, info.K = plan.fold is not None, plan.wide, plan.width
+        if plan.fold is not None:
+            f = plan.fold
+            info.col0, info.Kp = f["col0"], f["Kp"]
+            inv = [0] * plan.width
+            for j, c in enumerate(f["src"]):
+                if c >= 0:
+                    inv[c] = j
+            for t, (_i, _wpos, _vocab, dim, _off, col) in enumerate(plan.oh):
+                for e in range(dim):
+                    inv[col + e] = -1 - t
+            info.src = _sel_tensor(f["src"], out.device, torch.int32)
+            info.inv = _sel_tensor(tuple(inv), out.device, torch.int32)
         out._swr_onehot = info
     # columns that can take a gradient: everything up to the end of the last embedding column (dense-feature columns are
     # inputs).  A layer that reads this tensor need not compute d/dx beyond it (ops.LinearBNAct: `n_compute` of dX).
@@ -146,13 +160,13 @@ def _run_plan(plan, weights):
 _SEL_CACHE = {}
 
 
-def _sel_tensor(cols, device):
+def _sel_tensor(cols, device, dtype=torch.int64):
     """Column index list on the device, cached: built once per (layout, device) -- an upload per step would be a host
     sync and cannot be captured into a hipGraph."""
-    key = (cols, str(device))
+    key = (cols, str(device), dtype)
     t = _SEL_CACHE.get(key)
     if t is None:
-        t = _SEL_CACHE[key] = torch.tensor(cols, dtype=torch.int64, device=device)
+        t = _SEL_CACHE[key] = torch.tensor(cols, dtype=dtype, device=device)
     return t
 
 

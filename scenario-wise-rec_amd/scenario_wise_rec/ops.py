@@ -337,7 +337,7 @@ def _split_like(flat, tensors):
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide")
     # onehot: the caller promises that ONE LinearBNAct consumes the lookup (see OneHotInfo); oh: the block laid out by forward
     # bags: SequenceFeature lookups, dicts(wpos, idx [B, L], vocab, dim, col, L, mode 0 sum / 1 mean / 2 concat, pad, seed)
 
@@ -345,6 +345,7 @@ class _GatherPlan:
 ONEHOT = os.environ.get("SWR_ONEHOT", "1") != "0"
 ONEHOT_MAX_VOCAB = int(os.environ.get("SWR_ONEHOT_MAX_VOCAB", "16"))
 ONEHOT_MAX_WIDTH = int(os.environ.get("SWR_ONEHOT_MAX_WIDTH", "128"))
+FOLD = os.environ.get("SWR_FOLD", "1") != "0"       # the lookup writes [E_big | dense | one-hot] only; the layer folds the rest
 
 
 class OneHotInfo(object):
@@ -354,7 +355,8 @@ class OneHotInfo(object):
         per-row segment sums S of dZ in one launch; grad_t = S_t W_t (swr_onehot_table_grads) -- no K3 for them;
       * computes dX only for the columns of the other tables (`sel`), compactly, and passes it to the lookup's backward
         through `ctx` (autograd carries a zero-stride placeholder)."""
-    __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact")
+    __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact",
+                 "fold", "wide", "col0", "Kp", "src", "inv", "K")
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -402,22 +404,46 @@ class EmbedGather(Function):
                                [plan.sparse[t[0]] for t in tables] + plan.sparse[ng:])
                 first = ng - len(tables)
                 tables = [(first + j,) + t[1:] for j, t in enumerate(tables)]
-                oh_col = (plan.width + 3) // 4 * 4
                 oh_width = (off + 3) // 4 * 4
                 oh_off = (C.c_int32 * ns)(*([-1] * ns))
                 for i, _w, _v, _d, o, _c in tables:
                     oh_off[i] = o
-                plan.ld = oh_col + oh_width
                 plan.oh = tables
+                pad_col, oh_col = plan.width, (plan.width + 3) // 4 * 4
+                if FOLD:
+                    # folded layout (include/swr.h "folded first layer"): behind the (unwritten) ordinary columns a compact
+                    # block [embeddings of the other tables | dense features | 0-padding | one-hot]; the consuming layer
+                    # multiplies THAT with its folded weights
+                    oh_set = {t[0] for t in tables}
+                    col0 = (plan.width + 3) // 4 * 4
+                    cc, src, sp_col = col0, [], {}
+                    for i, (_wpos, _idx, _vocab, dim, col, _seed) in enumerate(plan.sparse):
+                        if i not in oh_set:
+                            sp_col[i] = cc
+                            src.extend(range(col, col + dim))
+                            cc += dim
+                    dn_col = []
+                    for _vals, col in plan.dense:
+                        dn_col.append(cc)
+                        src.append(col)
+                        cc += 1
+                    Kp = (cc - col0 + 3) // 4 * 4
+                    src.extend([-1] * (Kp - (cc - col0)))
+                    pad_col, oh_col = cc, col0 + Kp
+                    plan.fold = {"col0": col0, "Kp": Kp, "src": tuple(src), "sp_col": sp_col, "dn_col": dn_col}
+                plan.ld = oh_col + oh_width
+        fold = getattr(plan, "fold", None) if plan.oh else None
         out = torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
         sp = (H.SparseSlot * max(ns, 1))()
         for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse):
             H.require_device(idx, weights[wpos])
+            if fold is not None:            # compact column; a folded (one-hot) slot writes no embedding at all (dim 0)
+                col, dim = (fold["sp_col"][i], dim) if i in fold["sp_col"] else (0, 0)
             sp[i] = H.SparseSlot(weights[wpos].data_ptr(), idx.data_ptr(), vocab, dim, H.dtype_code(idx), col, seed)
         dn = (H.DenseSlot * max(nd, 1))()
         for i, (vals, col) in enumerate(plan.dense):
             H.require_device(vals)
-            dn[i] = H.DenseSlot(vals.data_ptr(), H.dtype_code(vals), col)
+            dn[i] = H.DenseSlot(vals.data_ptr(), H.dtype_code(vals), fold["dn_col"][i] if fold is not None else col)
         # lazily updated tables (optim.LazyRows): bring the rows about to be read up to date first (exact replay)
         seen = set()
         for wpos, idx, vocab, dim, col, seed in plan.sparse:
@@ -429,8 +455,9 @@ class EmbedGather(Function):
         keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
         flag = H.err_flag(dev)
         if plan.oh:
-            H.check(lib.swr_embed_gather_fwd_onehot(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), oh_off, plan.width,
+            H.check(lib.swr_embed_gather_fwd_onehot(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), oh_off, pad_col,
                                                     oh_col, oh_width, H.ptr(flag), H.stream()), "swr_embed_gather_fwd_onehot")
+            plan.wide = out
         else:
             H.check(lib.swr_embed_gather_fwd(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), H.ptr(flag), H.stream()),
                     "swr_embed_gather_fwd")
@@ -500,6 +527,9 @@ class EmbedGather(Function):
             if ctx.n_k3_slots == 0:
                 return (None,) + (None,) * len(weights)
         else:
+            if getattr(plan, "fold", None) and plan.oh:
+                raise H.SwrError("a lookup made with onehot=True was not consumed by the ONE fused layer it was promised to "
+                                 "(EmbeddingLayer.forward(..., onehot=True)): its ordinary columns were never written")
             dE, compact = H.f32c(dE), None
         dev = dE.device
         if no_plain:
@@ -689,8 +719,26 @@ class LinearBNAct(Function):
                 and x.data_ptr() % 16 == 0):
             # weights split into bf16 planes once per step (and W^T's planes for the dX product of the backward)
             planes, planes_t = split_weights(W, bool(ctx.needs_input_grad[1]) and Ntot % 4 == 0)
-        gemm("nt", x, W, Z, M, N, K, bias=b, stat_partials=partials, groups=G,
-             gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N, B_split=planes)
+        oh_in = getattr(x_in, "_swr_onehot", None)
+        if oh_in is not None and oh_in.fold:
+            # the lookup wrote [E_big | dense | one-hot] only (OneHotInfo / include/swr.h "folded first layer"): multiply
+            # that with the folded weights [W_big | W_dense | P], P_t[:, v] = W_t emb_t[v]
+            if G != 1 or K != oh_in.K or not oh_tables(oh_in):
+                raise H.SwrError("a lookup made with onehot=True must feed ONE ungrouped Linear over all its columns")
+            Kf = oh_in.Kp + oh_in.oh_width
+            x = oh_in.wide[:, oh_in.col0:oh_in.col0 + Kf]
+            Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
+            tabs = (H.OnehotTable * len(oh_in.tables_p))()
+            for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
+                tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
+            H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
+                                                 H.ptr(oh_in.inv), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
+                    "swr_fold_first_layer_fwd")
+            gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials)
+            planes_t = None
+        else:
+            gemm("nt", x, W, Z, M, N, K, bias=b, stat_partials=partials, groups=G,
+                 gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N, B_split=planes)
         ctx.planes_t = planes_t
         acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
         mean = rstd = scale = shift = None
@@ -729,8 +777,9 @@ class LinearBNAct(Function):
                                            Ntot, H.stream()), "swr_affine_act_fwd")
         ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
         ctx.grad_cols = getattr(x_in, "_swr_grad_cols", None)
-        oh = getattr(x_in, "_swr_onehot", None)
-        ctx.onehot = oh if (oh is not None and G == 1 and x.data_ptr() == x_in.data_ptr() and x.stride(0) == oh.oh_col + oh.oh_width) else None
+        oh = oh_in
+        ctx.onehot = oh if (oh is not None and G == 1 and (oh.fold or (x.data_ptr() == x_in.data_ptr()
+                                                                        and x.stride(0) == oh.oh_col + oh.oh_width))) else None
         ctx.params = params
         ctx.training_bn = training
         ctx.mix = mix
@@ -808,8 +857,28 @@ class LinearBNAct(Function):
             dW = torch.empty((Ntot, K), dtype=torch.float32, device=dev)
             db = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
         oh = ctx.onehot if (ctx.onehot is not None and direct_w and ctx.needs_input_grad[1] and oh_ready(ctx.onehot)) else None
+        if ctx.onehot is not None and ctx.onehot.fold and oh is None:
+            raise H.SwrError("folded first layer: the layer's and the small tables' gradients must live in the gradient arena "
+                             "(SwrModule.build_arena) and the lookup must take a gradient")
 
         def launch_dw():
+            if oh is not None and oh.fold:
+                # dWp = dZ^T [E_big | dense | one-hot]; unfolded into dW / db (arena), the small tables' gradients from S
+                Kf = oh.Kp + oh.oh_width
+                dWp = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
+                dbp = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
+                gemm_tn(dZ, x, dWp, M, N, Kf, colsum=dbp)
+                tw = (H.OnehotTable * len(oh.tables_p))()
+                tg = (H.OnehotTable * len(oh.tables))()
+                for j, ((p_t, vocab, dim, off, col), (g_t, *_r)) in enumerate(zip(oh.tables_p, oh.tables)):
+                    tw[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
+                    tg[j] = H.OnehotTable(g_t.data_ptr(), vocab, dim, oh.Kp + off, col)
+                H.check(lib.swr_fold_first_layer_bwd(H.ptr(dWp), Kf, H.ptr(dbp), Ntot, K, oh.Kp, oh.oh_width, H.ptr(oh.src),
+                                                     H.ptr(oh.inv), tw, len(oh.tables_p), H.ptr(dW), K, H.ptr(db), 1, H.stream()),
+                        "swr_fold_first_layer_bwd")
+                H.check(lib.swr_onehot_table_grads(H.ptr(dWp), Kf, H.ptr(W), W.stride(0), Ntot, tg, len(oh.tables), 1,
+                                                   H.stream()), "swr_onehot_table_grads")
+                return
             if oh is not None:
                 # dZ^T [E | 0 | one-hot]: dW into the arena, the segment sums of dZ per small-table row into S, then the small
                 # tables' gradients S_t W_t straight into the arena (OneHotInfo)
@@ -894,6 +963,11 @@ def _zero_scalar(dev):
     if z is None:
         z = _ZEROS[str(dev)] = torch.zeros(1, dtype=torch.float32, device=dev)
     return z
+
+
+def oh_tables(oh):
+    """Folded layout: the tables must be current fp32 tensors on the layer's device (always true for arena members)."""
+    return all(p.dtype == torch.float32 and p.is_contiguous() for p, *_r in oh.tables_p)
 
 
 def oh_ready(oh):

@@ -826,11 +826,16 @@ def test_sequence_pooled_lookup(B, L, dim, pooling, pad, idx_dtype, limit, monke
     np.testing.assert_allclose(got_grad, want_grad, rtol=0, atol=2e-6 * max(1.0, np.abs(want_grad).max()))
 
 
-def test_gather_one_hot_block_of_small_tables():
+@pytest.mark.parametrize("fold", [False, True], ids=["block", "folded"])
+def test_gather_one_hot_block_of_small_tables(fold, monkeypatch):
     """`onehot=True` (training): behind the concat, ONE-HOT columns of the tables with <= 16 rows -- out[b, oh + off_t + v]
-    = (id_t(b) == v), exact 0.0 / 1.0; the alignment column in between is zero; the embeddings themselves are unchanged."""
+    = (id_t(b) == v), exact 0.0 / 1.0; the alignment column in between is zero.  `block`: the embeddings themselves are
+    unchanged; `folded`: only [embeddings of the other tables | dense | 0 | one-hot] is written, behind the ordinary
+    columns (the consuming layer folds the small tables into its weights)."""
+    from scenario_wise_rec import ops
     from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
     from scenario_wise_rec.basic.layers import EmbeddingLayer
+    monkeypatch.setattr(ops, "FOLD", fold)
     rng = np.random.default_rng(5)
     B, vocabs = 333, [2, 200, 7, 16, 17, 3]
     feats = [SparseFeature(f"s{i}", v, 16) for i, v in enumerate(vocabs)] + [DenseFeature("d0"), DenseFeature("d1"), DenseFeature("d2")]
@@ -844,11 +849,26 @@ def test_gather_one_hot_block_of_small_tables():
     plain = layer(xd, feats, squeeze_dim=True)
     out = layer(xd, feats, squeeze_dim=True, onehot=True)
     info = out._swr_onehot
-    assert torch.equal(out, plain) and out.shape[1] == 6 * 16 + 3
-    assert info.oh_col == 100 and info.oh_width == 28            # 2 + 7 + 16 + 3 = 28 one-hot columns behind column 99 (+1 pad)
+    assert out.shape[1] == 6 * 16 + 3 and info.oh_width == 28    # 2 + 7 + 16 + 3 = 28 one-hot columns
+    want = np.zeros((B, 28), np.float32)
+    if fold:
+        wide = info.wide.detach().cpu().numpy()
+        pl = plain.detach().cpu().numpy()
+        # compact block from column 100: tables s1 (200 rows) and s4 (17 rows), the three dense features, one pad column
+        assert info.col0 == 100 and info.Kp == 36 and info.oh_col == 136 and wide.shape[1] == 164
+        assert np.array_equal(wide[:, 100:116], pl[:, 16:32]) and np.array_equal(wide[:, 116:132], pl[:, 64:80])
+        assert np.array_equal(wide[:, 132:135], pl[:, 96:99]) and np.array_equal(wide[:, 135], np.zeros(B, np.float32))
+        off = 0
+        for i, v in enumerate(vocabs):
+            if v <= 16:
+                want[np.arange(B), off + x[f"s{i}"]] = 1.0
+                off += v
+        assert np.array_equal(wide[:, 136:], want)
+        return
+    assert torch.equal(out, plain)
+    assert info.oh_col == 100                                    # behind column 99 (+1 pad)
     wide = torch.as_strided(out.detach(), (B, info.oh_col + info.oh_width), (out.stride(0), 1)).cpu().numpy()
     assert np.array_equal(wide[:, 99], np.zeros(B, np.float32))
-    want = np.zeros((B, 28), np.float32)
     off = 0
     for i, v in enumerate(vocabs):
         if v <= 16:
