@@ -144,8 +144,8 @@ int swr_embed_bag_bwd_expand(const float* d_out, int64_t ld, int in_col, int dim
  * src_col [Kp] (device): column of W behind compact column j (-1: zero padding); inv_col [K] (device): compact column
  * of W's column c, or -1 - t for a column of small table t (index into `tables`).  tables[t].grad = emb_t here. */
 int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, int ohw, const int32_t* src_col,
-                             const int32_t* inv_col, const swr_onehot_table* tables_host, int n_tables, float* Wp,
-                             int64_t ldwp, void* stream);
+                             const int32_t* inv_col, const int32_t* oh_table /* [ohw] (device): table of one-hot column o, -1 = padding */,
+                             const swr_onehot_table* tables_host, int n_tables, float* Wp, int64_t ldwp, void* stream);
 int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const float* dbp /* nullable */, int N, int K, int Kp, int ohw,
                              const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables_host,
                              int n_tables, float* dW, int64_t lddw, float* db /* nullable */, int accumulate, void* stream);

@@ -322,6 +322,8 @@ extern "C" int swr_onehot_table_grads(const float* S, int64_t lds, const float* 
 
 
 // ---- first layer folded over the one-hot block (include/swr.h "folded first layer")
+__device__ __forceinline__ bool swr_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 struct FoldK {
     swr_onehot_table tab[OHT_MAX];      // .grad = the table's weights here (forward) / dEmb is not touched by these kernels
     int n_tables, N, Kp, ohw, K, accumulate;
@@ -335,7 +337,9 @@ struct FoldK {
 };
 
 // Wp[n, j] = W[n, src_col[j]] (j < Kp);  Wp[n, Kp + off_t + v] = sum_e emb_t[v, e] W[n, col_t + e]
-__global__ __launch_bounds__(GATHER_THREADS) void fold_fwd_kernel(const FoldK k) {
+// thread = one output; the dot product's 2 x dim loads are independent 16-byte loads (the table of a one-hot column comes
+// from `oh_table`, not from a search)
+__global__ __launch_bounds__(GATHER_THREADS) void fold_fwd_kernel(const FoldK k, const int32_t* __restrict__ oh_table) {
     const int width = k.Kp + k.ohw;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x;
     if (i >= static_cast<int64_t>(k.N) * width) return;
@@ -346,13 +350,20 @@ __global__ __launch_bounds__(GATHER_THREADS) void fold_fwd_kernel(const FoldK k)
         if (c >= 0) v = k.W[n * k.ldw + c];
     } else {
         const int o = j - k.Kp;
-        for (int t = 0; t < k.n_tables; ++t) {
+        const int t = oh_table[o];
+        if (t >= 0) {
             const swr_onehot_table& T = k.tab[t];
-            if (o >= T.oh_off && o < T.oh_off + T.vocab) {
-                const float* e = T.grad + static_cast<int64_t>(o - T.oh_off) * T.dim;
-                const float* w = k.W + n * k.ldw + T.w_col;
+            const float* __restrict__ e = T.grad + static_cast<int64_t>(o - T.oh_off) * T.dim;
+            const float* __restrict__ w = k.W + n * k.ldw + T.w_col;
+            if ((T.dim & 3) == 0 && (T.w_col & 3) == 0 && (k.ldw & 3) == 0 && swr_aligned16_dev(k.W) && swr_aligned16_dev(T.grad)) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int q = 0; q < T.dim; q += 4) {
+                    const float4 ev = *reinterpret_cast<const float4*>(e + q), wv = *reinterpret_cast<const float4*>(w + q);
+                    a0 = fmaf(ev.x, wv.x, a0); a1 = fmaf(ev.y, wv.y, a1); a2 = fmaf(ev.z, wv.z, a2); a3 = fmaf(ev.w, wv.w, a3);
+                }
+                v = (a0 + a1) + (a2 + a3);
+            } else {
                 for (int q = 0; q < T.dim; ++q) v = fmaf(e[q], w[q], v);
-                break;
             }
         }
     }
@@ -395,16 +406,16 @@ static int fold_fill(FoldK& k, const swr_onehot_table* tables, int n_tables, int
 }
 
 extern "C" int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, int ohw, const int32_t* src_col,
-                                        const int32_t* inv_col, const swr_onehot_table* tables, int n_tables, float* Wp,
-                                        int64_t ldwp, void* stream) {
+                                        const int32_t* inv_col, const int32_t* oh_table, const swr_onehot_table* tables,
+                                        int n_tables, float* Wp, int64_t ldwp, void* stream) {
     FoldK k;
     int rc = fold_fill(k, tables, n_tables, N, K, Kp, ohw, src_col, inv_col, W, ldw);
     if (rc != SWR_OK) return rc;
-    SWR_REQUIRE(W && Wp && ldwp >= Kp + ohw, SWR_ERR_ARG);
+    SWR_REQUIRE(W && Wp && oh_table && ldwp >= Kp + ohw, SWR_ERR_ARG);
     k.Wp = Wp; k.ldwp = ldwp;
     const int64_t total = static_cast<int64_t>(N) * (Kp + ohw);
     hipLaunchKernelGGL(fold_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(total, GATHER_THREADS))), dim3(GATHER_THREADS), 0,
-                       static_cast<hipStream_t>(stream), k);
+                       static_cast<hipStream_t>(stream), k, oh_table);
     return swr_launch_status();
 }
 

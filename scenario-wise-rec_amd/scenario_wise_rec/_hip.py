@@ -163,7 +163,7 @@ _SIGS = {
     "swr_device_available": (C.c_int, []),
     "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
     "swr_embed_gather_fwd_onehot": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P]),
-    "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P]),
+    "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P]),
     "swr_fold_first_layer_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P, _I, _P]),
     "swr_onehot_table_grads": (C.c_int, [_P, _L, _P, _L, _I, _P, _I, _I, _P]),
     "swr_embed_bag_fwd": (C.c_int, [_P, _L, _I, _P, _I, _L, _I, _I, _I, _L, C.c_uint32, _P, _L, _I, _P, _P, _P, _P]),

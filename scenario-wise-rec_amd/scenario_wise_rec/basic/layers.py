@@ -147,6 +147,10 @@ def _run_plan(plan, weights):
             for t, (_i, _wpos, _vocab, dim, _off, col) in enumerate(plan.oh):
                 for e in range(dim):
                     inv[col + e] = -1 - t
+            ohtab = [-1] * info.oh_width
+            for t, (_i, _wpos, vocab, _dim, off, _col) in enumerate(plan.oh):
+                ohtab[off:off + vocab] = [t] * vocab
+            info.ohtab = _sel_tensor(tuple(ohtab), out.device, torch.int32)
             info.src = _sel_tensor(f["src"], out.device, torch.int32)
             info.inv = _sel_tensor(tuple(inv), out.device, torch.int32)
         out._swr_onehot = info

@@ -356,7 +356,7 @@ class OneHotInfo(object):
       * computes dX only for the columns of the other tables (`sel`), compactly, and passes it to the lookup's backward
         through `ctx` (autograd carries a zero-stride placeholder)."""
     __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact",
-                 "fold", "wide", "col0", "Kp", "src", "inv", "K")
+                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K")
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -732,7 +732,7 @@ class LinearBNAct(Function):
             for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
                 tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
             H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
-                                                 H.ptr(oh_in.inv), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
+                                                 H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
                     "swr_fold_first_layer_fwd")
             gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials)
             planes_t = None
