@@ -7,7 +7,9 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 
 MMoE with 4 experts, embed_dim 16, batch 65 536 per GPU, synthetic device-resident inputs, random-init
 weights.  One step = the reference's training step (`trainers/ctr_trainer.py:67-73`): fused lookup ->
 experts/gates -> towers -> domain select -> BCE -> backward (all parameter gradients, embedding tables
-included) -> Adam(lr 1e-3, weight_decay 1e-5) on every parameter.  fp32 end to end (f32 MFMA).
+included) -> Adam(lr 1e-3, weight_decay 1e-5) on every parameter.  fp32 results end to end (every fp32 product as six
+bf16 MFMA products with fp32 accumulation).  The timed region rotates four device-resident batches through the captured
+step (one batch-load launch + one graph replay per step), so rows are not cache-hot and the lazy Adam has real lag.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with
 HIP events on the launch stream) and `cpu_baseline` (the numpy oracle timed on this box's host cores on a
@@ -357,32 +359,53 @@ def main():
 
 
 def measure_roofline(cfg, model, trainer, x, dev, iters, B):
-    """The three big products of the step (stacked expert + gate layer, [B, 516] x [516, 148]) and the gather.
+    """The three products of the stacked expert + gate layer ([B, 516] x [516, 148] algorithmically) and the gather,
+    each timed stand-alone at the shapes the step really launches.
 
-    Primary entry = the longest kernel of the step, the weight-gradient product dW[148, 516] = dZ^T[148, B] @ E[B, 516]
-    (`gemm_tn_x6_kernel` + its fixed-order partial-tile reduction).  `achieved` / `frac` use SURVEY.md 8(d)'s ALGORITHMIC
-    flops, 2 * B * N * K, against the dense bf16 MFMA peak.  The kernel computes each fp32 product as six bf16 MFMA
+    The step runs the FOLDED first layer: the lookup writes A' = [E_big | dense | one-hot] (276
+    columns instead of 516) and the products run over A': forward Z = A' Wf^T, dW' = dZ^T A', dX only for the 144 columns
+    of the tables that go through K3.  `achieved` / `frac` use SURVEY.md 8(d)'s ALGORITHMIC flops of the layer,
+    2 * B * N * K with K = 516 -- what the reference's Linear computes -- against the dense bf16 MFMA peak;
+    `executed_flops_per_launch` is what the launch multiplies after the folding.  Every fp32 product is six bf16 MFMA
     products (3-way operand split, fp32 accumulate: the 1e-4 logit bar rules plain bf16 out), so the matrix pipes issue
-    6x that: `mfma_issue_util` = 6 * 2BNK / t / peak says how busy they are; `hbm_frac` prices the same launch against
-    the HBM roofline (algorithmic bytes 4 B (N + K) / t / 8 TB/s) -- at N = 148 the product moves 174 MB for 10 GFLOP
-    (58 flop/B, far below the ~300 flop/B ridge), so HBM is the roofline that can bind and the MFMA fraction of an ideal
-    (HBM-bound) kernel would be 0.14.  Timed live with HIP events on the launch stream over graph-captured launches."""
+    6 x the executed flops: `mfma_issue_util`.  `hbm_frac` prices the launch's executed bytes against the 8 TB/s HBM
+    peak: at N = 148 these products sit far below the ~300 flop/B ridge, HBM is the roofline that can bind.
+    Primary entry = the longest kernel of the step, the weight-gradient product (`gemm_tn_x6_kernel` + its fixed-order
+    partial-tile reduction).  Timed live with HIP events on the launch stream over graph-captured launches; four
+    operand sets (> the 256 MB Infinity Cache) are rotated."""
     from scenario_wise_rec import ops
+    from scenario_wise_rec.basic.layers import _sel_tensor
     fs, e, fd = len(cfg["vocabs"]), cfg["embed_dim"], cfg["n_dense"]
     k0 = fs * e + fd
     hyp = cfg["hyper"]
     n1 = hyp["n_expert"] * hyp["expert_params"]["dims"][0] + hyp["domain_num"] * hyp["n_expert"]
     g = torch.Generator(device=dev).manual_seed(1)
-    ld = (k0 + 3) // 4 * 4
-    # four operand sets (4 x 174 MB > the 256 MB Infinity Cache): repeated launches do not replay one cache-resident set
-    sets = [(torch.randn(B, n1, device=dev, generator=g), torch.randn(B, ld, device=dev, generator=g)[:, :k0]) for _ in range(4)]
-    W = torch.randn(n1, k0, device=dev, generator=g) * 0.05
-    Wt = W.t().contiguous()
+    # A' exactly as the step's lookup lays it out (real one-hot block, real embeddings of the other tables)
+    was_training = model.training
+    model.train()
+    sets, info = [], None
+    for j in range(4):
+        xb = x if j == 0 else {k: torch.from_numpy(v).to(dev) for k, v in synth_batch(cfg, B, seed=700 + j)[0].items()}
+        with torch.no_grad():
+            out = model.embedding(xb, model.features, squeeze_dim=True, onehot="layout")
+        info = getattr(out, "_swr_onehot", None)
+        if info is None or not info.fold:
+            A = out.detach()
+            kf = k0
+        else:
+            kf = info.Kp + info.oh_width
+            A = info.wide[:, info.col0:info.col0 + kf].detach()
+        sets.append((torch.randn(B, n1, device=dev, generator=g), A))
+    model.train(was_training)
+    folded = info is not None and info.fold
+    n_sel = info.n_sel if folded else k0
+    Wf = torch.randn(n1, kf, device=dev, generator=g) * 0.05
+    Wsel = torch.randn(n_sel, n1, device=dev, generator=g) * 0.05
     bias = torch.zeros(n1, device=dev)
-    dW = torch.empty(n1, k0, device=dev)
+    dW = torch.empty(n1, kf, device=dev)
     db = torch.empty(n1, device=dev)
     Z = torch.empty(B, n1, device=dev)
-    dX = torch.empty(B, ld, device=dev)
+    dX = torch.empty(B, (n_sel + 3) // 4 * 4, device=dev)
     parts = torch.empty(((B + 31) // 32, n1, 2), device=dev)
     stream = torch.cuda.Stream()
     st = {"i": 0}
@@ -392,37 +415,43 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         return sets[st["i"] % 4]
 
     def f_tn():
-        dZ, E = nxt()
-        ops.gemm_tn(dZ, E, dW, B, n1, k0, colsum=db)
+        dZ, A = nxt()
+        ops.gemm_tn(dZ, A, dW, B, n1, kf, colsum=db)
 
     def f_fwd():
-        _dZ, E = nxt()
-        ops.gemm("nt", E, W, Z, B, n1, k0, bias=bias, stat_partials=parts)
+        _dZ, A = nxt()
+        ops.gemm("nt", A, Wf, Z, B, n1, kf, bias=bias, stat_partials=parts)
 
     def f_dx():
-        dZ, _E = nxt()
-        ops.gemm("nt", dZ, Wt, dX, B, k0, n1, n_compute=fs * e)
+        dZ, _A = nxt()
+        ops.gemm("nt", dZ, Wsel, dX, B, n_sel, n1)
 
     x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f" and os.environ.get("SWR_TN_X6", "1") != "0"
-    flops = 2.0 * B * n1 * k0
-    nbytes = 4.0 * B * (n1 + k0)
     peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
+    alg_flops = 2.0 * B * n1 * k0
 
-    def entry(kname, fn, pmc_name):
+    def entry(kname, fn, pmc_name, k_exec, alg):
         ms = time_kernel_events(fn, max(10, iters), stream)
-        tf = flops / (ms * 1e-3) / 1e12
+        exe = 2.0 * B * n1 * k_exec
+        nbytes = 4.0 * B * (n1 + k_exec)
+        tf = alg / (ms * 1e-3) / 1e12
         return {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-                "mfma_issue_util": (6.0 if x6 else 1.0) * tf / peak,
+                "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe, "executed_bytes_per_launch": nbytes,
+                "avg_launch_ms": ms, "mfma_issue_util": (6.0 if x6 else 1.0) * exe / (ms * 1e-3) / 1e12 / peak,
                 "mfma_dtype": "bf16 x 6 products per fp32 product (3-way operand split, fp32 accumulate)" if x6 else "f32",
-                "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_name)}
+                "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_name),
+                "shape": f"[{B}, {k_exec}] x [{k_exec}, {n1}]" + (" (folded from K = %d)" % k0 if folded and k_exec != n_sel else "")}
 
     kname = "gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"
-    roof = entry(kname + " (+tn_reduce_kernel)", f_tn, "void %s<" % kname)
+    roof = entry(kname + " (+tn_reduce_kernel)", f_tn, "void %s<" % kname, kf, alg_flops)
     roof["traffic_unit"] = "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)"
     roof["also"] = {
-        "gemm_rows_x6_kernel(forward)": entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd, "void gemm_rows_x6_kernel<5"),
-        "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W)", f_dx, "void gemm_rows_x6_kernel<6"),
+        "gemm_rows_x6_kernel(forward)": entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd,
+                                              "void gemm_rows_x6_kernel<5", kf, alg_flops),
+        # dX is algorithmically [B, 148] x [148, 512]; the small tables' columns are never computed (their gradients
+        # come out of the weight-gradient product's one-hot block)
+        "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W, columns of the K3 tables only)", f_dx,
+                                         "void gemm_rows_x6_kernel<5", n_sel, 2.0 * B * n1 * fs * e),
         "embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters, B),
     }
     return roof
@@ -448,7 +477,9 @@ def gather_roofline(cfg, model, x, dev, iters, B):
     F_s (idx + 4 E) + 4 F_d + 4 K0 over the measured launch time of the fused lookup."""
     from scenario_wise_rec.basic.layers import fused_lookup
     if hasattr(model, "embedding"):
-        lookup = lambda b: model.embedding(b, model.features, squeeze_dim=True)
+        # the lookup the training step launches: with the folded layout when the model's first layer takes it
+        fold = cfg["family"] in ("MMOE", "SharedBottom") and model.training
+        lookup = lambda b: model.embedding(b, model.features, squeeze_dim=True, onehot="layout" if fold else False)
     else:                                         # PPNet: id + agnostic groups in one fused lookup (ppnet.py:51-54)
         lookup = lambda b: fused_lookup(b, [(model.id_embedding, model.id_features), (model.agn_embedding, model.agn_features, True)])
     stream = torch.cuda.Stream()
@@ -475,9 +506,20 @@ def gather_roofline(cfg, model, x, dev, iters, B):
             p._swr_lazy = st
     nbytes = gather_bytes_per_sample(cfg) * B
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-            "traffic": pmc_traffic("void embed_gather_kernel<4>"), "kernel": "embed_gather_kernel"}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+           "traffic": pmc_traffic("void embed_gather_kernel<4>"), "kernel": "embed_gather_kernel"}
+    last = state["keep"][-1] if state["keep"] else None
+    info = getattr(last, "_swr_onehot", None)
+    if info is not None and info.fold:
+        # folded layout: the small tables' embeddings are not written (nor read) at all -- SURVEY.md 8(d)'s per-sample
+        # figure above is the reference's lookup; this is what the launch really moves
+        fs_, e_ = len(cfg["vocabs"]), cfg["embed_dim"]
+        exe = B * (fs_ * 8 + 4 * (info.Kp + info.oh_width) + 4 * e_ * len(info.compact) + 4 * cfg["n_dense"])
+        out["executed_bytes_per_launch"] = exe
+        out["executed_frac"] = exe / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["layout"] = f"folded: [{len(info.compact)} tables x {e_} | {cfg['n_dense']} dense | {info.oh_width} one-hot columns]"
+    return out
 
 
 if __name__ == "__main__":

@@ -60,7 +60,8 @@ class EmbeddingLayer(SwrModule):
                 "If keep the original shape:[batch_size, num_features, embed_dim], expected %s in feature list, got %s" %
                 ("SparseFeatures", features))
         plan, weights = _new_plan(self)
-        plan.onehot = bool(onehot and squeeze_dim and self.training)
+        # (onehot="layout": the training layout without a backward to follow -- bench.py times the lookup alone that way)
+        plan.onehot = (onehot if onehot == "layout" else bool(onehot)) if (squeeze_dim and self.training) else False
         _plan_part(plan, weights, {}, self, x, sparse, dense if squeeze_dim else [])
         out = _run_plan(plan, weights)
         if squeeze_dim:

@@ -387,7 +387,8 @@ class EmbedGather(Function):
         ns, nd = len(plan.sparse), len(plan.dense)
         # one-hot block of the small tables (see OneHotInfo): only when the caller vouches for a single consuming layer
         plan.oh, oh_off, oh_width, oh_col = None, None, 0, 0
-        if (ONEHOT and getattr(plan, "onehot", False) and getattr(plan, "want_grad", False) and not bags and 0 < ns <= 64):
+        if (ONEHOT and getattr(plan, "onehot", False) and (getattr(plan, "want_grad", False) or plan.onehot == "layout")
+                and not bags and 0 < ns <= 64):
             off, tables = 0, []
             for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse[:ctx.n_grad_slots]):
                 w = weights[wpos]
