@@ -169,8 +169,12 @@ SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measur
                                                                         # whatever it is overlapped with; off by default
 SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "4"))   # measured: 4 (edge at once, launches after the next main kernel) 0.700 ms,
                                                         # 1 (fork at once) 0.709, 3 (edge and launches later) 0.711, 2 (event nodes) stalls the branch
-SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "0"))    # measured: forking the small (tower) products costs more
-                                                                        # in cross-stream edges than the overlap returns
+SIDE_DW_MIN_FLOP = float(os.environ.get("SWR_SIDE_DW_MIN_FLOP", "2e9"))
+SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "2e10"))  # weight-gradient products below this size run on a
+                                                                        # stream of their own (_fork_dw) next to the dX -> K3
+                                                                        # chain: 0.535 -> 0.506 ms at config 2 now that the
+                                                                        # product is half its round-1 size (round 1, on the SORT's
+                                                                        # side stream and joined by K3: no gain)
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
@@ -208,7 +212,7 @@ def _transposed_weight(W):
     key = (W.data_ptr(), W.shape[0], W.shape[1])
     ent = _side["wt"].get(key)
     if ent is not None and ent["epoch"] == _side["epoch"] and SIDE_STREAM:
-        join_side_streams()
+        join_side_streams(dw=False)
         return ent["buf"]
     Wt = W.t().contiguous()
     if SIDE_STREAM and len(_side["wt"]) < 64:
@@ -222,7 +226,7 @@ def _selected_wt(W, sel):
     key = (W.data_ptr(), W.shape[0], W.shape[1], sel.data_ptr())
     ent = _side["wt"].get(key)
     if ent is not None and ent["epoch"] == _side["epoch"] and SIDE_STREAM:
-        join_side_streams()
+        join_side_streams(dw=False)
         return ent["buf"]
     Wt = W.t().index_select(0, sel)
     if SIDE_STREAM and len(_side["wt"]) < 64:
@@ -237,16 +241,43 @@ def _side_stream(dev):
     return _side["streams"][key]
 
 
-def join_side_streams():
+def join_side_streams(dw=True):
     """Make the current stream wait for everything forked onto the side stream so far.  Cheap when nothing is
     pending.  A cross-stream edge costs ~10 us of latency when the waiting stream is otherwise ready, so callers
-    join where the main stream still has work queued behind it (the trainer joins before `loss.backward()`)."""
+    join where the main stream still has work queued behind it (the trainer joins before `loss.backward()`).
+    `dw=False` leaves the weight-gradient branch (a stream of its own, `_fork_dw`) running: the embedding backward
+    joins only the sort it needs."""
     _flush_deferred()
     if _side["pending"]:
         for st in _side["streams"].values():
             torch.cuda.current_stream(st.device).wait_stream(st)
         _side["pending"] = 0
-    _side["keep"].clear()
+    if dw and _dw["pending"]:
+        for st in _dw["streams"].values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        _dw["pending"] = 0
+    if dw:
+        _side["keep"].clear()
+
+
+# weight-gradient branch: the dW chain of the first layer (product + reduce + unfold + small-table gradients) has no
+# consumer before the optimizer, and the dX -> K3 chain does not depend on it
+_dw = {"streams": {}, "pending": 0}
+
+
+def _fork_dw(dev, fn, keep):
+    key = torch.device(dev).index or 0
+    if key not in _dw["streams"]:
+        _dw["streams"][key] = torch.cuda.Stream(device=dev)
+    st = _dw["streams"][key]
+    st.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(st):
+        fn()
+    _dw["pending"] += 1
+    _side["keep"].append(keep)
+    if not _side["queued"]:
+        _side["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
 
 
 def _join_side():
@@ -579,7 +610,7 @@ class EmbedGather(Function):
         if nbytes == 0:
             raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 40 lookup slots)")
         if ctx.presorted is not None and ctx.presorted["nbytes"] == nbytes:
-            join_side_streams()                                       # the sort forked in forward() (no-op if joined)
+            join_side_streams(dw=False)                               # the sort forked in forward() (no-op if joined)
             ws = ctx.presorted["ws"]
             all_direct = all(g is None or isinstance(g, tuple) for g in grads)      # dense gradients go to the arena
             if _late["on"] and sparse_out and all_direct:
@@ -894,7 +925,9 @@ class LinearBNAct(Function):
                 return
             gemm_tn(dZ, x, dW, M, N, K, colsum=db, accumulate=direct_w, groups=G, gsA=N, gsB=(K if G > 1 else 0),
                     gsC=N * K, gsColsum=N, ldc=K)
-        side_dw = direct_w and SIDE_STREAM and (SIDE_DW or 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP)
+        # (a fork / join pair costs ~10-20 us of edges: only a product worth several of those goes to its own stream --
+        # measured: forking every small product LOSES 0.02 ms at configs 1, 3 and 4)
+        side_dw = direct_w and SIDE_STREAM and (SIDE_DW or SIDE_DW_MIN_FLOP <= 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP)
         late_dw = direct_w and _late["on"] and ctx.needs_input_grad[1] and not side_dw
         if late_dw:
             _late["jobs"].append(launch_dw)       # split backward: dX first, this product after the row lists are out
@@ -937,7 +970,7 @@ class LinearBNAct(Function):
         if side_dw:
             # forked AFTER the dX product is enqueued: dX is on the critical path and must not share the MFMA pipes
             # with dW; dW then overlaps whatever the main stream does next (the embedding backward, lower layers)
-            _on_side_stream(dev, launch_dw, (dZ, x, dW, db))
+            _fork_dw(dev, launch_dw, (dZ, x, dW, db))
         if direct_w:
             _mark_touched(p_W + tuple(p_b))
             grads = [None] * (nw * (2 if cfg["has_bias"] else 1))
