@@ -119,10 +119,12 @@ __global__ __launch_bounds__(GATHER_THREADS) void embed_gather_kernel(const Gath
     const int upr = a.units_per_row;
     // U lanes walk along a row (consecutive units -> consecutive addresses of `out`); the other
     // GATHER_THREADS / U row groups take different samples of the tile
-    int U = 1;
-    while (U < upr && U < GATHER_THREADS) U <<= 1;
+    // U = units_per_row itself when it fits (not the next power of two: at 36 units per row -- the folded KuaiRand
+    // layout -- a 64-lane group idles 28 lanes; 7 groups of 36 lanes idle 4 of 256)
+    const int U = max(1, min(upr, GATHER_THREADS));
     const int nrg = GATHER_THREADS / U;
     const int rg = tid / U;
+    if (rg >= nrg) goto dense_part;
     for (int j = tid % U; j < upr; j += U) {
         const int s = s_unit_slot[j], q = s_unit_q[j];
         const float* w = s_w[s] + q * VEC;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void embed_gather_kernel(const Gath
             }
         }
     }
+dense_part:
     // x[name].float() columns (layers.py:88-89), the tail of each row of the slab
     for (int t = tid; t < rows * a.n_dense; t += GATHER_THREADS) {
         const int r = t / a.n_dense, s = t - r * a.n_dense;
