@@ -515,6 +515,28 @@ int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last, int32_t* 
 int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t vocab, int dim,
                    const float* hist, const swr_adam_hyper* hyper_dev, void* stream);
 
+/* Several large (lazily updated) tables in one launch each: swr_adam_catchup_multi = swr_adam_catchup_rows for every
+ * listed table (one claim launch + one replay launch in all), swr_adam_rows_multi = swr_adam_rows in lazy mode for
+ * every listed table.  Per entry the arithmetic is the single-table kernels'.  `from` / `rows` ([n] each) are the
+ * per-table workspace of the catch-up. */
+#define SWR_ADAM_MAX_TABLES 16
+typedef struct {
+    float* p; float* m; float* v;      /* [vocab, dim] */
+    int32_t* last;                     /* [vocab] */
+    int32_t* claim;                    /* [vocab] scratch (catch-up) */
+    int64_t vocab;
+    int32_t dim;
+    int32_t idx_dtype;                 /* catch-up: type of idx */
+    const void* idx;                   /* catch-up: [n] looked-up ids */
+    uint32_t hash_seed; uint32_t pad;
+    int64_t n;                         /* entries: looked-up ids (catch-up) or row-list entries (rows) */
+    int32_t* from_step; uint32_t* rows;   /* catch-up workspace, [n] each */
+    const int32_t* urow; const float* ugrad;   /* rows: the row list ([n], [n, dim]) */
+} swr_adam_table;
+int swr_adam_catchup_multi(const swr_adam_table* tables_host, int n_tables, const float* hist,
+                           const swr_adam_hyper* hyper_dev, void* stream);
+int swr_adam_rows_multi(const swr_adam_table* tables_host, int n_tables, const swr_adam_hyper* hyper_dev, void* stream);
+
 /* ---------------------------------------------------------------- STAR ----
  * STAR's factorised weights (reference models/multi_domain/star.py:99-107): per layer, for ALL domains in one launch
  * each way, the effective weights W_s (.) W_d[d] in Linear layout [out, in] and biases b_s + b_d[d] -- the first layer

@@ -295,3 +295,134 @@ extern "C" int swr_adam_flush(float* p, float* m, float* v, int32_t* last, int64
     hipLaunchKernelGGL(adam_mark_current_kernel, dim3(g2), dim3(AD_THREADS), 0, st, last, vocab, hyper);
     return swr_launch_status();
 }
+
+
+// ------------------------------------------------------------------------------ several large tables, one launch each
+// A model with T row-sparse tables (Ali-CCP: 10) paid T x (claim + catch-up) launches in front of every lookup and T
+// row-update launches in every optimizer step -- 30 launches of ~5 us with nothing in them.  The kernels below take a
+// descriptor per table and walk the concatenation of the tables' entries; per entry they do exactly what the
+// single-table kernels do (same arithmetic, same ticket election per table).
+struct AdamMultiK {
+    swr_adam_table tab[SWR_ADAM_MAX_TABLES];
+    int64_t first[SWR_ADAM_MAX_TABLES + 1];     // first work item of each table
+    int n_tables;
+    const float* hist;
+    const swr_adam_hyper* hp;
+};
+
+__device__ __forceinline__ int adam_multi_table(const AdamMultiK& k, int64_t i) {
+    int t = 0;
+    while (t + 1 < k.n_tables && i >= k.first[t + 1]) ++t;
+    return t;
+}
+
+__global__ __launch_bounds__(AD_THREADS) void adam_claim_multi_kernel(const AdamMultiK k) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x;
+    if (g >= k.first[k.n_tables]) return;
+    const int t = adam_multi_table(k, g);
+    const swr_adam_table& T = k.tab[t];
+    const int64_t i = g - k.first[t];
+    int64_t id = swr_load_index(T.idx, T.idx_dtype, i);
+    if (T.hash_seed != 0u) {
+        uint64_t z = static_cast<uint64_t>(id) ^ T.hash_seed;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        id = static_cast<int64_t>((z ^ (z >> 31)) % static_cast<uint64_t>(T.vocab));
+    }
+    const int now = static_cast<int>(k.hp->step);
+    int f = now;
+    if (id >= 0 && id < T.vocab) {
+        f = T.last[id];
+        T.rows[i] = static_cast<uint32_t>(id);
+        if (f < now) T.claim[id] = static_cast<int32_t>(i);
+    }
+    T.from_step[i] = f;
+}
+
+__global__ __launch_bounds__(AD_THREADS) void adam_catchup_multi_kernel(const AdamMultiK k) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x;
+    if (g >= k.first[k.n_tables]) return;
+    const int t = adam_multi_table(k, g);
+    const swr_adam_table& T = k.tab[t];
+    const int64_t idx = g - k.first[t];
+    const int64_t i = idx / T.dim;
+    const swr_adam_hyper h = *k.hp;
+    const int now = static_cast<int>(h.step);
+    const int f = T.from_step[i];
+    if (f >= now) return;
+    const uint32_t row = T.rows[i];
+    if (T.claim[row] != static_cast<int32_t>(i)) return;
+    const int e = static_cast<int>(idx - i * T.dim);
+    const int64_t o = static_cast<int64_t>(row) * T.dim + e;
+    float pi = T.p[o], mi = T.m[o], vi = T.v[o];
+    adam_replay(pi, mi, vi, f, now, k.hist, h);
+    T.p[o] = pi; T.m[o] = mi; T.v[o] = vi;
+    if (e == 0) T.last[row] = now;
+}
+
+__global__ __launch_bounds__(AD_THREADS) void adam_rows_multi_kernel(const AdamMultiK k) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x;
+    if (g >= k.first[k.n_tables]) return;
+    const int t = adam_multi_table(k, g);
+    const swr_adam_table& T = k.tab[t];
+    const int64_t idx = g - k.first[t];
+    const int64_t i = idx / T.dim;
+    const int e = static_cast<int>(idx - i * T.dim);
+    const int32_t row = T.urow[i];
+    if (row < 0 || row >= T.vocab) return;
+    const swr_adam_hyper h = *k.hp;
+    const int64_t o = static_cast<int64_t>(row) * T.dim + e;
+    float pi = T.p[o], mi = T.m[o], vi = T.v[o];
+    adam_elem(pi, T.ugrad[i * T.dim + e], mi, vi, h);
+    T.p[o] = pi; T.m[o] = mi; T.v[o] = vi;
+    if (e == 0) T.last[row] = static_cast<int32_t>(h.step);
+}
+
+static int adam_multi_fill(AdamMultiK& k, const swr_adam_table* tables, int n_tables, bool per_elem, bool rows_mode,
+                           const float* hist, const swr_adam_hyper* hyper) {
+    SWR_REQUIRE(tables && n_tables > 0 && n_tables <= SWR_ADAM_MAX_TABLES && hyper, SWR_ERR_ARG);
+    int64_t pos = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        const swr_adam_table& T = tables[t];
+        SWR_REQUIRE(T.p && T.m && T.v && T.last && T.vocab > 0 && T.dim > 0 && T.n >= 0, SWR_ERR_ARG);
+        if (rows_mode) SWR_REQUIRE(T.urow && T.ugrad, SWR_ERR_ARG);
+        else {
+            SWR_REQUIRE(T.idx && T.claim && T.from_step && T.rows, SWR_ERR_ARG);
+            SWR_REQUIRE(swr_is_index_dtype(T.idx_dtype), SWR_ERR_DTYPE);
+        }
+        k.tab[t] = T;
+        k.first[t] = pos;
+        pos += per_elem ? T.n * T.dim : T.n;
+    }
+    k.first[n_tables] = pos;
+    k.n_tables = n_tables; k.hist = hist; k.hp = hyper;
+    return SWR_OK;
+}
+
+extern "C" int swr_adam_catchup_multi(const swr_adam_table* tables, int n_tables, const float* hist,
+                                      const swr_adam_hyper* hyper, void* stream) {
+    SWR_REQUIRE(hist != nullptr, SWR_ERR_ARG);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AdamMultiK k;
+    int rc = adam_multi_fill(k, tables, n_tables, false, false, hist, hyper);
+    if (rc != SWR_OK) return rc;
+    if (k.first[n_tables] == 0) return SWR_OK;
+    hipLaunchKernelGGL(adam_claim_multi_kernel, dim3(static_cast<unsigned>(swr_ceil_div(k.first[n_tables], AD_THREADS))),
+                       dim3(AD_THREADS), 0, st, k);
+    rc = adam_multi_fill(k, tables, n_tables, true, false, hist, hyper);
+    if (rc != SWR_OK) return rc;
+    hipLaunchKernelGGL(adam_catchup_multi_kernel, dim3(static_cast<unsigned>(swr_ceil_div(k.first[n_tables], AD_THREADS))),
+                       dim3(AD_THREADS), 0, st, k);
+    return swr_launch_status();
+}
+
+extern "C" int swr_adam_rows_multi(const swr_adam_table* tables, int n_tables, const swr_adam_hyper* hyper, void* stream) {
+    AdamMultiK k;
+    int rc = adam_multi_fill(k, tables, n_tables, true, true, nullptr, hyper);
+    if (rc != SWR_OK) return rc;
+    if (k.first[n_tables] == 0) return SWR_OK;
+    hipLaunchKernelGGL(adam_rows_multi_kernel, dim3(static_cast<unsigned>(swr_ceil_div(k.first[n_tables], AD_THREADS))),
+                       dim3(AD_THREADS), 0, static_cast<hipStream_t>(stream), k);
+    return swr_launch_status();
+}

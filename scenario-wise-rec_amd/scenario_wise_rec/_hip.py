@@ -144,6 +144,16 @@ class LayerNormArgs(C.Structure):
                 ("dbeta", C.c_void_p)]
 
 
+ADAM_MAX_TABLES = 16        # SWR_ADAM_MAX_TABLES
+
+
+class AdamTable(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("last", C.c_void_p), ("claim", C.c_void_p),
+                ("vocab", C.c_int64), ("dim", C.c_int32), ("idx_dtype", C.c_int32), ("idx", C.c_void_p),
+                ("hash_seed", C.c_uint32), ("pad", C.c_uint32), ("n", C.c_int64), ("from_step", C.c_void_p), ("rows", C.c_void_p),
+                ("urow", C.c_void_p), ("ugrad", C.c_void_p)]
+
+
 class OnehotTable(C.Structure):
     _fields_ = [("grad", C.c_void_p), ("vocab", C.c_int32), ("dim", C.c_int32), ("oh_off", C.c_int32), ("w_col", C.c_int32)]
 
@@ -166,6 +176,8 @@ _SIGS = {
     "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P]),
     "swr_fold_first_layer_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P, _I, _P]),
     "swr_onehot_table_grads": (C.c_int, [_P, _L, _P, _L, _I, _P, _I, _I, _P]),
+    "swr_adam_catchup_multi": (C.c_int, [_P, _I, _P, _P, _P]),
+    "swr_adam_rows_multi": (C.c_int, [_P, _I, _P, _P]),
     "swr_embed_bag_fwd": (C.c_int, [_P, _L, _I, _P, _I, _L, _I, _I, _I, _L, C.c_uint32, _P, _L, _I, _P, _P, _P, _P]),
     "swr_embed_bag_bwd_expand": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _L, _P, _P]),
     "swr_embed_bwd_workspace_bytes": (_Z, [_P, _I, _L]),

@@ -477,12 +477,17 @@ class EmbedGather(Function):
             H.require_device(vals)
             dn[i] = H.DenseSlot(vals.data_ptr(), H.dtype_code(vals), fold["dn_col"][i] if fold is not None else col)
         # lazily updated tables (optim.LazyRows): bring the rows about to be read up to date first (exact replay)
-        seen = set()
+        seen, behind = set(), []
         for wpos, idx, vocab, dim, col, seed in plan.sparse:
             lazy = getattr(plan, "lazy", {}).get(wpos)
             if lazy is not None and (wpos, idx.data_ptr()) not in seen:
                 seen.add((wpos, idx.data_ptr()))
-                lazy.catchup(idx, seed)
+                behind.append((lazy, idx, seed))
+        if len(behind) == 1:
+            behind[0][0].catchup(behind[0][1], behind[0][2])
+        elif behind:
+            from .optim import catchup_many
+            catchup_many(behind)               # one claim + one replay launch for all large tables of the lookup
         need_keys = ctx.n_grad_slots > 0
         keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
         flag = H.err_flag(dev)

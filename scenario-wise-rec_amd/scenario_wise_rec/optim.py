@@ -59,6 +59,38 @@ class LazyRows(object):
                                    H.ptr(self.hist), H.ptr(self.hyper), H.stream()), "swr_adam_flush")
 
 
+def catchup_many(items):
+    """`LazyRows.catchup` for several tables: items = [(lazy, idx, hash_seed)].  Tables that share an optimizer group
+    (one history, one set of step scalars) go through ONE claim launch and ONE replay launch (swr_adam_catchup_multi)
+    instead of two launches per table."""
+    groups = {}
+    for lazy, idx, seed in items:
+        groups.setdefault((lazy.hist.data_ptr(), lazy.hyper.data_ptr()), []).append((lazy, idx, seed))
+    for members in groups.values():
+        if len(members) == 1:
+            members[0][0].catchup(members[0][1], members[0][2])
+            continue
+        lazy0 = members[0][0]
+        if lazy0.hyper.data_ptr() in _EARLY_ADVANCED:
+            raise H.SwrError("a lookup of a lazily updated table after FusedAdam.advance_early(): the step counter already "
+                             "counts the coming update (use advance_early only with one lookup per step)")
+        for c0 in range(0, len(members), H.ADAM_MAX_TABLES):
+            chunk = members[c0:c0 + H.ADAM_MAX_TABLES]
+            idxs = [idx.contiguous() for _l, idx, _s in chunk]
+            total = sum(max(i.numel(), 1) for i in idxs)
+            ws = torch.empty(total * 2, dtype=torch.int32, device=idxs[0].device)
+            tabs = (H.AdamTable * len(chunk))()
+            off = 0
+            for j, ((lazy, _i, seed), idx) in enumerate(zip(chunk, idxs)):
+                n, p = idx.numel(), lazy.p
+                tabs[j] = H.AdamTable(p.data_ptr(), lazy.m.data_ptr(), lazy.v.data_ptr(), lazy.last.data_ptr(), lazy.claim.data_ptr(),
+                                      p.shape[0], p.shape[1], H.dtype_code(idx), idx.data_ptr(), seed, 0, n,
+                                      ws.data_ptr() + 4 * off, ws.data_ptr() + 4 * (off + max(n, 1)), None, None)
+                off += 2 * max(n, 1)
+            H.check(lib.swr_adam_catchup_multi(tabs, len(chunk), H.ptr(lazy0.hist), H.ptr(lazy0.hyper), H.stream()),
+                    "swr_adam_catchup_multi")
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_rows=True, hist_cap=HIST_CAP):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -183,13 +215,15 @@ class FusedAdam(torch.optim.Optimizer):
             ent = self._hyper[gi]
             hist = ent[2]
             if self.lazy_rows:
+                behind = []
                 for p, (urow, ugrad) in sparse:
                     # rows that take a gradient must be current BEFORE the step advances: those looked up by this
                     # rank were caught up by the forward lookup, those that only other ranks touched are caught up here
+                    st = self._lazy_state(p, hist, hyper)        # (state must exist before the row kernel)
                     if not getattr(p, "_swr_sparse_local", False):
-                        self._lazy_state(p, hist, hyper).catchup(urow)
-                    else:
-                        self._lazy_state(p, hist, hyper)       # (state must exist before the row kernel)
+                        behind.append((st, urow, 0))
+                if behind:
+                    catchup_many(behind)
             if gi == 0 and getattr(self, "_advanced", False):
                 self._advanced = False                         # advance_early() already did it for this step
                 _EARLY_ADVANCED.discard(hyper.data_ptr())
@@ -248,6 +282,17 @@ class FusedAdam(torch.optim.Optimizer):
             for p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep in runs:
                 H.check(lib.swr_adam_dense(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
                                            n, H.ptr(hyper), stream), "swr_adam_dense")
+            if self.lazy_rows and len(sparse) > 1:
+                # several large tables: one row-update launch for all of them (swr_adam_rows_multi)
+                for c0 in range(0, len(sparse), H.ADAM_MAX_TABLES):
+                    chunk = sparse[c0:c0 + H.ADAM_MAX_TABLES]
+                    tabs = (H.AdamTable * len(chunk))()
+                    for j, (p, (urow, ugrad)) in enumerate(chunk):
+                        st = self._lazy_state(p, hist, hyper)
+                        tabs[j] = H.AdamTable(p.data_ptr(), st.m.data_ptr(), st.v.data_ptr(), st.last.data_ptr(), None, p.shape[0],
+                                              p.shape[1], 0, None, 0, 0, urow.numel(), None, None, urow.data_ptr(), ugrad.data_ptr())
+                    H.check(lib.swr_adam_rows_multi(tabs, len(chunk), H.ptr(hyper), stream), "swr_adam_rows_multi")
+                sparse = []
             for p, (urow, ugrad) in sparse:
                 if self.lazy_rows:
                     st = self._lazy_state(p, hist, hyper)

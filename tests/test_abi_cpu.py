@@ -48,7 +48,7 @@ def test_struct_layouts_match_the_header():
     structs = {"swr_sparse_slot": H.SparseSlot, "swr_dense_slot": H.DenseSlot, "swr_embed_grad_slot": H.EmbedGradSlot,
                "swr_tower_args": H.TowerArgs, "swr_bnmix_args": H.BnMixArgs,
                "swr_gemm_args": H.GemmArgs, "swr_gemm_tn_args": H.GemmTnArgs, "swr_act_range": H.ActRange,
-               "swr_mix_desc": H.MixDesc, "swr_adam_hyper": H.AdamHyper,
+               "swr_mix_desc": H.MixDesc, "swr_adam_hyper": H.AdamHyper, "swr_adam_table": H.AdamTable,
                "swr_dp_table": H.DpTable, "swr_star_layer_args": H.StarLayerArgs,
                "swr_take_column": H.TakeColumn, "swr_layernorm_args": H.LayerNormArgs,
                "swr_onehot_table": H.OnehotTable}
