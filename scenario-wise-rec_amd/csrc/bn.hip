@@ -148,37 +148,51 @@ __global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_v4_kernel(
     }
 }
 
-// one workgroup per 64-row tile (the layout swr_bn_bwd_finalize expects); threads with the same column slot are
-// summed through LDS in fixed order
+// one workgroup per (64-row tile, block of <= 64 float4 columns) (the tile layout swr_bn_bwd_finalize expects); threads
+// with the same column slot are summed through LDS in fixed order.  Wide layers are cut into column blocks: with one
+// workgroup per row tile, N = 768 left 192 threads walking 64 rows each from 256 workgroups -- 75 us for 150 MB at
+// M = 16 384 (STAR); four rows are loaded before any is used
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_v4_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
     int64_t ldz, const float* __restrict__ mean, const float* __restrict__ rstd, const ActSpec acts,
-    float* __restrict__ partials, int64_t M, int N, const V4Plan pl) {
+    float* __restrict__ partials, int64_t M, int N, const V4Plan pl, int vpb) {
     __shared__ float4 s1[BN_THREADS], s2[BN_THREADS];
-    const int r_in = threadIdx.x / pl.vpr, v = threadIdx.x - r_in * pl.vpr;
-    const bool active = r_in < pl.rows;
+    const int r_in = threadIdx.x / vpb, vl = threadIdx.x - r_in * vpb;
+    const int rows = BN_THREADS / vpb;
+    const int v = blockIdx.y * vpb + vl;
+    const bool active = r_in < rows && v < pl.vpr;
     const int n = 4 * v;
     float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
     if (active) {
         const int act = act_of_col(acts, n);
         const float4 mu = ld4(mean + n), rs = ld4(rstd + n);
         const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BWD_TILE;
-        for (int r = r_in; r < BWD_TILE; r += pl.rows) {
-            const int64_t m = m0 + r;
-            if (m >= M) break;
-            const float4 g = act_bwd4(act, ld4(dY + m * lddy + n), ld4(Y + m * ldy + n));
-            const float4 z = ld4(Z + m * ldz + n);
-            a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
-            a2.x = fmaf(g.x, (z.x - mu.x) * rs.x, a2.x); a2.y = fmaf(g.y, (z.y - mu.y) * rs.y, a2.y);
-            a2.z = fmaf(g.z, (z.z - mu.z) * rs.z, a2.z); a2.w = fmaf(g.w, (z.w - mu.w) * rs.w, a2.w);
+        const int64_t mend = min<int64_t>(m0 + BWD_TILE, M);
+        constexpr int U = 4;
+        for (int64_t mb = m0 + r_in; mb < mend; mb += static_cast<int64_t>(U) * rows) {
+            float4 d[U], y[U], z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = min<int64_t>(mb + static_cast<int64_t>(u) * rows, mend - 1);
+                d[u] = ld4(dY + m * lddy + n); y[u] = ld4(Y + m * ldy + n); z[u] = ld4(Z + m * ldz + n);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (mb + static_cast<int64_t>(u) * rows < mend) {
+                    const float4 g = act_bwd4(act, d[u], y[u]);
+                    a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
+                    a2.x = fmaf(g.x, (z[u].x - mu.x) * rs.x, a2.x); a2.y = fmaf(g.y, (z[u].y - mu.y) * rs.y, a2.y);
+                    a2.z = fmaf(g.z, (z[u].z - mu.z) * rs.z, a2.z); a2.w = fmaf(g.w, (z[u].w - mu.w) * rs.w, a2.w);
+                }
+            }
         }
     }
     s1[threadIdx.x] = a1;
     s2[threadIdx.x] = a2;
     __syncthreads();
     if (active && r_in == 0) {
-        for (int r = 1; r < pl.rows; ++r) {
-            const float4 b1 = s1[r * pl.vpr + v], b2 = s2[r * pl.vpr + v];
+        for (int r = 1; r < rows; ++r) {
+            const float4 b1 = s1[r * vpb + vl], b2 = s2[r * vpb + vl];
             a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
             a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
         }
@@ -446,8 +460,11 @@ extern "C" int swr_bn_act_bwd_stats(const float* dY, int64_t lddy, const float* 
         V4Plan pl;
         pl.vpr = N / 4;
         pl.rows = BN_THREADS / pl.vpr;
-        hipLaunchKernelGGL(bn_act_bwd_stats_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE))), dim3(BN_THREADS), 0,
-                           static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, mean, rstd, as, partials, M, N, pl);
+        const int vpb = pl.vpr < 64 ? pl.vpr : 64;
+        hipLaunchKernelGGL(bn_act_bwd_stats_v4_kernel,
+                           dim3(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE)), static_cast<unsigned>(swr_ceil_div(pl.vpr, vpb))),
+                           dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, mean, rstd, as, partials,
+                           M, N, pl, vpb);
         return swr_launch_status();
     }
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE)), static_cast<unsigned>(swr_ceil_div(N, 64)));
