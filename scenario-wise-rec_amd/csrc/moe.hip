@@ -625,6 +625,33 @@ __global__ __launch_bounds__(EW_THREADS) void mul_kernel(const float* __restrict
     if (i < n) C[i] = A[i] * B[i];
 }
 
+// c = a + b (residual connections: HAMUR's adapter `out + h`, hamur.py:197 / 366; M3oE's `star_mlp(emb) + skip`, m3oe.py:147):
+// 16 bytes per lane when the three pointers allow it
+__global__ __launch_bounds__(EW_THREADS) void add_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                         int64_t n, int vec) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
+    if (vec) {
+        if (4 * i + 3 < n) {
+            const float4 a = *reinterpret_cast<const float4*>(A + 4 * i), b = *reinterpret_cast<const float4*>(B + 4 * i);
+            *reinterpret_cast<float4*>(C + 4 * i) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        } else {
+            for (int64_t j = 4 * i; j < n; ++j) C[j] = A[j] + B[j];
+        }
+    } else if (i < n) {
+        C[i] = A[i] + B[i];
+    }
+}
+
+extern "C" int swr_add_fwd(const float* A, const float* B, float* C, int64_t n, void* stream) {
+    SWR_REQUIRE(A && B && C && n >= 0, SWR_ERR_ARG);
+    if (n == 0) return SWR_OK;
+    const int vec = swr_aligned16(A) && swr_aligned16(B) && swr_aligned16(C);
+    const int64_t items = vec ? swr_ceil_div(n, 4) : n;
+    hipLaunchKernelGGL(add_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, EW_THREADS))), dim3(EW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), A, B, C, n, vec);
+    return swr_launch_status();
+}
+
 extern "C" int swr_mul_fwd(const float* A, const float* B, float* C, int64_t n, void* stream) {
     SWR_REQUIRE(A && B && C && n >= 0, SWR_ERR_ARG);
     if (n == 0) return SWR_OK;

@@ -108,20 +108,19 @@ class _Hamur(SwrModule):
         # down projection with W1_b = U0 H_b V0, applied as ((h U0) H_b) V0; the shared factors are plain products on
         # [B*D, .], the per-sample factor is swr_rowmat
         k = self.k
-        t = ops.MatmulIO.apply(hd.reshape(B * D, m), self.u[iu], None)                     # [B*D, k]
+        t = ops.MatmulIO.apply(hd.reshape(B * D, m), self.u[iu], None, None)                     # [B*D, k]
         t = ops.RowMat.apply(t.reshape(B, D, k), Hm)
-        t = ops.MatmulIO.apply(t.reshape(B * D, k), self.v[iu], self.b_list[iu])          # [B*D, 32]
-        t = torch.sigmoid(t)
-        t = ops.MatmulIO.apply(t, self.u[iu + 1], None)
+        t = ops.MatmulIO.apply(t.reshape(B * D, k), self.v[iu], self.b_list[iu], "sigmoid")   # [B*D, 32], sigmoid fused in
+        t = ops.MatmulIO.apply(t, self.u[iu + 1], None, None)
         t = ops.RowMat.apply(t.reshape(B, D, k), Hm)
-        t = ops.MatmulIO.apply(t.reshape(B * D, k), self.v[iu + 1], self.b_list[iu + 1])  # [B*D, m]
+        t = ops.MatmulIO.apply(t.reshape(B * D, k), self.v[iu + 1], self.b_list[iu + 1], None)  # [B*D, m]
         # domain norm over the batch: UNBIASED variance, eps 1e-5.  With n rows,
         #   (t - mean) / sqrt(M2 / (n - 1) + eps) = sqrt((n - 1) / n) * (t - mean) / sqrt(M2 / n + eps (n - 1) / n),
         # i.e. the biased-variance kernel with a rescaled eps and gamma
         c = ((B - 1) / B) ** 0.5 if B > 1 else 0.0
         eps_b = self.eps * (B - 1) / B if B > 1 else self.eps
         out = ops.batch_standardize(t.reshape(B, D * m), eps_b, (gamma * c).repeat(D), bias.repeat(D)).reshape(B, D, m)
-        return (out + hd).reshape(B, D * m)
+        return ops.add(out.reshape(B, D * m), h)
 
     def forward(self, x):
         domain_id = x["domain_indicator"]

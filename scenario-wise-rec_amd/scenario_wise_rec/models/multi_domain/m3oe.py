@@ -144,7 +144,7 @@ class M3oE(SwrModule):
         eff = ops.star_layer_weights(False, D, self.shared_weight, self.shared_bias, *self.slot_weight, *self.slot_bias)
         z = ops.linear_bn_act(e, list(eff[:D]), list(eff[D:]), bn=None, acts=None, groups=1, training=False)   # [B, D*star1]
         emb = ops.block_select(z, domain_id, D, self.star_dim[1])
-        emb = mlp_n_bank([self.star_mlp], emb, True) + skip
+        emb = ops.add(mlp_n_bank([self.star_mlp], emb, True), skip)
         # shared experts + domain experts on the same input, one stacked evaluation
         both = mlp_n_bank(list(self.expert) + list(self.domain_expert), emb, True)         # [B, (ne + D) * H]
         gates = LayerBank([s[0] for s in self.gate], None, [("softmax", ne)] * D)(emb.detach(), False)   # [B, D*ne]
@@ -160,7 +160,7 @@ class M3oE(SwrModule):
         M = we * (wd * eye + (1.0 - wd) / (D - 1) * (1.0 - eye))                            # [D, D], M[i, j]
         Wk = torch.kron(M, torch.eye(H_, device=e.device, dtype=torch.float32))            # [D*H, D*H] Linear layout [out, in]
         dom = both[:, ne * H_:]
-        fused = mixed + ops.linear_bn_act(dom, [Wk], None, bn=None, acts=None, groups=1, training=False)
+        fused = ops.add(mixed, ops.linear_bn_act(dom, [Wk], None, bn=None, acts=None, groups=1, training=False))
         # towers: Linear(H, H) -> LayerNorm -> ReLU -> Linear(H, 1), grouped over the domains
         t = LayerBank([t[0] for t in self.tower], grouped=True)(fused, False)
         t = ops.layer_norm_act(t, [t_[1] for t_ in self.tower], relu=True)

@@ -1252,22 +1252,36 @@ class MatmulIO(Function):
     """y = x @ W + b with W stored [in, out] -- STAR's factorised FCN layer (star.py:103-107)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, act=None):
         H.require_device(x, W)
         x, W = H.f32c(x), H.f32c(W)
         M, K, N = x.shape[0], W.shape[0], W.shape[1]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         gemm("nn", x, W, y, M, N, K, bias=b)
-        ctx.save_for_backward(x, W)
-        ctx.has_b = b is not None
+        ctx.has_b, ctx.act = b is not None, act
+        if act is not None:                      # activation on the product (HAMUR's adapter: sigmoid, hamur.py:180,349)
+            z, y = y, torch.empty_like(y)
+            acts, n_acts = H.act_ranges(act, N)
+            H.check(lib.swr_affine_act_fwd(H.ptr(z), N, None, None, acts, n_acts, H.ptr(y), N, M, N, H.stream()),
+                    "swr_affine_act_fwd")
+            ctx.save_for_backward(x, W, y, z)
+        else:
+            ctx.save_for_backward(x, W)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, W = ctx.saved_tensors[:2]
         dy = H.f32c(dy)
         M, K, N = x.shape[0], W.shape[0], W.shape[1]
+        if ctx.act is not None:
+            y, z = ctx.saved_tensors[2:]
+            acts, n_acts = H.act_ranges(ctx.act, N)
+            dz = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            H.check(lib.swr_act_bwd_apply(H.ptr(dy), dy.stride(0), H.ptr(y), N, H.ptr(z), N, None, None, None, None, acts, n_acts,
+                                          H.ptr(dz), N, M, N, H.stream()), "swr_act_bwd_apply")
+            dy = dz
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
@@ -1277,7 +1291,7 @@ class MatmulIO(Function):
         gemm_tn(x, dy, dW, M, K, N)                           # dW[k,n] = sum_m x[m,k] dy[m,n]
         if db is not None:
             colsum(dy, M, N, out=db)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 # =========================================================================== gate mixing
@@ -1495,6 +1509,29 @@ class Mul(Function):
 
 def mul(a, b):
     return Mul.apply(a, b)
+
+
+class Add(Function):
+    """c = a + b of two equally shaped tensors (residual connections); the backward passes the gradient to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        H.require_device(a, b)
+        if a.shape != b.shape:
+            raise ValueError("ops.add: shapes differ")
+        a, b = H.f32c(a).contiguous(), H.f32c(b).contiguous()
+        c = torch.empty_like(a)
+        H.check(lib.swr_add_fwd(H.ptr(a), H.ptr(b), H.ptr(c), a.numel(), H.stream()), "swr_add_fwd")
+        return c
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dc):
+        return (dc if ctx.needs_input_grad[0] else None), (dc if ctx.needs_input_grad[1] else None)
+
+
+def add(a, b):
+    return Add.apply(a, b)
 
 
 class StopGradCols(Function):
