@@ -652,6 +652,33 @@ extern "C" int swr_add_fwd(const float* A, const float* B, float* C, int64_t n, 
     return swr_launch_status();
 }
 
+__global__ __launch_bounds__(EW_THREADS) void mul_scale_kernel(const float* __restrict__ A, const float* __restrict__ B, float s,
+                                                               float* __restrict__ C, int64_t n, int vec) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
+    if (vec) {
+        if (4 * i + 3 < n) {
+            const float4 a = *reinterpret_cast<const float4*>(A + 4 * i), b = *reinterpret_cast<const float4*>(B + 4 * i);
+            *reinterpret_cast<float4*>(C + 4 * i) = make_float4(a.x * (b.x * s), a.y * (b.y * s), a.z * (b.z * s), a.w * (b.w * s));
+        } else {
+            for (int64_t j = 4 * i; j < n; ++j) C[j] = A[j] * (B[j] * s);
+        }
+    } else if (i < n) {
+        C[i] = A[i] * (B[i] * s);
+    }
+}
+
+// C = A * (s * B): PPNet's `hidden * gate`, gate = gamma * sigmoid(...) (ppnet.py:27, layers.py:318-320) with the GateNU's
+// gamma folded in -- same rounding as scaling the gate first and multiplying then
+extern "C" int swr_mul_scale_fwd(const float* A, const float* B, float scale, float* C, int64_t n, void* stream) {
+    SWR_REQUIRE(A && B && C && n >= 0, SWR_ERR_ARG);
+    if (n == 0) return SWR_OK;
+    const int vec = swr_aligned16(A) && swr_aligned16(B) && swr_aligned16(C);
+    const int64_t items = vec ? swr_ceil_div(n, 4) : n;
+    hipLaunchKernelGGL(mul_scale_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, EW_THREADS))), dim3(EW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), A, B, scale, C, n, vec);
+    return swr_launch_status();
+}
+
 extern "C" int swr_mul_fwd(const float* A, const float* B, float* C, int64_t n, void* stream) {
     SWR_REQUIRE(A && B && C && n >= 0, SWR_ERR_ARG);
     if (n == 0) return SWR_OK;

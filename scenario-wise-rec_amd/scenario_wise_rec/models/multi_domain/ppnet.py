@@ -103,6 +103,6 @@ class PPNet(SwrModule):
             if l > 0:
                 hidden = LayerBank([t.mlp_layers[l].block(0)[0] for t in T], [t.mlp_layers[l].block(0)[1] for t in T],
                                    ["relu"] * D, grouped=True)(hidden, self.training)
-            hidden = ops.mul(hidden, gate * T[0].gate_layers[l].gemma)
+            hidden = ops.mul(hidden, gate, T[0].gate_layers[l].gemma)      # gamma * sigmoid folded into the product
         logits = LayerBank([t.final_layer for t in T], None, [None] * D, grouped=True)(hidden, self.training)   # [B, D]
         return ops.domain_select(logits, domain_id, apply_sigmoid=True)

@@ -1481,15 +1481,17 @@ def domain_select(V, domain, apply_sigmoid=True, extra=None):
 
 # =========================================================================== small helpers
 class Mul(Function):
-    """c = a * b (PPNet's `hidden * gate_out`, ppnet.py:27; EPNet's `agn_x * gate_output`, epnet.py:30)."""
+    """c = a * (scale * b) (PPNet's `hidden * gate_out`, ppnet.py:27; EPNet's `agn_x * gate_output`, epnet.py:30; `scale` =
+    the GateNU's gamma when b is the bare sigmoid)."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, scale):
         H.require_device(a, b)
         a, b = H.f32c(a).contiguous(), H.f32c(b).contiguous()
         c = torch.empty_like(a)
-        H.check(lib.swr_mul_fwd(H.ptr(a), H.ptr(b), H.ptr(c), a.numel(), H.stream()), "swr_mul_fwd")
+        H.check(lib.swr_mul_scale_fwd(H.ptr(a), H.ptr(b), scale, H.ptr(c), a.numel(), H.stream()), "swr_mul_scale_fwd")
         ctx.save_for_backward(a, b)
+        ctx.scale = scale
         return c
 
     @staticmethod
@@ -1500,15 +1502,15 @@ class Mul(Function):
         da = db = None
         if ctx.needs_input_grad[0]:
             da = torch.empty_like(a)
-            H.check(lib.swr_mul_fwd(H.ptr(dc), H.ptr(b), H.ptr(da), a.numel(), H.stream()), "swr_mul_fwd")
+            H.check(lib.swr_mul_scale_fwd(H.ptr(dc), H.ptr(b), ctx.scale, H.ptr(da), a.numel(), H.stream()), "swr_mul_scale_fwd")
         if ctx.needs_input_grad[1]:
             db = torch.empty_like(b)
-            H.check(lib.swr_mul_fwd(H.ptr(dc), H.ptr(a), H.ptr(db), a.numel(), H.stream()), "swr_mul_fwd")
-        return da, db
+            H.check(lib.swr_mul_scale_fwd(H.ptr(dc), H.ptr(a), ctx.scale, H.ptr(db), a.numel(), H.stream()), "swr_mul_scale_fwd")
+        return da, db, None
 
 
-def mul(a, b):
-    return Mul.apply(a, b)
+def mul(a, b, scale=1.0):
+    return Mul.apply(a, b, float(scale))
 
 
 class Add(Function):
