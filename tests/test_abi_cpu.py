@@ -160,3 +160,44 @@ def test_evaluate_multi_domain_loss_host_logic():
     auc, ll = tr.evaluate(tr.model, batches)
     assert auc == pytest.approx(ta) and ll == pytest.approx(tl)
     assert tr.predict(tr.model, batches) == pytest.approx(p.tolist())
+
+
+def test_bench_configs_have_the_baseline_shapes():
+    """bench.py's configurations are the BASELINE.json shapes: K0 = F_s * E + F_d, domain counts,
+    per-GPU batches; synthetic batches are reproducible and within the vocabularies."""
+    sys.path.insert(0, ROOT)
+    import bench
+    want = {1: (49, 3, 4096), 2: (516, 5, 65536), 3: (376, 3, 131072 // 8), 4: (96, 4, 65536 // 8), 5: (388, 8, 262144 // 8),
+            6: (452, 8, 262144 // 8)}
+    for n, (k0, D, B) in want.items():
+        cfg = bench.CONFIGS[n]
+        assert len(cfg["vocabs"]) * cfg["embed_dim"] + cfg["n_dense"] == k0, n
+        assert len(cfg["domain_shares"]) == D and cfg["batch"] == B, n
+    assert bench.gather_bytes_per_sample(bench.CONFIGS[2]) == 4384            # SURVEY.md 8(d)
+    cfg = dict(bench.CONFIGS[2], vocabs=[1000, 50000, 8, 2])
+    x1, y1 = bench.synth_batch(cfg, 512, seed=3)
+    x2, y2 = bench.synth_batch(cfg, 512, seed=3)
+    assert all(np.array_equal(x1[k], x2[k]) for k in x1) and np.array_equal(y1, y2)
+    for i, v in enumerate(cfg["vocabs"]):
+        assert x1[f"s{i}"].min() >= 0 and x1[f"s{i}"].max() < v
+    assert set(np.unique(x1["domain_indicator"])) <= set(range(5))
+
+
+def test_ctrtrainer_gpus_without_a_launcher_says_how_to_launch(monkeypatch):
+    """`CTRTrainer(gpus=[0, 1])` (reference: nn.DataParallel, ctr_trainer.py:45-47) outside `torch.distributed.run` raises
+    with the command line to use instead of silently training on one GPU; the row chunk of a rank is torch.chunk's."""
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.models.multi_domain import MMOE
+    from scenario_wise_rec.trainers import CTRTrainer
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    feats = [SparseFeature("s0", 5, 4), DenseFeature("d0")]
+    model = MMOE(feats, 2, 2, {"dims": [4]}, {"dims": [4]})
+    with pytest.raises(RuntimeError, match="torch.distributed.run"):
+        CTRTrainer(model, "x", gpus=[0, 1])
+    tr = CTRTrainer.__new__(CTRTrainer)
+    tr._world, tr._rank = 4, 2
+    xs, ys = tr._my_rows({"a": torch.arange(12)}, torch.arange(12))
+    assert xs["a"].tolist() == [6, 7, 8] and ys.tolist() == torch.arange(12).chunk(4)[2].tolist()
+    with pytest.raises(ValueError, match="split evenly"):
+        tr._my_rows({"a": torch.arange(10)}, torch.arange(10))
