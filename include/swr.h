@@ -361,7 +361,7 @@ int swr_moe_mix_bwd(const swr_mix_desc* desc_host, const float* dP, int64_t lddp
  *   Z[:, 0 : ne*H] experts (BN -> ReLU), Z[:, ne*H : ne*H + D*ne] gates (BN -> softmax over ne),
  *   P[:, o*H:(o+1)*H] = sum_j gate_o[j] * expert_j          (identity selection: every output mixes every expert)
  * swr_bnmix_fwd: Z, scale, shift -> P.   swr_bnmix_bwd: dP, Z, scale, shift, mean, rstd -> dY = dL/d(BN output)
- * [M, ne*H + D*ne] and bn_partials [ceil(M/64)][ne*H + D*ne][2] for swr_bn_bwd_finalize; swr_act_bwd_apply without
+ * [M, ne*H + D*ne] and bn_partials [ceil(M/T)][ne*H + D*ne][2], T = swr_bnmix_tile_rows(), for swr_bn_bwd_finalize; swr_act_bwd_apply without
  * activations then gives dZ.  ne <= 8, D <= 8, H in {16, 32} (swr_bnmix_supported); other shapes:
  * swr_affine_act_fwd + swr_moe_mix_* + swr_bn_act_bwd_stats. */
 typedef struct {
@@ -379,6 +379,7 @@ typedef struct {
 } swr_bnmix_args;
 
 int swr_bnmix_supported(int ne, int H, int D);
+int swr_bnmix_tile_rows(void);
 int swr_bnmix_fwd(const swr_bnmix_args* args_host, void* stream);
 int swr_bnmix_bwd(const swr_bnmix_args* args_host, void* stream);
 

@@ -514,7 +514,7 @@ extern "C" int swr_bn_bwd_finalize(const float* partials, int n_tiles, int64_t M
                                    const float* rstd, float* dgamma, float* dbeta, int accumulate, float* ca, float* cb,
                                    float* cc, void* stream) {
     SWR_REQUIRE(partials && rstd && ca && cb && cc && n_tiles > 0 && M > 0 && N > 0, SWR_ERR_ARG);
-    SWR_REQUIRE(n_tiles == swr_ceil_div(M, BWD_TILE), SWR_ERR_ARG);
+    SWR_REQUIRE(n_tiles <= M, SWR_ERR_ARG);          // any row tiling: the partials are summed in tile order
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(N), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), partials,
                        n_tiles, M, N, gamma, rstd, dgamma, dbeta, accumulate, ca, cb, cc);
     return swr_launch_status();

@@ -18,7 +18,9 @@
 // values) rather than exchanged.  Identity selection only (every output mixes every expert, in order).
 #include "common.h"
 
-#define BM_ROWS 64            // rows per workgroup = the tile of swr_bn_bwd_finalize
+#ifndef BM_ROWS
+#define BM_ROWS 64            // rows per workgroup = one tile of partial sums for swr_bn_bwd_finalize
+#endif
 #define BM_MAX_D 8
 #define BM_MAX_G 32           // D * ne
 
@@ -246,6 +248,7 @@ static bool bnmix_ok(int ne, int H, int D) {
 }
 
 extern "C" int swr_bnmix_supported(int ne, int H, int D) { return bnmix_ok(ne, H, D) ? 1 : 0; }
+extern "C" int swr_bnmix_tile_rows(void) { return BM_ROWS; }
 
 static int bnmix_common(const swr_bnmix_args* args, BnMixK& kk) {
     SWR_REQUIRE(args != nullptr, SWR_ERR_ARG);

@@ -18,7 +18,9 @@
 // All reductions are per-tile partials summed in a fixed order: deterministic.
 #include "common.h"
 
+#ifndef TW_THREADS
 #define TW_THREADS 256
+#endif
 
 struct TowerK {
     swr_tower_args a;
@@ -372,7 +374,7 @@ extern "C" int swr_tower_fwd_linear(const swr_tower_args* args, void* stream) {
     TowerK kk;
     kk.a = a;
     kk.bn_partials = kk.head_partials = nullptr;
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)), static_cast<unsigned>(a.G));
+        const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)), static_cast<unsigned>(a.G));
     TW_DISPATCH_KH(launch_linear_fwd, a.K, a.H, (kk, grid, static_cast<hipStream_t>(stream)));
     return swr_launch_status();
 }
@@ -412,7 +414,7 @@ extern "C" int swr_tower_bwd(const swr_tower_args* args, void* workspace, size_t
     kk.bn_partials = static_cast<float*>(workspace);
     kk.head_partials = kk.bn_partials + static_cast<size_t>(n_tiles) * N * 2;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)), static_cast<unsigned>(a.G));
+        const dim3 grid(static_cast<unsigned>(swr_ceil_div(a.M, TW_THREADS)), static_cast<unsigned>(a.G));
     TW_DISPATCH_H(launch_bwd_stats, a.H, (kk, grid, st));
     hipLaunchKernelGGL(tower_bwd_finalize_kernel, dim3(static_cast<unsigned>(N + a.G)), dim3(TW_THREADS), 0, st, kk, n_tiles);
     TW_DISPATCH_KH(launch_bwd_apply, a.K, a.H, (kk, grid, st));

@@ -208,6 +208,7 @@ _SIGS = {
     "swr_select_bce_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
     "swr_select_bce_bwd": (C.c_int, [_P, _P, _I, _I, _P, _I, _L, _P, _P, _L, _P]),
     "swr_bnmix_supported": (C.c_int, [_I, _I, _I]),
+    "swr_bnmix_tile_rows": (C.c_int, []),
     "swr_bnmix_fwd": (C.c_int, [_P, _P]),
     "swr_bnmix_bwd": (C.c_int, [_P, _P]),
     "swr_tower_supported": (C.c_int, [_I, _I]),

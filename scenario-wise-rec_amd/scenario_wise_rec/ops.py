@@ -843,7 +843,8 @@ class LinearBNAct(Function):
         direct_bn = False
         dZ = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
         if ctx.training_bn:
-            nt = (M + 63) // 64
+            tile = lib.swr_bnmix_tile_rows() if ctx.mix is not None else 64
+            nt = (M + tile - 1) // tile
             partials = torch.empty((nt, Ntot, 2), dtype=torch.float32, device=dev)
             if ctx.mix is not None:
                 # incoming gradient is dP (w.r.t. the pooled outputs): one pass gives dL/d(BN output) + the statistics
@@ -974,7 +975,9 @@ class LinearBNAct(Function):
                     dx = dx[:, :K]
         if side_dw:
             # forked AFTER the dX product is enqueued: dX is on the critical path and must not share the MFMA pipes
-            # with dW; dW then overlaps whatever the main stream does next (the embedding backward, lower layers)
+            # with dW; dW then overlaps whatever the main stream does next (the embedding backward, lower layers).
+            # (Measured, config 2: forking BEFORE dX instead -- dW next to dX and K3 -- 0.523 vs 0.520 ms: that stretch of
+            # the step is throughput-bound, not dependency-bound.)
             _fork_dw(dev, launch_dw, (dZ, x, dW, db))
         if direct_w:
             _mark_touched(p_W + tuple(p_b))
