@@ -248,7 +248,9 @@ typedef struct {
     int32_t n_compute;     /* 0 = all: columns n >= n_compute of C are written as ZERO without being computed (whole
                               32-column tiles are skipped; nt bf16-split kernel, one group).  dX of a layer that sits on
                               the embedding concat: the trailing dense-feature columns take no gradient */
-    int32_t pad0;
+    int32_t a_exact_from;  /* 0 = none: columns k >= a_exact_from of A hold values that are exactly representable in bf16
+                              (the one-hot block of a folded first layer: 0 / 1).  The bf16-split kernel then issues
+                              three products instead of six for those k and skips their split; same bits either way */
 } swr_gemm_args;
 
 int swr_gemm_nt(const swr_gemm_args* args_host, void* stream);

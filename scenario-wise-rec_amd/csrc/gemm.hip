@@ -301,6 +301,13 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     } while (0)
 #endif
 
+#define CVT_PAIR(x0, x1, H, idx)                                            \
+    do {                                                                    \
+        const f32x2 cx_ = {x0, x1};                                         \
+        const bf16x2 ch_ = __builtin_convertvector(cx_, bf16x2);            \
+        H[idx] = ch_[0]; H[(idx) + 1] = ch_[1];                             \
+    } while (0)
+
 template <int NT, bool PRO, bool PS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD
     constexpr int NCOL = NT * 32;
@@ -421,16 +428,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(bp + p * PLANE);
     };
-    auto do_chunk = [&](int c, auto half) {
+    // EX: the A columns of this chunk are exactly representable in bf16 (a_exact_from: the one-hot block of a folded first
+    // layer): their middle / low terms are zero, so three of the six products vanish -- and so does the split
+    auto do_chunk = [&](int c, auto half, auto exact) {
         constexpr int HALF = decltype(half)::value;
+        constexpr bool EX = decltype(exact)::value;
         stage_load((c + 1) * X6_KC);                   // beyond K this loads zeros (never stored)
 #pragma unroll
         for (int gq = 0; gq < X6_KC / 16; ++gq) {
             float4 av[2];
             a_use(c * (X6_KC / 16) + gq, ar[gq + HALF * (DEPTH / 2)], av);
             bf16x8 ah, am, al;
-            SPLIT3_PAIR(av[0].x, av[0].y, ah, am, al, 0); SPLIT3_PAIR(av[0].z, av[0].w, ah, am, al, 2);
-            SPLIT3_PAIR(av[1].x, av[1].y, ah, am, al, 4); SPLIT3_PAIR(av[1].z, av[1].w, ah, am, al, 6);
+            if (EX) {
+                CVT_PAIR(av[0].x, av[0].y, ah, 0); CVT_PAIR(av[0].z, av[0].w, ah, 2);
+                CVT_PAIR(av[1].x, av[1].y, ah, 4); CVT_PAIR(av[1].z, av[1].w, ah, 6);
+            } else {
+                SPLIT3_PAIR(av[0].x, av[0].y, ah, am, al, 0); SPLIT3_PAIR(av[0].z, av[0].w, ah, am, al, 2);
+                SPLIT3_PAIR(av[1].x, av[1].y, ah, am, al, 4); SPLIT3_PAIR(av[1].z, av[1].w, ah, am, al, 6);
+            }
             bf16x8 b0[3], b1[3];
             b_read(b0, gq, 0, DB ? HALF : 0);
 #pragma unroll
@@ -441,10 +456,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
                 if (t + 1 < NT) b_read(nxt, gq, t + 1, DB ? HALF : 0);
                 __builtin_amdgcn_sched_barrier(0);      // next tile's LDS reads are issued before this tile's MFMAs
                 f32x16 c_ = acc[t];
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cur[0], c_, 0, 0, 0);     // small terms first
+                if (!EX) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cur[0], c_, 0, 0, 0);     // small terms first
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[2], c_, 0, 0, 0);
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[1], c_, 0, 0, 0);
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[0], c_, 0, 0, 0);
+                if (!EX) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[1], c_, 0, 0, 0);
+                if (!EX) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[0], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[1], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[0], c_, 0, 0, 0);
                 acc[t] = c_;
@@ -460,9 +475,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const Gem
             __syncthreads();
         }
     };
-    for (int c = 0; c < n_chunks; c += 2) {
-        do_chunk(c, std::integral_constant<int, 0>{});
-        if (c + 1 < n_chunks) do_chunk(c + 1, std::integral_constant<int, 1>{});
+    // chunk PAIRS that lie entirely inside the exact column range run the three-product body (PRO rescales A: never
+    // exact).  Two plain loops: a single loop with a per-chunk choice of body made hipcc spill 449 VGPRs, and so did a
+    // mixed pair (full chunk + exact chunk) between the two loops (488)
+    const int c_exact = (!PRO && a.a_exact_from > 0) ? min(n_chunks, (a.a_exact_from + 2 * X6_KC - 1) / (2 * X6_KC) * 2) : n_chunks;
+    int c = 0;
+    for (; c < c_exact; c += 2) {
+        do_chunk(c, std::integral_constant<int, 0>{}, std::false_type{});
+        if (c + 1 < n_chunks) do_chunk(c + 1, std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    if (!PRO) {
+        for (; c < n_chunks; c += 2) {
+            do_chunk(c, std::integral_constant<int, 0>{}, std::true_type{});
+            if (c + 1 < n_chunks) do_chunk(c + 1, std::integral_constant<int, 1>{}, std::true_type{});
+        }
     }
     rows_epilogue<NT>(a, kk.n_tiles_m, acc, g, tile_m, m0, n0, i, s);
 }

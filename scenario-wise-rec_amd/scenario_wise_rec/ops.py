@@ -26,10 +26,12 @@ def _ld(t):
 
 def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_relu=False, accumulate=False,
          stat_partials=None, groups=1, gsA=0, gsB=0, gsC=0, gsBias=0, gsScale=0, lda=None, ldb=None, ldc=None,
-         B_split=None, n_compute=0):
+         B_split=None, n_compute=0, a_exact_from=0):
     """kind 'nt': C[m,n] = sum_k A[m,k] B[n,k];  'nn': C[m,n] = sum_k A[m,k] B[k,n].
-    B_split: (planes, ld, plane_stride) from split_weights -- B already split into bf16 planes ('nt', one group)."""
+    B_split: (planes, ld, plane_stride) from split_weights -- B already split into bf16 planes ('nt', one group).
+    a_exact_from: columns k >= this of A hold bf16-exact values (0 / 1 of a one-hot block): half the products there."""
     a = H.GemmArgs()
+    a.a_exact_from = int(a_exact_from)
     if B_split is not None:
         a.B_split, a.ld_split, a.plane_stride = B_split[0].data_ptr(), B_split[1], B_split[2]
     a.M, a.N, a.K = M, N, K
@@ -169,6 +171,7 @@ SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measur
                                                                         # whatever it is overlapped with; off by default
 SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "4"))   # measured: 4 (edge at once, launches after the next main kernel) 0.700 ms,
                                                         # 1 (fork at once) 0.709, 3 (edge and launches later) 0.711, 2 (event nodes) stalls the branch
+EXACT_ONEHOT = os.environ.get("SWR_EXACT_ONEHOT", "1") != "0"   # one-hot columns: three bf16 products instead of six
 SIDE_DW_MIN_FLOP = float(os.environ.get("SWR_SIDE_DW_MIN_FLOP", "2e9"))
 SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "2e10"))  # weight-gradient products below this size run on a
                                                                         # stream of their own (_fork_dw) next to the dX -> K3
@@ -771,7 +774,7 @@ class LinearBNAct(Function):
             H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
                                                  H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
                     "swr_fold_first_layer_fwd")
-            gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials)
+            gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp if EXACT_ONEHOT else 0)
             planes_t = None
         else:
             gemm("nt", x, W, Z, M, N, K, bias=b, stat_partials=partials, groups=G,

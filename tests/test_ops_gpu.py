@@ -878,3 +878,24 @@ def test_gather_one_hot_block_of_small_tables(fold, monkeypatch):
     assert sorted(t[1] for t in info.tables_p) == [2, 3, 7, 16]
     layer.eval()
     assert getattr(layer(xd, feats, squeeze_dim=True, onehot=True), "_swr_onehot", None) is None
+
+
+@pytest.mark.parametrize("M,N,K,ex", [(4096, 148, 276, 148), (1000, 148, 276, 148), (250, 33, 200, 64), (4096, 64, 96, 32),
+                                      (300, 148, 128, 1), (64, 160, 260, 200)])
+def test_gemm_exact_columns_give_the_same_bits(M, N, K, ex):
+    """`a_exact_from` (swr.h): columns of A that hold 0 / 1 need three of the six bf16 products; the three left out are
+    products with zero terms, so the result is bitwise the full kernel's.  Also against fp64."""
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(M + N + K + ex)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    A[:, ex:] = (rng.random((M, K - ex)) < 0.1).astype(np.float32)          # the one-hot block
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dA, dW, db = _dev(A), _dev(W), _dev(b)
+    full = torch.empty((M, N), device="cuda")
+    fast = torch.empty((M, N), device="cuda")
+    ops.gemm("nt", dA, dW, full, M, N, K, bias=db)
+    ops.gemm("nt", dA, dW, fast, M, N, K, bias=db, a_exact_from=ex)
+    assert torch.equal(full, fast)
+    bound = 2e-6 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1)
+    assert np.all(np.abs(fast.cpu().numpy() - (A.astype(np.float64) @ W.astype(np.float64).T + b)) <= bound)
