@@ -206,44 +206,52 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_v4_kernel(
 // ---------------------------------------------------------------------------------- forward stats
 // Two fixed-order fp64 passes over the tiles of one column: mean = sum(n_t mean_t) / n, then
 // M2 = sum(M2_t + n_t (mean_t - mean)^2) -- the pairwise (Chan) combination written as two plain sums, so the
-// 256-thread trees are additions only (a tree of fp64 divisions made this small kernel take 10 us).
+// block sums are additions only (a tree of fp64 divisions made this small kernel take 10 us); the tile statistics stay
+// in registers between the passes and the sums are wave butterflies + one LDS exchange (swr_block_sum_f64).
 __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
     const float* __restrict__ part, int n_tiles, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var,
     int64_t* nbt, int n_tracked, float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
-    __shared__ double sm[BN_THREADS];
-    __shared__ double mean_s;
+    __shared__ double sm1[BN_THREADS / 64], sm2[BN_THREADS / 64];
+    constexpr int KEEP = 8;                                   // tiles per thread held in registers (B <= 65 536)
     const int n = blockIdx.x;
     const int per = (n_tiles + BN_THREADS - 1) / BN_THREADS;
     const int t0 = threadIdx.x * per, t1 = min(t0 + per, n_tiles);
-    auto tree = [&](double v) {
-        sm[threadIdx.x] = v;
-        __syncthreads();
-        for (int st = 1; st < BN_THREADS; st <<= 1) {
-            if ((threadIdx.x & (2 * st - 1)) == 0) sm[threadIdx.x] += sm[threadIdx.x + st];
-            __syncthreads();
-        }
-        const double r = sm[0];
-        __syncthreads();
-        return r;
-    };
+    const bool keep = per <= KEEP;
+    float2 pv[KEEP];
+    if (keep) {                                               // one trip to memory for both passes
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            pv[u] = t0 + u < t1 ? *reinterpret_cast<const float2*>(part + (static_cast<int64_t>(t0 + u) * N + n) * 2)
+                                : make_float2(0.f, 0.f);
+    }
+    auto tile_rows = [&](int t) { return static_cast<double>(min<int64_t>(32, M - static_cast<int64_t>(t) * 32)); };
     double acc = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const double nt = static_cast<double>(min<int64_t>(32, M - static_cast<int64_t>(t) * 32));
-        acc += nt * static_cast<double>(part[(static_cast<int64_t>(t) * N + n) * 2]);
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            if (t0 + u < t1) acc += tile_rows(t0 + u) * static_cast<double>(pv[u].x);
+    } else {
+        for (int t = t0; t < t1; ++t) acc += tile_rows(t) * static_cast<double>(part[(static_cast<int64_t>(t) * N + n) * 2]);
     }
-    const double total = tree(acc);
-    if (threadIdx.x == 0) mean_s = total / static_cast<double>(M);
-    __syncthreads();
-    const double mu = mean_s;
+    const double mu = swr_block_sum_f64<BN_THREADS>(acc, sm1) / static_cast<double>(M);
     acc = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const float* p = part + (static_cast<int64_t>(t) * N + n) * 2;
-        const double nt = static_cast<double>(min<int64_t>(32, M - static_cast<int64_t>(t) * 32));
-        const double d = static_cast<double>(p[0]) - mu;
-        acc += static_cast<double>(p[1]) + nt * d * d;
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            if (t0 + u < t1) {
+                const double d = static_cast<double>(pv[u].x) - mu;
+                acc += static_cast<double>(pv[u].y) + tile_rows(t0 + u) * d * d;
+            }
+        }
+    } else {
+        for (int t = t0; t < t1; ++t) {
+            const float* p = part + (static_cast<int64_t>(t) * N + n) * 2;
+            const double d = static_cast<double>(p[0]) - mu;
+            acc += static_cast<double>(p[1]) + tile_rows(t) * d * d;
+        }
     }
-    const double m2 = tree(acc);
+    const double m2 = swr_block_sum_f64<BN_THREADS>(acc, sm2);
     if (threadIdx.x == 0) {
         const double cnt = static_cast<double>(M);
         const double var_b = m2 / cnt;
@@ -478,28 +486,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_finalize_kernel(const float
                                                                      const float* __restrict__ rstd, float* dgamma,
                                                                      float* dbeta, int accumulate, float* ca, float* cb,
                                                                      float* cc) {
-    __shared__ double t1[BN_THREADS], t2[BN_THREADS];
+    __shared__ double t1[BN_THREADS / 64], t2[BN_THREADS / 64];
     const int n = blockIdx.x;
     double a1 = 0.0, a2 = 0.0;
     const int per = (n_tiles + BN_THREADS - 1) / BN_THREADS;
     const int t0 = threadIdx.x * per;
     for (int t = t0; t < min(t0 + per, n_tiles); ++t) {
-        const float* p = part + (static_cast<int64_t>(t) * N + n) * 2;
-        a1 += p[0];
-        a2 += p[1];
+        const float2 p = *reinterpret_cast<const float2*>(part + (static_cast<int64_t>(t) * N + n) * 2);
+        a1 += p.x;
+        a2 += p.y;
     }
-    t1[threadIdx.x] = a1;
-    t2[threadIdx.x] = a2;
-    __syncthreads();
-    for (int st = 1; st < BN_THREADS; st <<= 1) {
-        if ((threadIdx.x & (2 * st - 1)) == 0) {
-            t1[threadIdx.x] += t1[threadIdx.x + st];
-            t2[threadIdx.x] += t2[threadIdx.x + st];
-        }
-        __syncthreads();
-    }
+    const double S1 = swr_block_sum_f64<BN_THREADS>(a1, t1), S2 = swr_block_sum_f64<BN_THREADS>(a2, t2);
     if (threadIdx.x == 0) {
-        const double S1 = t1[0], S2 = t2[0];
         const double g = gamma ? gamma[n] : 1.0, rs = rstd[n];
         if (dgamma) dgamma[n] = (accumulate ? dgamma[n] : 0.f) + static_cast<float>(S2);
         if (dbeta) dbeta[n] = (accumulate ? dbeta[n] : 0.f) + static_cast<float>(S1);

@@ -82,3 +82,19 @@ __device__ __forceinline__ float swr_sigmoid(float x) {
 // library never issues memsets on the hot path.
 __global__ void swr_zero_kernel(uint4* p, size_t n16, unsigned char* tail, size_t ntail);
 int swr_zero_async(void* p, size_t bytes, hipStream_t st);
+
+// Sum of one double per thread over a workgroup of NT threads (NT a multiple of 64, <= 1024), in a FIXED order: butterfly
+// inside each wave, then the per-wave sums added in wave order by every thread (result in all threads).  `sm` = one
+// double per wave, a different array for every call inside a kernel (no barrier protects its reuse).  Replaces the
+// 8-step LDS tree (8 barriers) of the statistics finalisers.
+template <int NT>
+__device__ __forceinline__ double swr_block_sum_f64(double v, double* sm) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = sm[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r += sm[w];
+    return r;
+}

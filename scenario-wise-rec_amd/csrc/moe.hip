@@ -401,17 +401,12 @@ __global__ __launch_bounds__(EW_THREADS) void bce_partial_kernel(const float* __
 
 __global__ __launch_bounds__(EW_THREADS) void bce_final_kernel(const float* __restrict__ part, int n_part, int64_t M,
                                                                float* __restrict__ loss) {
-    __shared__ double sm[EW_THREADS];
+    __shared__ double sm[EW_THREADS / 64];
     double acc = 0.0;
     const int per = (n_part + EW_THREADS - 1) / EW_THREADS;
     for (int t = threadIdx.x * per; t < min((threadIdx.x + 1) * per, n_part); ++t) acc += part[t];
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (int st = 1; st < EW_THREADS; st <<= 1) {
-        if ((threadIdx.x & (2 * st - 1)) == 0) sm[threadIdx.x] += sm[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = static_cast<float>(sm[0] / static_cast<double>(M));
+    const double total = swr_block_sum_f64<EW_THREADS>(acc, sm);
+    if (threadIdx.x == 0) *loss = static_cast<float>(total / static_cast<double>(M));
 }
 
 extern "C" size_t swr_bce_workspace_bytes(int64_t M) { return static_cast<size_t>(swr_ceil_div(M > 0 ? M : 1, BCE_PER_BLOCK)) * 4 + 256; }
@@ -455,7 +450,7 @@ __global__ __launch_bounds__(EW_THREADS) void select_bce_fwd_kernel(const float*
                                                                     float* __restrict__ p_out, float* part, int n_part,
                                                                     uint32_t* ticket, float* __restrict__ loss) {
     __shared__ float sm[EW_THREADS / 64];
-    __shared__ double smd[EW_THREADS];
+    __shared__ double smd[EW_THREADS / 64];
     __shared__ bool is_last;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * BCE_PER_BLOCK;
     float acc = 0.f;
@@ -483,14 +478,9 @@ __global__ __launch_bounds__(EW_THREADS) void select_bce_fwd_kernel(const float*
     const int per = (n_part + EW_THREADS - 1) / EW_THREADS;
     for (int t = threadIdx.x * per; t < min((threadIdx.x + 1) * per, n_part); ++t)
         a += __hip_atomic_load(part + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    smd[threadIdx.x] = a;
-    __syncthreads();
-    for (int st = 1; st < EW_THREADS; st <<= 1) {
-        if ((threadIdx.x & (2 * st - 1)) == 0) smd[threadIdx.x] += smd[threadIdx.x + st];
-        __syncthreads();
-    }
+    const double total = swr_block_sum_f64<EW_THREADS>(a, smd);
     if (threadIdx.x == 0) {
-        *loss = static_cast<float>(smd[0] / static_cast<double>(M));
+        *loss = static_cast<float>(total / static_cast<double>(M));
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

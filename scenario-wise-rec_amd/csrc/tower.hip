@@ -207,7 +207,7 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_stats_kernel(const Tower
 // fixed-order fp64 sums over the 64-row tiles; one workgroup per hidden column (+ one per tower for db2)
 __global__ __launch_bounds__(TW_THREADS) void tower_bwd_finalize_kernel(const TowerK kk, int n_tiles) {
     const swr_tower_args& a = kk.a;
-    __shared__ double t1[TW_THREADS], t2[TW_THREADS], t3[TW_THREADS];
+    __shared__ double t1[TW_THREADS / 64], t2[TW_THREADS / 64], t3[TW_THREADS / 64];
     const int N = a.G * (a.H);
     const int n = blockIdx.x;                                                  // < N: hidden column, >= N: tower
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -215,30 +215,21 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_finalize_kernel(const To
     const int t0 = threadIdx.x * per;
     for (int t = t0; t < min(t0 + per, n_tiles); ++t) {
         if (n < N) {
-            const float* p = kk.bn_partials + (static_cast<int64_t>(t) * N + n) * 2;
-            a1 += p[0];
-            a2 += p[1];
+            const float2 p = *reinterpret_cast<const float2*>(kk.bn_partials + (static_cast<int64_t>(t) * N + n) * 2);
+            a1 += p.x;
+            a2 += p.y;
         }
         a3 += kk.head_partials[static_cast<int64_t>(t) * (N + a.G) + n];
     }
-    t1[threadIdx.x] = a1; t2[threadIdx.x] = a2; t3[threadIdx.x] = a3;
-    __syncthreads();
-    for (int st = 1; st < TW_THREADS; st <<= 1) {
-        if ((threadIdx.x & (2 * st - 1)) == 0) {
-            t1[threadIdx.x] += t1[threadIdx.x + st];
-            t2[threadIdx.x] += t2[threadIdx.x + st];
-            t3[threadIdx.x] += t3[threadIdx.x + st];
-        }
-        __syncthreads();
-    }
+    const double S1 = swr_block_sum_f64<TW_THREADS>(a1, t1), S2 = swr_block_sum_f64<TW_THREADS>(a2, t2);
+    const double S3 = swr_block_sum_f64<TW_THREADS>(a3, t3);
     if (threadIdx.x != 0) return;
-    const float s3 = static_cast<float>(t3[0]);
+    const float s3 = static_cast<float>(S3);
     if (n >= N) {
         if (a.db2) a.db2[n - N] = (a.accumulate ? a.db2[n - N] : 0.f) + s3;
         return;
     }
     if (a.dw2) a.dw2[n] = (a.accumulate ? a.dw2[n] : 0.f) + s3;
-    const double S1 = t1[0], S2 = t2[0];
     const double gm = a.gamma ? a.gamma[n] : 1.0, rs = a.rstd[n];
     if (a.dgamma) a.dgamma[n] = (a.accumulate ? a.dgamma[n] : 0.f) + static_cast<float>(S2);
     if (a.dbeta) a.dbeta[n] = (a.accumulate ? a.dbeta[n] : 0.f) + static_cast<float>(S1);
