@@ -393,6 +393,9 @@ int swr_bnmix_bwd(const swr_bnmix_args* args_host, void* stream);
  * {4,8,16,32} (swr_tower_supported); other shapes go through swr_gemm_* + swr_bn_* + swr_affine_act_*.
  *   swr_tower_fwd_linear : Z1[M, G*H] = X_g W1_g^T + b1 (+ stat_partials [ceil(M/32)][G*H][2] for swr_bn_finalize)
  *   swr_tower_fwd_head   : V[M, G]    = relu(scale * Z1 + shift)_g . w2_g + b2_g
+ *   swr_tower_head_select_bce_fwd : the output layer of each row's OWN tower + sigmoid + domain select (mmoe.py:51-55) +
+ *                          mean BCE (ctr_trainer.py:56,70) in one launch: p[M], loss; the bits of swr_tower_fwd_head +
+ *                          swr_select_bce_fwd.  workspace: swr_bce_workspace_bytes(M); ticket as swr_select_bce_fwd
  *   swr_tower_bwd        : from dV[M, G]: dgamma, dbeta, dw2[G*H], db2[G] (written, or added when `accumulate`),
  *                          dZ1[M, G*H] (feed swr_gemm_tn for dW1 / db1) and dX[M, G*K] (skipped when null).
  *                          ca / cb / cc: [G*H] scratch for the BatchNorm backward coefficients. */
@@ -412,8 +415,18 @@ typedef struct {
     float* dgamma; float* dbeta; float* dw2; float* db2;        /* nullable */
     float* dZ1;      int64_t lddz;
     float* dX;       int64_t lddx;                /* nullable */
+    /* selected mode of swr_tower_bwd (dV == NULL): the towers fed swr_tower_head_select_bce_fwd, so
+       dV[m, g] = (domain[m] == g) ? d(mean BCE)/d(logit)(p[m], y[m]) * dloss : 0 is computed on the fly, never stored */
+    const void* sel_domain; const void* sel_y;    /* [M] each */
+    const float* sel_p;                           /* [M] selected probabilities (forward output) */
+    const float* sel_dloss;                       /* device scalar: gradient arriving on the mean loss */
+    int32_t sel_dom_dtype, sel_y_dtype;
 } swr_tower_args;
 
+int swr_tower_head_select_bce_fwd(const float* Z1, int64_t ldz, int G, int H, const float* scale, const float* shift,
+                                  const float* w2, const float* b2, const void* domain, int dom_dtype, const void* y,
+                                  int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
+                                  uint32_t* ticket, void* stream);
 int swr_tower_supported(int K, int H);
 int swr_tower_fwd_linear(const swr_tower_args* args_host, void* stream);
 int swr_tower_fwd_head(const swr_tower_args* args_host, void* stream);

@@ -83,6 +83,13 @@ __device__ __forceinline__ float swr_sigmoid(float x) {
 __global__ void swr_zero_kernel(uint4* p, size_t n16, unsigned char* tail, size_t ntail);
 int swr_zero_async(void* p, size_t bytes, hipStream_t st);
 
+// d(mean BCE)/d(logit) of one row whose probability p = sigmoid(logit) was selected: dBCE/dp rounded as swr_bce_bwd rounds it
+// (torch's clamp of p (1 - p) at 1e-12), times p (1 - p) as swr_select_bwd rounds it.
+__device__ __forceinline__ float swr_bce_logit_grad(float pi, float yi, float dloss, int64_t M) {
+    const float g = dloss * (pi - yi) / fmaxf(pi * (1.f - pi), 1e-12f) / static_cast<float>(M);
+    return g * pi * (1.f - pi);
+}
+
 // Sum of one double per thread over a workgroup of NT threads (NT a multiple of 64, <= 1024), in a FIXED order: butterfly
 // inside each wave, then the per-wave sums added in wave order by every thread (result in all threads).  `sm` = one
 // double per wave, a different array for every call inside a kernel (no barrier protects its reuse).  Replaces the

@@ -439,6 +439,29 @@ extern "C" int swr_bce_bwd(const float* p, const void* y, int y_dtype, int64_t M
     return swr_launch_status();
 }
 
+// per-workgroup loss partial + the final fixed-order fp64 sum by whichever workgroup draws the last ticket (no spinning: a
+// workgroup either is last or leaves); the ticket word is zero on entry and zero again on exit
+__device__ __forceinline__ void bce_finish(float acc, float* sm, double* smd, bool* is_last, float* part, int n_part,
+                                           uint32_t* ticket, float* __restrict__ loss, int64_t M) {
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = tot;
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *is_last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!*is_last) return;
+    double a = 0.0;
+    const int per = (n_part + EW_THREADS - 1) / EW_THREADS;
+    for (int t = threadIdx.x * per; t < min((threadIdx.x + 1) * per, n_part); ++t)
+        a += __hip_atomic_load(part + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double total = swr_block_sum_f64<EW_THREADS>(a, smd);
+    if (threadIdx.x == 0) {
+        *loss = static_cast<float>(total / static_cast<double>(M));
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------- select + BCE in one launch each way
 // The model's last op (domain select of the tower sigmoids, mmoe.py:51-55) and the trainer's criterion
 // (BCELoss, ctr_trainer.py:56,70) back to back: p and the per-workgroup loss partials in one pass, the final fp64 tree
@@ -466,23 +489,7 @@ __global__ __launch_bounds__(EW_THREADS) void select_bce_fwd_kernel(const float*
             acc -= yi * lp + (1.f - yi) * l1;
         }
     }
-    const float tot = block_sum(acc, sm);
-    if (threadIdx.x == 0) {
-        part[blockIdx.x] = tot;
-        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = t == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    double a = 0.0;
-    const int per = (n_part + EW_THREADS - 1) / EW_THREADS;
-    for (int t = threadIdx.x * per; t < min((threadIdx.x + 1) * per, n_part); ++t)
-        a += __hip_atomic_load(part + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double total = swr_block_sum_f64<EW_THREADS>(a, smd);
-    if (threadIdx.x == 0) {
-        *loss = static_cast<float>(total / static_cast<double>(M));
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    bce_finish(acc, sm, smd, &is_last, part, n_part, ticket, loss, M);
 }
 
 extern "C" int swr_select_bce_fwd(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype, const void* y,
@@ -498,6 +505,65 @@ extern "C" int swr_select_bce_fwd(const float* V, int64_t ldv, int D, const void
     return swr_launch_status();
 }
 
+// The per-domain tower output layer + sigmoid + domain select + BCE in one launch (towers of mmoe.py:38-41,50-55 /
+// ple.py / sharebottom.py, tower_params = {"dims": [H]}, in training mode): a row evaluates ONLY the tower of its own
+// domain -- V[m, g] for the other towers is never used by the loss -- with the operation order of tower_head_fwd_kernel
+// (tower.hip) and of select_bce_fwd_kernel above, so p and the loss are the bits of the two-launch path.
+__global__ __launch_bounds__(EW_THREADS) void tower_head_select_bce_kernel(
+    const float* __restrict__ Z1, int64_t ldz, int G, int Hd, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ w2, const float* __restrict__ b2, const void* __restrict__ domain, int dom_dtype,
+    const void* __restrict__ y, int y_dtype, int64_t M, float* __restrict__ p_out, float* part, int n_part, uint32_t* ticket,
+    float* __restrict__ loss) {
+    __shared__ float sm[EW_THREADS / 64];
+    __shared__ double smd[EW_THREADS / 64];
+    __shared__ bool is_last;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * BCE_PER_BLOCK;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < BCE_PER_BLOCK; k += EW_THREADS) {
+        const int64_t m = base + k;
+        if (m < M) {
+            const int64_t dom = swr_load_index(domain, dom_dtype, m);
+            float pi = 0.f;
+            if (dom >= 0 && dom < G) {
+                const int c0 = static_cast<int>(dom) * Hd;
+                const float* __restrict__ z = Z1 + m * ldz + c0;
+                float v = b2 ? b2[dom] : 0.f;
+                for (int j = 0; j < Hd; j += 4) {
+                    const float4 zq = *reinterpret_cast<const float4*>(z + j);
+                    const float zz[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float act = fmaxf(fmaf(zz[u], scale[c0 + j + u], shift[c0 + j + u]), 0.f);
+                        v = fmaf(act, w2[c0 + j + u], v);
+                    }
+                }
+                pi = swr_sigmoid(v);
+            }
+            p_out[m] = pi;
+            const float yi = swr_load_value(y, y_dtype, m);
+            const float lp = fmaxf(logf(pi), -100.f), l1 = fmaxf(logf(1.f - pi), -100.f);   // torch clamps the logs
+            acc -= yi * lp + (1.f - yi) * l1;
+        }
+    }
+    bce_finish(acc, sm, smd, &is_last, part, n_part, ticket, loss, M);
+}
+
+extern "C" int swr_tower_head_select_bce_fwd(const float* Z1, int64_t ldz, int G, int H, const float* scale,
+                                             const float* shift, const float* w2, const float* b2, const void* domain,
+                                             int dom_dtype, const void* y, int y_dtype, int64_t M, float* p, float* loss,
+                                             void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream) {
+    SWR_REQUIRE(Z1 && scale && shift && w2 && domain && y && p && loss && workspace && ticket && G > 0 && M > 0, SWR_ERR_ARG);
+    SWR_REQUIRE(H > 0 && H % 4 == 0 && ldz >= static_cast<int64_t>(G) * H && ldz % 4 == 0 && swr_aligned16(Z1), SWR_ERR_ALIGN);
+    SWR_REQUIRE(swr_is_index_dtype(dom_dtype), SWR_ERR_DTYPE);
+    SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
+    SWR_REQUIRE(workspace_bytes >= swr_bce_workspace_bytes(M), SWR_ERR_WORKSPACE);
+    const int nb = static_cast<int>(swr_ceil_div(M, BCE_PER_BLOCK));
+    hipLaunchKernelGGL(tower_head_select_bce_kernel, dim3(nb), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), Z1, ldz, G,
+                       H, scale, shift, w2, b2, domain, dom_dtype, y, y_dtype, M, p, static_cast<float*>(workspace), nb, ticket,
+                       loss);
+    return swr_launch_status();
+}
+
 // dV[m, d] = (d == dom[m]) ? dBCE/dp * p (1 - p) : 0, the two factors rounded exactly as swr_bce_bwd and
 // swr_select_bwd round them
 __global__ __launch_bounds__(EW_THREADS) void select_bce_bwd_kernel(const float* __restrict__ p, const void* __restrict__ y,
@@ -510,9 +576,7 @@ __global__ __launch_bounds__(EW_THREADS) void select_bce_bwd_kernel(const float*
     const int d = static_cast<int>(idx - m * D);
     float r = 0.f;
     if (swr_load_index(domain, dom_dtype, m) == d) {
-        const float pi = p[m], yi = swr_load_value(y, y_dtype, m);
-        const float g = dloss[0] * (pi - yi) / fmaxf(pi * (1.f - pi), 1e-12f) / static_cast<float>(M);
-        r = g * pi * (1.f - pi);
+        r = swr_bce_logit_grad(p[m], swr_load_value(y, y_dtype, m), dloss[0], M);
     }
     dV[m * lddv + d] = r;
 }

@@ -39,6 +39,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// dV[m, g]: read, or -- selected mode (swr.h) -- implied by the fused select + BCE: the gradient of the mean BCE with
+// respect to the logit of the row's own tower, zero for the other towers
+__device__ __forceinline__ float tower_dv(const swr_tower_args& a, int64_t m, int g) {
+    if (a.dV) return a.dV[m * a.lddv + g];
+    if (swr_load_index(a.sel_domain, a.sel_dom_dtype, m) != g) return 0.f;
+    return swr_bce_logit_grad(a.sel_p[m], swr_load_value(a.sel_y, a.sel_y_dtype, m), a.sel_dloss[0], a.M);
+}
+
 template <int N4>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&v)[4 * N4]) {
 #pragma unroll
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_stats_kernel(const Tower
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
     const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
     tile_load<H>(a.Z1 + m0 * a.ldz + g * H, a.ldz, rows, lz);
-    ldv[threadIdx.x] = static_cast<int>(threadIdx.x) < rows ? a.dV[(m0 + threadIdx.x) * a.lddv + g] : 0.f;
+    ldv[threadIdx.x] = static_cast<int>(threadIdx.x) < rows ? tower_dv(a, m0 + threadIdx.x, g) : 0.f;
     __syncthreads();
     constexpr int TPP = 64 / H;                               // H <= 32 -> >= 2
     constexpr int RPT = 64 / TPP;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_apply_kernel(const Tower
         lc[3 * H + threadIdx.x] = a.cb[n];    lc[4 * H + threadIdx.x] = a.mean[n];  lc[5 * H + threadIdx.x] = a.ca[n];
         lc[6 * H + threadIdx.x] = a.cc[n];
     }
-    const float dv = valid ? a.dV[(m0 + threadIdx.x) * a.lddv + g] : 0.f;
+    const float dv = valid ? tower_dv(a, m0 + threadIdx.x, g) : 0.f;
     __syncthreads();
     float dx[K];
 #pragma unroll
@@ -393,7 +401,14 @@ extern "C" int swr_tower_bwd(const swr_tower_args* args, void* workspace, size_t
     int rc = tower_common(args);
     if (rc != SWR_OK) return rc;
     swr_tower_args a = *args;
-    SWR_REQUIRE(a.dV && a.lddv >= a.G && a.scale && a.shift && a.mean && a.rstd && a.w2 && a.W1, SWR_ERR_ARG);
+    SWR_REQUIRE(a.scale && a.shift && a.mean && a.rstd && a.w2 && a.W1, SWR_ERR_ARG);
+    if (a.dV) {
+        SWR_REQUIRE(a.lddv >= a.G, SWR_ERR_ARG);
+    } else {                                                   // selected mode: dV implied by (p, y, domain, dloss)
+        SWR_REQUIRE(a.sel_domain && a.sel_y && a.sel_p && a.sel_dloss, SWR_ERR_ARG);
+        SWR_REQUIRE(swr_is_index_dtype(a.sel_dom_dtype), SWR_ERR_DTYPE);
+        SWR_REQUIRE(swr_is_value_dtype(a.sel_y_dtype), SWR_ERR_DTYPE);
+    }
     SWR_REQUIRE(a.ca && a.cb && a.cc && a.dZ1 && a.lddz >= a.G * a.H, SWR_ERR_ARG);
     SWR_REQUIRE(a.lddz % 4 == 0 && swr_aligned16(a.dZ1), SWR_ERR_ALIGN);
     SWR_REQUIRE(!a.dX || (a.lddx >= static_cast<int64_t>(a.G) * a.K && a.lddx % 4 == 0 && swr_aligned16(a.dX)), SWR_ERR_ALIGN);

@@ -111,7 +111,9 @@ class TowerArgs(C.Structure):
                 ("gamma", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("V", C.c_void_p), ("ldv", C.c_int64),
                 ("dV", C.c_void_p), ("lddv", C.c_int64), ("ca", C.c_void_p), ("cb", C.c_void_p), ("cc", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
-                ("dZ1", C.c_void_p), ("lddz", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64)]
+                ("dZ1", C.c_void_p), ("lddz", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64),
+                ("sel_domain", C.c_void_p), ("sel_y", C.c_void_p), ("sel_p", C.c_void_p), ("sel_dloss", C.c_void_p),
+                ("sel_dom_dtype", C.c_int32), ("sel_y_dtype", C.c_int32)]
 
 
 _P8 = C.c_void_p * 8
@@ -207,6 +209,7 @@ _SIGS = {
     "swr_bce_bwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _P]),
     "swr_select_bce_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
     "swr_select_bce_bwd": (C.c_int, [_P, _P, _I, _I, _P, _I, _L, _P, _P, _L, _P]),
+    "swr_tower_head_select_bce_fwd": (C.c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
     "swr_bnmix_supported": (C.c_int, [_I, _I, _I]),
     "swr_bnmix_tile_rows": (C.c_int, []),
     "swr_bnmix_fwd": (C.c_int, [_P, _P]),

@@ -322,6 +322,17 @@ def _tower_head_ok(mlps, x, shared_input, first_block):
     return ops.tower_head_supported(lin.in_features, lin.out_features)
 
 
+def mlp_bank_select(mlps, x, domain_id, first_block=0):
+    """`domain_select(sigmoid(towers(x)))` for per-domain towers on their own column blocks of x (mmoe.py:50-55): with the
+    fused tower kernels and the trainer's fused loss active, the output layer, the select and the BCE are one launch."""
+    if _tower_head_ok(mlps, x, False, first_block):
+        blocks = [m.block(first_block) for m in mlps]
+        outs = [m.output_linear() for m in mlps]
+        return ops.tower_head_select(x, [b[0].weight for b in blocks], [b[0].bias for b in blocks],
+                                     _bn_dict([b[1] for b in blocks]), [o.weight for o in outs], [o.bias for o in outs], domain_id)
+    return ops.domain_select(mlp_bank_forward(mlps, x, shared_input=False, first_block=first_block), domain_id, apply_sigmoid=True)
+
+
 def mlp_bank_forward(mlps, x, shared_input, first_block=0):
     """Evaluate structurally identical MLPs together: block `first_block` reads a shared x (stacked
     outputs) or per-member column slices of x; later blocks and the output layer are grouped launches.

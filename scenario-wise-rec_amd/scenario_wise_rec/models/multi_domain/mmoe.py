@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...basic.layers import MLP, EmbeddingLayer, LayerBank, _bn_dict, mlp_bank_forward, mlp_bank_groups
+from ...basic.layers import MLP, EmbeddingLayer, LayerBank, _bn_dict, mlp_bank_forward, mlp_bank_groups, mlp_bank_select
 from ...basic.module import SwrModule
 
 
@@ -68,8 +68,7 @@ class MMOE(SwrModule):
                     and ops.bnmix_supported(ne, h0, D)):
                 # single-layer ReLU experts: BatchNorm + ReLU / softmax + gate mix in one pass, no [B, 148] activations
                 pooled = self._first_bank()(embed_x, True, mix=(ne, h0, D))      # [B, D*H]
-                logits = mlp_bank_forward(list(self.towers), pooled, shared_input=False)
-                return ops.domain_select(logits, domain_id, apply_sigmoid=True)
+                return mlp_bank_select(list(self.towers), pooled, domain_id)
             y = self._first_bank()(embed_x, self.training)                       # [B, ne*H0 + D*ne]
             if experts[0].n_blocks > 1:
                 ex = mlp_bank_forward(experts, y[:, :ne * h0], shared_input=False, first_block=1)
@@ -90,5 +89,4 @@ class MMOE(SwrModule):
                                         domain_id)
         desc = ops.make_mix_desc(D, ne, H_, 0, ne * H_, ne, [list(range(ne))] * D)
         pooled = ops.MoeMix.apply(y, desc, y.shape[1])                           # [B, D*H]
-        logits = mlp_bank_forward(list(self.towers), pooled, shared_input=False)  # [B, D]
-        return ops.domain_select(logits, domain_id, apply_sigmoid=True)
+        return mlp_bank_select(list(self.towers), pooled, domain_id)              # towers [B, D] -> sigmoid -> select

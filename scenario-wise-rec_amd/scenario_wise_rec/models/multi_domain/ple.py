@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...basic.layers import MLP, EmbeddingLayer, LayerBank, mlp_bank_forward, mlp_bank_groups
+from ...basic.layers import MLP, EmbeddingLayer, LayerBank, mlp_bank_forward, mlp_bank_groups, mlp_bank_select
 from ...basic.module import SwrModule
 
 
@@ -42,8 +42,7 @@ class PLE(SwrModule):
             os_ = route.rows(outs)
             return ops.routed_probs(route, [self.towers[d](route.segment(os_, d)[:, d * H_:(d + 1) * H_]) if route.count(d) else None
                                             for d in range(D)])
-        logits = mlp_bank_forward(list(self.towers), outs[:, :D * H_], shared_input=False)      # [B, D]
-        return ops.domain_select(logits, domain_id, apply_sigmoid=True)
+        return mlp_bank_select(list(self.towers), outs[:, :D * H_], domain_id)                  # towers [B, D] -> select
 
 
 class CGC(SwrModule):

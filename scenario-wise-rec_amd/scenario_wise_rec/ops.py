@@ -1056,6 +1056,100 @@ def linear_bn_act(x, weights, biases, bn=None, acts=None, groups=1, training=Tru
     return LinearBNAct.apply(cfg, x, *params)
 
 
+def _tower_forward_linear(cfg, x, params):
+    """First tower layer + its BatchNorm statistics (swr_tower_fwd_linear, swr_bn_finalize); returns the launch arguments
+    with scale / shift / w2 / b2 filled in for the head kernel, and the tensors the backward needs."""
+    G = cfg["groups"]
+    W1s, b1s, gammas, betas, w2s, b2s = (params[i * G:(i + 1) * G] for i in range(6))
+    H.require_device(x, W1s[0])
+    x = H.f32c(x)
+    M = x.shape[0]
+    Hd, K = W1s[0].shape
+    N = G * Hd
+    dev = x.device
+    if M < 2:
+        raise ValueError("Expected more than 1 value per channel when training")   # torch's message
+    W1, b1 = _cat_params(W1s), _cat_params(b1s)
+    gamma, beta = _cat_params(gammas), _cat_params(betas)
+    w2, b2 = _cat_params([w.reshape(-1) for w in w2s]), _cat_params(b2s)
+    Z1 = torch.empty((M, N), dtype=torch.float32, device=dev)
+    n_tiles = (M + 31) // 32
+    partials = torch.empty((n_tiles, N, 2), dtype=torch.float32, device=dev)
+    a = H.TowerArgs()
+    a.M, a.G, a.K, a.H = M, G, K, Hd
+    a.X, a.ldx = x.data_ptr(), x.stride(0)
+    a.W1, a.b1 = W1.data_ptr(), b1.data_ptr()
+    a.Z1, a.ldz = Z1.data_ptr(), N
+    a.stat_partials = partials.data_ptr()
+    H.check(lib.swr_tower_fwd_linear(C.byref(a), H.stream()), "swr_tower_fwd_linear")
+    mean, rstd, scale, shift = _bn_train_finalize(cfg["bn"], gamma, beta, partials, n_tiles, M, N, dev)
+    a.scale, a.shift = scale.data_ptr(), shift.data_ptr()
+    a.w2, a.b2 = w2.data_ptr(), b2.data_ptr()
+    return a, (M, G, K, Hd), (x, W1, Z1, mean, rstd, scale, shift, gamma, w2), b2
+
+
+def _tower_backward(ctx, saved, dV=None, sel=None):
+    """swr_tower_bwd + the grouped weight-gradient product of the first layer.  `dV` [M, G], or `sel` = (domain, y, p, dloss):
+    the gradient implied by the fused select + BCE, computed inside the kernels (include/swr.h "selected mode")."""
+    x, W1, Z1, mean, rstd, scale, shift, gamma, w2 = saved
+    M, G, K, Hd = ctx.dims
+    N = G * Hd
+    dev = x.device
+    p_W1, p_b1, p_g, p_be, p_w2, p_b2 = (ctx.params[i * G:(i + 1) * G] for i in range(6))
+    dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_be, 2)
+    dw2, db2 = _grad_alias(p_w2), _grad_alias(p_b2)
+    direct = all(t is not None for t in (dgamma, dbeta, dw2, db2))
+    if not direct:
+        dgamma, dbeta, dw2 = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+        db2 = torch.empty(G, dtype=torch.float32, device=dev)
+    ca, cb, cc = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+    dZ1 = torch.empty((M, N), dtype=torch.float32, device=dev)
+    need_dx = ctx.needs_input_grad[1]
+    dx = torch.empty((M, G * K), dtype=torch.float32, device=dev) if need_dx else None
+    a = H.TowerArgs()
+    a.M, a.G, a.K, a.H, a.accumulate = M, G, K, Hd, int(direct)
+    a.W1 = W1.data_ptr()
+    a.Z1, a.ldz = Z1.data_ptr(), N
+    a.scale, a.shift, a.mean, a.rstd, a.gamma = (t.data_ptr() for t in (scale, shift, mean, rstd, gamma))
+    a.w2 = w2.data_ptr()
+    if dV is not None:
+        a.dV, a.lddv = dV.data_ptr(), G
+    else:
+        domain, y, p, dloss = sel
+        a.sel_domain, a.sel_dom_dtype = domain.data_ptr(), H.dtype_code(domain)
+        a.sel_y, a.sel_y_dtype = y.data_ptr(), H.dtype_code(y)
+        a.sel_p, a.sel_dloss = p.data_ptr(), dloss.data_ptr()
+    a.ca, a.cb, a.cc = ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
+    a.dgamma, a.dbeta, a.dw2, a.db2 = dgamma.data_ptr(), dbeta.data_ptr(), dw2.data_ptr(), db2.data_ptr()
+    a.dZ1, a.lddz = dZ1.data_ptr(), N
+    a.dX, a.lddx = (dx.data_ptr(), G * K) if need_dx else (None, 0)
+    nbytes = lib.swr_tower_bwd_workspace_bytes(M, G, Hd)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    H.check(lib.swr_tower_bwd(C.byref(a), H.ptr(ws), nbytes, H.stream()), "swr_tower_bwd")
+    # first-layer weights: the ordinary grouped weight-gradient product on dZ1, x
+    dW1, db1 = _grad_alias(p_W1), _grad_alias(p_b1)
+    direct_w = dW1 is not None and db1 is not None
+    if not direct_w:
+        dW1 = torch.empty((N, K), dtype=torch.float32, device=dev)
+        db1 = torch.empty(N, dtype=torch.float32, device=dev)
+    gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
+            ldc=K)
+    grads = []
+    if direct_w:
+        _mark_touched(p_W1 + p_b1)
+        grads += [None] * (2 * G)
+    else:
+        grads += list(_split_like(dW1, p_W1)) + list(_split_like(db1, p_b1))
+    if direct:
+        _mark_touched(p_g + p_be + p_w2 + p_b2)
+        grads += [None] * (4 * G)
+    else:
+        grads += list(_split_like(dgamma, p_g)) + list(_split_like(dbeta, p_be))
+        grads += [t.reshape(p.shape) for t, p in zip(_split_like(dw2, [w.reshape(-1) for w in p_w2]), p_w2)]
+        grads += list(_split_like(db2, p_b2))
+    return dx, tuple(grads)
+
+
 class TowerHead(Function):
     """G per-domain towers [Linear(K, H) -> BatchNorm1d(H) -> ReLU -> Linear(H, 1)] on their own K-column blocks of x, in
     training mode (batch statistics): mmoe.py:38-41,50-51 with tower_params = {"dims": [H]}.  Three launches forward,
@@ -1065,94 +1159,72 @@ class TowerHead(Function):
 
     @staticmethod
     def forward(ctx, cfg, x, *params):
-        G = cfg["groups"]
-        W1s, b1s, gammas, betas, w2s, b2s = (params[i * G:(i + 1) * G] for i in range(6))
-        H.require_device(x, W1s[0])
-        x = H.f32c(x)
-        M = x.shape[0]
-        Hd, K = W1s[0].shape
-        N = G * Hd
-        dev = x.device
-        if M < 2:
-            raise ValueError("Expected more than 1 value per channel when training")   # torch's message
-        W1, b1 = _cat_params(W1s), _cat_params(b1s)
-        gamma, beta = _cat_params(gammas), _cat_params(betas)
-        w2, b2 = _cat_params([w.reshape(-1) for w in w2s]), _cat_params(b2s)
-        Z1 = torch.empty((M, N), dtype=torch.float32, device=dev)
-        n_tiles = (M + 31) // 32
-        partials = torch.empty((n_tiles, N, 2), dtype=torch.float32, device=dev)
-        a = H.TowerArgs()
-        a.M, a.G, a.K, a.H = M, G, K, Hd
-        a.X, a.ldx = x.data_ptr(), x.stride(0)
-        a.W1, a.b1 = W1.data_ptr(), b1.data_ptr()
-        a.Z1, a.ldz = Z1.data_ptr(), N
-        a.stat_partials = partials.data_ptr()
-        H.check(lib.swr_tower_fwd_linear(C.byref(a), H.stream()), "swr_tower_fwd_linear")
-        mean, rstd, scale, shift = _bn_train_finalize(cfg["bn"], gamma, beta, partials, n_tiles, M, N, dev)
-        V = torch.empty((M, G), dtype=torch.float32, device=dev)
-        a.scale, a.shift = scale.data_ptr(), shift.data_ptr()
-        a.w2, a.b2 = w2.data_ptr(), b2.data_ptr()
+        a, dims, saved, _b2 = _tower_forward_linear(cfg, x, params)
+        M, G = dims[0], dims[1]
+        V = torch.empty((M, G), dtype=torch.float32, device=saved[0].device)
         a.V, a.ldv = V.data_ptr(), G
         H.check(lib.swr_tower_fwd_head(C.byref(a), H.stream()), "swr_tower_fwd_head")
-        ctx.cfg, ctx.dims, ctx.params = cfg, (M, G, K, Hd), params
-        ctx.save_for_backward(x, W1, Z1, mean, rstd, scale, shift, gamma, w2)
+        ctx.cfg, ctx.dims, ctx.params = cfg, dims, params
+        ctx.save_for_backward(*saved)
         return V
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dV):
-        x, W1, Z1, mean, rstd, scale, shift, gamma, w2 = ctx.saved_tensors
-        M, G, K, Hd = ctx.dims
-        N = G * Hd
-        dev = x.device
-        p_W1, p_b1, p_g, p_be, p_w2, p_b2 = (ctx.params[i * G:(i + 1) * G] for i in range(6))
-        dV = H.f32c(dV).contiguous()
-        dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_be, 2)
-        dw2, db2 = _grad_alias(p_w2), _grad_alias(p_b2)
-        direct = all(t is not None for t in (dgamma, dbeta, dw2, db2))
-        if not direct:
-            dgamma, dbeta, dw2 = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
-            db2 = torch.empty(G, dtype=torch.float32, device=dev)
-        ca, cb, cc = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
-        dZ1 = torch.empty((M, N), dtype=torch.float32, device=dev)
-        need_dx = ctx.needs_input_grad[1]
-        dx = torch.empty((M, G * K), dtype=torch.float32, device=dev) if need_dx else None
-        a = H.TowerArgs()
-        a.M, a.G, a.K, a.H, a.accumulate = M, G, K, Hd, int(direct)
-        a.W1 = W1.data_ptr()
-        a.Z1, a.ldz = Z1.data_ptr(), N
-        a.scale, a.shift, a.mean, a.rstd, a.gamma = (t.data_ptr() for t in (scale, shift, mean, rstd, gamma))
-        a.w2 = w2.data_ptr()
-        a.dV, a.lddv = dV.data_ptr(), G
-        a.ca, a.cb, a.cc = ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
-        a.dgamma, a.dbeta, a.dw2, a.db2 = dgamma.data_ptr(), dbeta.data_ptr(), dw2.data_ptr(), db2.data_ptr()
-        a.dZ1, a.lddz = dZ1.data_ptr(), N
-        a.dX, a.lddx = (dx.data_ptr(), G * K) if need_dx else (None, 0)
-        nbytes = lib.swr_tower_bwd_workspace_bytes(M, G, Hd)
+        dx, grads = _tower_backward(ctx, ctx.saved_tensors, dV=H.f32c(dV).contiguous())
+        return (None, dx) + grads
+
+
+class TowerHeadSelectBCE(Function):
+    """TowerHead + sigmoid + domain select (mmoe.py:51-55) + the trainer's mean BCE (ctr_trainer.py:56,70): returns
+    (p [M], loss).  A row evaluates only the output layer of its own domain's tower (swr_tower_head_select_bce_fwd: one
+    launch instead of head + select/BCE), and the backward kernels form dV from (p, y, domain) on the fly (no select/BCE
+    backward launch, no dV).  Same bits as TowerHead -> SelectBCE.  A gradient arriving on p as well (someone used the
+    probabilities) goes through the explicit dV path."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, domain, y, *params):
+        a, dims, saved, b2 = _tower_forward_linear(cfg, x, params)
+        M, G, _K, Hd = dims
+        dev = saved[0].device
+        H.require_device(domain, y)
+        domain, y = domain.contiguous(), y.contiguous()
+        p = torch.empty(M, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        nbytes = lib.swr_bce_workspace_bytes(M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        H.check(lib.swr_tower_bwd(C.byref(a), H.ptr(ws), nbytes, H.stream()), "swr_tower_bwd")
-        # first-layer weights: the ordinary grouped weight-gradient product on dZ1, x
-        dW1, db1 = _grad_alias(p_W1), _grad_alias(p_b1)
-        direct_w = dW1 is not None and db1 is not None
-        if not direct_w:
-            dW1 = torch.empty((N, K), dtype=torch.float32, device=dev)
-            db1 = torch.empty(N, dtype=torch.float32, device=dev)
-        gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
-                ldc=K)
-        grads = []
-        if direct_w:
-            _mark_touched(p_W1 + p_b1)
-            grads += [None] * (2 * G)
+        Z1, scale, shift, w2 = saved[2], saved[5], saved[6], saved[8]
+        H.check(lib.swr_tower_head_select_bce_fwd(H.ptr(Z1), G * Hd, G, Hd, H.ptr(scale), H.ptr(shift), H.ptr(w2), H.ptr(b2),
+                                                  H.ptr(domain), H.dtype_code(domain), H.ptr(y), H.dtype_code(y), M, H.ptr(p),
+                                                  H.ptr(loss), H.ptr(ws), nbytes, H.ptr(H.ticket(dev)), H.stream()),
+                "swr_tower_head_select_bce_fwd")
+        ctx.cfg, ctx.dims, ctx.params = cfg, dims, params
+        ctx.save_for_backward(*saved, p, domain, y)
+        ctx.set_materialize_grads(False)
+        return p, loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp, dloss):
+        saved, (p, domain, y) = ctx.saved_tensors[:-3], ctx.saved_tensors[-3:]
+        M, G = ctx.dims[0], ctx.dims[1]
+        if dloss is None and dp is None:
+            return (None,) * (4 + len(ctx.params))
+        if dloss is None:
+            dloss = torch.zeros((), dtype=torch.float32, device=p.device)
+        dloss = dloss.float().contiguous()
+        if dp is None:
+            dx, grads = _tower_backward(ctx, saved, sel=(domain, y, p, dloss))
         else:
-            grads += list(_split_like(dW1, p_W1)) + list(_split_like(db1, p_b1))
-        if direct:
-            _mark_touched(p_g + p_be + p_w2 + p_b2)
-            grads += [None] * (4 * G)
-        else:
-            grads += list(_split_like(dgamma, p_g)) + list(_split_like(dbeta, p_be))
-            grads += [t.reshape(p.shape) for t, p in zip(_split_like(dw2, [w.reshape(-1) for w in p_w2]), p_w2)]
-            grads += list(_split_like(db2, p_b2))
-        return (None, dx) + tuple(grads)
+            dV = torch.empty((M, G), dtype=torch.float32, device=p.device)
+            H.check(lib.swr_select_bce_bwd(H.ptr(p), H.ptr(y), H.dtype_code(y), G, H.ptr(domain), H.dtype_code(domain), M,
+                                           H.ptr(dloss), H.ptr(dV), G, H.stream()), "swr_select_bce_bwd")
+            extra = torch.empty((M, G), dtype=torch.float32, device=p.device)
+            dp = H.f32c(dp).contiguous()
+            H.check(lib.swr_select_bwd(H.ptr(dp), H.ptr(p), G, H.ptr(domain), H.dtype_code(domain), 1, 0, H.ptr(extra), G,
+                                       None, M, H.stream()), "swr_select_bwd")
+            dx, grads = _tower_backward(ctx, saved, dV=dV + extra)
+        return (None, dx, None, None) + grads
 
 
 def tower_head_supported(K, Hd):
@@ -1163,6 +1235,21 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
     """Functional front-end of TowerHead; `bn` as in linear_bn_act."""
     cfg = {"groups": len(W1s), "bn": {k: bn[k] for k in ("running_mean", "running_var", "nbt", "eps", "momentum")}}
     return TowerHead.apply(cfg, x, *W1s, *b1s, *bn["gamma"], *bn["beta"], *w2s, *b2s)
+
+
+TOWER_SELECT = os.environ.get("SWR_TOWER_SELECT", "1") != "0"
+
+
+def tower_head_select(x, W1s, b1s, bn, w2s, b2s, domain):
+    """`domain_select(tower_head(...), domain)`.  Inside `fused_bce(y)` (the trainer's step) head + select + BCE are one
+    launch (TowerHeadSelectBCE) and the selected probabilities come back with the loss parked on the request."""
+    req = fused_bce._active
+    if TOWER_SELECT and req is not None and req.p is None and req.y.numel() == x.shape[0] and x.shape[0] > 0:
+        cfg = {"groups": len(W1s), "bn": {k: bn[k] for k in ("running_mean", "running_var", "nbt", "eps", "momentum")}}
+        req.p, req.loss = TowerHeadSelectBCE.apply(cfg, x, domain, req.y.reshape(-1), *W1s, *b1s, *bn["gamma"], *bn["beta"],
+                                                   *w2s, *b2s)
+        return req.p
+    return domain_select(tower_head(x, W1s, b1s, bn, w2s, b2s), domain, apply_sigmoid=True)
 
 
 class BatchStandardize(Function):

@@ -899,3 +899,59 @@ def test_gemm_exact_columns_give_the_same_bits(M, N, K, ex):
     assert torch.equal(full, fast)
     bound = 2e-6 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1)
     assert np.all(np.abs(fast.cpu().numpy() - (A.astype(np.float64) @ W.astype(np.float64).T + b)) <= bound)
+
+
+@pytest.mark.parametrize("M,G,K,Hd,ddt,ydt,use_p", [(1000, 5, 32, 16, torch.int64, torch.float32, False),
+                                                      (257, 3, 8, 4, torch.int8, torch.int64, False),
+                                                      (4099, 4, 16, 32, torch.int32, torch.float32, True),
+                                                      (64, 2, 16, 8, torch.int64, torch.float32, False)])
+def test_tower_head_select_bce_is_bitwise_the_three_launch_path(M, G, K, Hd, ddt, ydt, use_p, monkeypatch):
+    """Towers -> sigmoid -> domain select -> mean BCE: the one-launch output layer (own tower per row) with the gradient
+    implied inside the backward kernels (ops.TowerHeadSelectBCE) against TowerHead -> SelectBCE (SWR_TOWER_SELECT off):
+    probabilities, loss, input gradient, every parameter gradient and the running statistics bit for bit -- also with
+    out-of-range domain ids (probability 0, no gradient) and with an extra gradient arriving on the probabilities."""
+    from scenario_wise_rec import ops
+    from scenario_wise_rec.basic.layers import MLP, mlp_bank_select
+    from scenario_wise_rec.basic.module import SwrModule
+
+    class Towers(SwrModule):
+        def __init__(self):
+            super().__init__()
+            self.towers = torch.nn.ModuleList(MLP(K, True, [Hd]) for _ in range(G))
+
+        def forward(self, x, dom):
+            return mlp_bank_select(list(self.towers), x, dom)
+
+    torch.manual_seed(M + G)
+    two, one = Towers(), Towers()
+    for mod in (two, one):
+        mod.to("cuda").train()
+    for p in two.parameters():
+        p.data.add_(0.1 * torch.randn_like(p))
+    one.load_state_dict(two.state_dict())
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x0 = torch.randn(M, G * K, device="cuda", generator=g)
+    dom = torch.randint(-1 if ddt != torch.int64 else 0, G + 1, (M,), device="cuda", generator=g).to(ddt)   # some ids out of range
+    y = (torch.rand(M, device="cuda", generator=g) < 0.3).to(ydt)
+    wp = torch.randn(M, device="cuda", generator=g)
+    res = []
+    for mod, flag in ((two, False), (one, True)):
+        monkeypatch.setattr(ops, "TOWER_SELECT", flag)
+        x = x0.clone().requires_grad_(True)
+        with ops.fused_bce(y) as f:
+            p = mod(x, dom)
+        loss = f.loss_for(p)
+        assert loss is not None
+        total = loss + (p * wp).sum() * 1e-3 if use_p else loss
+        total.backward()
+        res.append((p.detach(), loss.detach(), x.grad, {n: q.grad.clone() for n, q in mod.named_parameters()},
+                    {n: b.clone() for n, b in mod.named_buffers()}))
+    (pa, la, dxa, ga, ba), (pb, lb, dxb, gb, bb) = res
+    assert torch.equal(pa, pb) and torch.equal(la, lb)
+    assert torch.equal(dxa, dxb)
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+    for n in ba:
+        assert torch.equal(ba[n], bb[n]), n
+    oob = (dom.long() < 0) | (dom.long() >= G)
+    assert bool((pb[oob] == 0).all()) and float(lb) > 0
