@@ -181,7 +181,8 @@ SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "2e10"))  # weig
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
-         "epoch": 0}
+         "epoch": 0, "extras_ev": None}
+LATE_SORT_JOIN = os.environ.get("SWR_LATE_SORT_JOIN", "1") != "0"
 
 
 def add_side_job(fn):
@@ -199,7 +200,8 @@ def run_side_jobs():
 def _fork_extras():
     """Inside the forward-time fork, on the side stream: pending one-shot jobs and the transposed copies of the weights
     whose dX product wants W^T (registered by the previous step's backward): launches that would otherwise sit on
-    the critical path of the backward pass."""
+    the critical path of the backward pass.  An event marks their end: the backward pass needs THEM from its first
+    kernel on (zero_grad), the sort that follows on the same stream only when the embedding backward runs."""
     _side["epoch"] += 1
     run_side_jobs()
     for ent in _side["wt"].values():
@@ -208,6 +210,22 @@ def _fork_extras():
         else:
             ent["buf"].copy_(ent["src"].t())
         ent["epoch"] = _side["epoch"]
+    if LATE_SORT_JOIN:
+        _side["extras_ev"] = torch.cuda.Event()
+        _side["extras_ev"].record(torch.cuda.current_stream())
+
+
+def join_side_extras():
+    """Before the backward pass: wait for the one-shot jobs of the forward-time fork (zero_grad, W^T copies), NOT for the
+    sort behind them -- that join is the embedding backward's own (join_side_streams(dw=False) there), where the main stream
+    has work queued; here it is idle and a join on the sort's last kernel costs ~8 us of edge latency."""
+    _flush_deferred()
+    ev = _side.get("extras_ev")
+    if ev is None:
+        join_side_streams()
+        return
+    _side["extras_ev"] = None
+    torch.cuda.current_stream().wait_event(ev)
 
 
 def _transposed_weight(W):

@@ -126,8 +126,9 @@ class CTRTrainer(object):
             y_pred = self.model(x_dict)
             loss = self.criterion(y_pred, y)
         ops.run_side_jobs()          # zero_grad, unless the fork already ran it
-        ops.join_side_streams()      # work forked during the forward pass (embedding sort, W^T copies): joined here,
-        loss.backward(gradient=self._one(loss))     # where the main stream still has the whole backward queued behind
+        ops.join_side_extras()       # zero_grad / W^T copies forked during the forward pass: needed from the first backward
+        loss.backward(gradient=self._one(loss))     # kernel on; the sort behind them is joined by the embedding backward
+        ops.join_side_streams()      # (no-op unless no embedding backward ran: nothing forked outlives the step)
         return loss
 
     def train_step(self, x_dict, y):
