@@ -418,9 +418,14 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         dZ, A = nxt()
         ops.gemm_tn(dZ, A, dW, B, n1, kf, colsum=db)
 
+    # the one-hot columns of A' are bf16-exact: the forward kernel issues 3 products instead of 6 for whole pairs of
+    # 32-column chunks behind `a_exact_from` (include/swr.h), as the model's own launch does
+    ex_from = info.Kp if (folded and ops.EXACT_ONEHOT) else 0
+    k_half = max(0, kf - (ex_from + 63) // 64 * 64) if ex_from > 0 else 0      # columns on the 3-product body
+
     def f_fwd():
         _dZ, A = nxt()
-        ops.gemm("nt", A, Wf, Z, B, n1, kf, bias=bias, stat_partials=parts)
+        ops.gemm("nt", A, Wf, Z, B, n1, kf, bias=bias, stat_partials=parts, a_exact_from=ex_from)
 
     def f_dx():
         dZ, _A = nxt()
@@ -430,14 +435,16 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
     peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
     alg_flops = 2.0 * B * n1 * k0
 
-    def entry(kname, fn, pmc_name, k_exec, alg):
+    def entry(kname, fn, pmc_name, k_exec, alg, k3=0):
+        """k3: columns of the reduction range that take 3 bf16 products instead of 6."""
         ms = time_kernel_events(fn, max(10, iters), stream)
         exe = 2.0 * B * n1 * k_exec
         nbytes = 4.0 * B * (n1 + k_exec)
         tf = alg / (ms * 1e-3) / 1e12
         return {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe, "executed_bytes_per_launch": nbytes,
-                "avg_launch_ms": ms, "mfma_issue_util": (6.0 if x6 else 1.0) * exe / (ms * 1e-3) / 1e12 / peak,
+                "avg_launch_ms": ms,
+                "mfma_issue_util": ((6.0 - 3.0 * k3 / k_exec) if x6 else 1.0) * exe / (ms * 1e-3) / 1e12 / peak,
                 "mfma_dtype": "bf16 x 6 products per fp32 product (3-way operand split, fp32 accumulate)" if x6 else "f32",
                 "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_name),
                 "shape": f"[{B}, {k_exec}] x [{k_exec}, {n1}]" + (" (folded from K = %d)" % k0 if folded and k_exec != n_sel else "")}
@@ -447,7 +454,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
     roof["traffic_unit"] = "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)"
     roof["also"] = {
         "gemm_rows_x6_kernel(forward)": entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd,
-                                              "void gemm_rows_x6_kernel<5", kf, alg_flops),
+                                              "void gemm_rows_x6_kernel<5", kf, alg_flops, k3=k_half),
         # dX is algorithmically [B, 148] x [148, 512]; the small tables' columns are never computed (their gradients
         # come out of the weight-gradient product's one-hot block)
         "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W, columns of the K3 tables only)", f_dx,
