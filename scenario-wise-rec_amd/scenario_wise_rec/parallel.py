@@ -18,11 +18,14 @@ RCCL over xGMI).  Replaces the reference's single-process `torch.nn.DataParallel
   * the optimizer runs replicated.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+AG_AFTER_LAUNCH = os.environ.get("SWR_DP_AG_AFTER_LAUNCH", "1") != "0"
 
 
 def hip_merge_rows(urow, ugrad, vocab):
@@ -325,6 +328,7 @@ class DataParallelStep(object):
         self._graphs = (g1, g1b, g2, xb)
         self._big, self._arena_g = big, arena["g"]
         self._merge_stream = torch.cuda.Stream()
+        self._rows_ready = torch.cuda.Event()
         self.loss = loss
         return self
 
@@ -339,15 +343,26 @@ class DataParallelStep(object):
             self.trainer.optimizer.note_replays(1)
         g1.replay()
         rows = bool(xb["offs"])
-        if rows:                                                                # the row lists leave now ...
-            work = dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group, async_op=True)
-            self._merge_stream.wait_stream(cur)                                 # (after the previous step's readers)
-        g1b.replay()                                                            # ... while the rest of the gradients is computed
-        if rows:
-            # the merge needs only the first all-gather: its own stream, so it too hides behind the gradient products
+        if rows and AG_AFTER_LAUNCH:
+            # the row lists leave now, while the rest of the gradients is computed -- but the collective is ENQUEUED after the
+            # second graph, from the merge stream, ordered behind an event recorded here: issued between the two graph
+            # launches, its stream synchronisation kept the second graph's first kernel waiting ~30 us
+            self._rows_ready.record(cur)
+            g1b.replay()
             with torch.cuda.stream(self._merge_stream):
+                self._merge_stream.wait_event(self._rows_ready)                 # (also: after the previous step's readers)
+                work = dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group, async_op=True)
                 work.wait()
-                self._merge_rows(xb, self._big)
+                self._merge_rows(xb, self._big)                                 # needs only this all-gather: hidden too
+        else:
+            if rows:
+                work = dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group, async_op=True)
+                self._merge_stream.wait_stream(cur)                             # (after the previous step's readers)
+            g1b.replay()
+            if rows:
+                with torch.cuda.stream(self._merge_stream):
+                    work.wait()
+                    self._merge_rows(xb, self._big)
         self._send_dense(xb, self._arena_g, pack=False)
         if rows:
             cur.wait_stream(self._merge_stream)
