@@ -596,23 +596,43 @@ extern "C" int swr_select_bce_bwd(const float* p, const void* y, int y_dtype, in
 // W_b = U H_b V applied as ((h U) H_b) V (hamur.py:175-186 materialises U H_b V per sample instead).  HBM-bound on
 // the k*k floats of H_b per sample.  One wave per sample: H_b and the D rows staged in LDS, lane j owns column j.
 #define RM_WAVES 4
+#define RM_DB 8                         // rows of T per pass: one register per row and lane
+#define RM_KMAX 64                      // k <= 64: lane j owns column j
+// One wave per sample, lane j = column j.  The D rows of T (and of dOut) live in registers, one per row, lane i holding
+// element i; the scalar t[d, i] an FMA needs is a v_readlane of that register (uniform i) -- no LDS round trip, no branch
+// in the inner loops (rows past D are zero registers).  H_b streams straight from global memory (forward: lane j reads
+// h[i, j], consecutive lanes consecutive addresses) or through a wave-private LDS copy (backward, which also walks its
+// rows).  The first version kept T and H_b in LDS and gave every (d, j) its own k-trip dependent loop of two LDS reads per
+// FMA: LDS-latency-bound, 105 us forward / 232 us backward for HAMUR's [32 768, 8, 35] x [35, 35] (160 MB of H_b).
+__device__ __forceinline__ float rm_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_fwd_kernel(const float* __restrict__ T, const float* __restrict__ Hm,
                                                                    float* __restrict__ out, int64_t B, int D, int k) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* h = lds + wave * (k * k + D * k);
-    float* t = h + k * k;
+    const int kk = k * k, dk = D * k;
+    const bool on = lane < k;
+    const int j = on ? lane : 0;
     for (int64_t b = static_cast<int64_t>(blockIdx.x) * RM_WAVES + wave; b < B; b += static_cast<int64_t>(gridDim.x) * RM_WAVES) {
-        for (int q = lane; q < k * k; q += 64) h[q] = Hm[b * k * k + q];
-        for (int q = lane; q < D * k; q += 64) t[q] = T[b * D * k + q];
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < k; j += 64)
-            for (int d = 0; d < D; ++d) {
-                float acc = 0.f;
-                for (int i = 0; i < k; ++i) acc = fmaf(t[d * k + i], h[i * k + j], acc);
-                out[b * D * k + d * k + j] = acc;
+        const float* __restrict__ h = Hm + b * kk + j;
+        for (int d0 = 0; d0 < D; d0 += RM_DB) {
+            float tr[RM_DB], acc[RM_DB];
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u) {
+                tr[u] = (on && d0 + u < D) ? T[b * dk + (d0 + u) * k + lane] : 0.f;
+                acc[u] = 0.f;
             }
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll 5
+            for (int i = 0; i < k; ++i) {
+                const float hv = h[i * k];
+#pragma unroll
+                for (int u = 0; u < RM_DB; ++u) acc[u] = fmaf(rm_bcast(tr[u], i), hv, acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u)
+                if (on && d0 + u < D) out[b * dk + (d0 + u) * k + lane] = acc[u];
+        }
     }
 }
 
@@ -622,51 +642,73 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_bwd_kernel(const float* 
                                                                    float* __restrict__ dHm, int64_t B, int D, int k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* h = lds + wave * (k * k + 2 * D * k);
-    float* t = h + k * k;
-    float* g = t + D * k;
+    const int kk = k * k, dk = D * k;
+    const bool on = lane < k;
+    float* hs = lds + wave * kk;                                  // this wave's H_b (dT only)
     for (int64_t b = static_cast<int64_t>(blockIdx.x) * RM_WAVES + wave; b < B; b += static_cast<int64_t>(gridDim.x) * RM_WAVES) {
-        for (int q = lane; q < k * k; q += 64) h[q] = Hm[b * k * k + q];
-        for (int q = lane; q < D * k; q += 64) {
-            t[q] = T[b * D * k + q];
-            g[q] = dOut[b * D * k + q];
+        if (dT) {
+            const float* __restrict__ src = Hm + b * kk;
+#pragma unroll 5
+            for (int q = lane; q < kk; q += 64) hs[q] = src[q];
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        if (dT)
-            for (int i = lane; i < k; i += 64)
-                for (int d = 0; d < D; ++d) {
-                    float acc = 0.f;
-                    for (int j = 0; j < k; ++j) acc = fmaf(g[d * k + j], h[i * k + j], acc);
-                    dT[b * D * k + d * k + i] = acc;
+        for (int d0 = 0; d0 < D; d0 += RM_DB) {
+            float gr[RM_DB], tr[RM_DB];
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u) {
+                const bool ok = on && d0 + u < D;
+                gr[u] = ok ? dOut[b * dk + (d0 + u) * k + lane] : 0.f;
+                tr[u] = ok ? T[b * dk + (d0 + u) * k + lane] : 0.f;
+            }
+            if (dT) {                                             // lane i: row i of H_b against the rows of dOut
+                float acc[RM_DB];
+#pragma unroll
+                for (int u = 0; u < RM_DB; ++u) acc[u] = 0.f;
+                const float* hrow = hs + (on ? lane : 0) * k;
+#pragma unroll 5
+                for (int jj = 0; jj < k; ++jj) {
+                    const float hv = hrow[jj];
+#pragma unroll
+                    for (int u = 0; u < RM_DB; ++u) acc[u] = fmaf(rm_bcast(gr[u], jj), hv, acc[u]);
                 }
-        if (dHm)
-            for (int j = lane; j < k; j += 64)
+#pragma unroll
+                for (int u = 0; u < RM_DB; ++u)
+                    if (on && d0 + u < D) dT[b * dk + (d0 + u) * k + lane] = acc[u];
+            }
+            if (dHm) {                                            // lane j: column j of dOut (its own registers) against T
+                float* __restrict__ dst = dHm + b * kk + (on ? lane : 0);
+#pragma unroll 5
                 for (int i = 0; i < k; ++i) {
                     float acc = 0.f;
-                    for (int d = 0; d < D; ++d) acc = fmaf(t[d * k + i], g[d * k + j], acc);
-                    dHm[b * k * k + i * k + j] = acc;
+#pragma unroll
+                    for (int u = 0; u < RM_DB; ++u) acc = fmaf(rm_bcast(tr[u], i), gr[u], acc);
+                    if (on) {
+                        if (d0 == 0) dst[i * k] = acc;
+                        else dst[i * k] += acc;                   // D > 8: further passes add (same thread, same address)
+                    }
                 }
-        __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (dT) __builtin_amdgcn_wave_barrier();
     }
 }
 
 extern "C" int swr_rowmat_fwd(const float* T, const float* Hm, float* out, int64_t B, int D, int k, void* stream) {
     SWR_REQUIRE(T && Hm && out && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
-    const size_t lds = static_cast<size_t>(RM_WAVES) * (k * k + D * k) * sizeof(float);
-    SWR_REQUIRE(lds <= 64 * 1024, SWR_ERR_UNSUPPORTED);
+    SWR_REQUIRE(k <= RM_KMAX, SWR_ERR_UNSUPPORTED);
     if (B == 0) return SWR_OK;
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 8192));
-    hipLaunchKernelGGL(rowmat_fwd_kernel, dim3(grid), dim3(RM_WAVES * 64), lds, static_cast<hipStream_t>(stream), T, Hm, out, B, D, k);
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 16384));
+    hipLaunchKernelGGL(rowmat_fwd_kernel, dim3(grid), dim3(RM_WAVES * 64), 0, static_cast<hipStream_t>(stream), T, Hm, out, B, D, k);
     return swr_launch_status();
 }
 
 extern "C" int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm, float* dT, float* dHm, int64_t B, int D,
                               int k, void* stream) {
     SWR_REQUIRE(dOut && T && Hm && (dT || dHm) && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
-    const size_t lds = static_cast<size_t>(RM_WAVES) * (k * k + 2 * D * k) * sizeof(float);
-    SWR_REQUIRE(lds <= 64 * 1024, SWR_ERR_UNSUPPORTED);
+    SWR_REQUIRE(k <= RM_KMAX, SWR_ERR_UNSUPPORTED);
+    const size_t lds = dT ? static_cast<size_t>(RM_WAVES) * k * k * sizeof(float) : 0;
     if (B == 0) return SWR_OK;
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 8192));
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 16384));
     hipLaunchKernelGGL(rowmat_bwd_kernel, dim3(grid), dim3(RM_WAVES * 64), lds, static_cast<hipStream_t>(stream), dOut, T, Hm, dT,
                        dHm, B, D, k);
     return swr_launch_status();

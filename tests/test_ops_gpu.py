@@ -955,3 +955,28 @@ def test_tower_head_select_bce_is_bitwise_the_three_launch_path(M, G, K, Hd, ddt
         assert torch.equal(ba[n], bb[n]), n
     oob = (dom.long() < 0) | (dom.long() >= G)
     assert bool((pb[oob] == 0).all()) and float(lb) > 0
+
+
+@pytest.mark.parametrize("B,D,k,offset", [(4096, 1, 35, 0), (4099, 1, 35, 0), (1000, 3, 8, 0), (513, 2, 35, 1), (3, 1, 5, 0),
+                                          (40000, 1, 35, 0)])
+def test_rowmat_sample_blocks(B, D, k, offset):
+    """swr_rowmat_fwd / _bwd stage four samples per workgroup with 16-byte accesses when the tensors allow it: full and
+    ragged last groups, operands that are NOT 16-byte aligned (views at an odd element offset), more samples than the grid
+    has workgroups; against torch's einsum in fp64."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(B + D + k)
+
+    def view(shape):
+        n = int(np.prod(shape))
+        buf = torch.randn(n + offset, device="cuda", generator=g)
+        return buf[offset:].view(shape).detach()
+
+    T, Hm, dO = view((B, D, k)).requires_grad_(True), view((B, k, k)).requires_grad_(True), view((B, D, k))
+    out = ops.RowMat.apply(T, Hm)
+    out.backward(dO)
+    T64, H64 = T.detach().double().requires_grad_(True), Hm.detach().double().requires_grad_(True)
+    ref = torch.einsum("bdi,bij->bdj", T64, H64)
+    ref.backward(dO.double())
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(T.grad.double(), T64.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(Hm.grad.double(), H64.grad, rtol=1e-5, atol=1e-5)
