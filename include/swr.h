@@ -474,9 +474,11 @@ int swr_add_fwd(const float* A, const float* B, float* C, int64_t n, void* strea
 /* column sums: out[n] (+)= sum_m X[m, n]  (bias gradients of layers without BatchNorm) */
 /* out[b, d, :] = T[b, d, :] @ Hm[b] with a k x k matrix per sample (contiguous [B, D, k] / [B, k, k]): the per-sample
  * middle factor of HAMUR's adapter weights U H_b V (hamur.py:175-186, 344-355), applied as ((h U) H_b) V.
- * bwd: dT[b,d,i] = sum_j dOut[b,d,j] Hm[b,i,j]; dHm[b,i,j] = sum_d T[b,d,i] dOut[b,d,j] (either may be null). */
+ * bwd: dT[b,d,i] = sum_j dOut[b,d,j] Hm[b,i,j]; dHm[b,i,j] (+)= sum_d T[b,d,i] dOut[b,d,j] (either may be null;
+ * accumulate_dhm != 0 adds into dHm: H_b feeds both products of an adapter cell, hamur.py:177,186, and the second
+ * backward adds onto the first instead of leaving two 160 MB gradients for autograd to sum). */
 int swr_rowmat_fwd(const float* T, const float* Hm, float* out, int64_t B, int D, int k, void* stream);
-int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm, float* dT, float* dHm,
+int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm, float* dT, float* dHm, int accumulate_dhm,
                    int64_t B, int D, int k, void* stream);
 size_t swr_colsum_workspace_bytes(int64_t M, int N);
 int swr_colsum(const float* X, int64_t ldx, int64_t M, int N, float* out, int accumulate,

@@ -639,7 +639,7 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_fwd_kernel(const float* 
 // dT[b, d, i] = sum_j dOut[b, d, j] Hm[b, i, j];   dHm[b, i, j] = sum_d T[b, d, i] dOut[b, d, j]
 __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ T,
                                                                    const float* __restrict__ Hm, float* __restrict__ dT,
-                                                                   float* __restrict__ dHm, int64_t B, int D, int k) {
+                                                                   float* __restrict__ dHm, int acc_dhm, int64_t B, int D, int k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = k * k, dk = D * k;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_bwd_kernel(const float* 
 #pragma unroll
                     for (int u = 0; u < RM_DB; ++u) acc = fmaf(rm_bcast(tr[u], i), gr[u], acc);
                     if (on) {
-                        if (d0 == 0) dst[i * k] = acc;
+                        if (d0 == 0 && !acc_dhm) dst[i * k] = acc;
                         else dst[i * k] += acc;                   // D > 8: further passes add (same thread, same address)
                     }
                 }
@@ -702,15 +702,15 @@ extern "C" int swr_rowmat_fwd(const float* T, const float* Hm, float* out, int64
     return swr_launch_status();
 }
 
-extern "C" int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm, float* dT, float* dHm, int64_t B, int D,
-                              int k, void* stream) {
+extern "C" int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm, float* dT, float* dHm, int accumulate_dhm,
+                              int64_t B, int D, int k, void* stream) {
     SWR_REQUIRE(dOut && T && Hm && (dT || dHm) && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
     SWR_REQUIRE(k <= RM_KMAX, SWR_ERR_UNSUPPORTED);
     const size_t lds = dT ? static_cast<size_t>(RM_WAVES) * k * k * sizeof(float) : 0;
     if (B == 0) return SWR_OK;
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 16384));
     hipLaunchKernelGGL(rowmat_bwd_kernel, dim3(grid), dim3(RM_WAVES * 64), lds, static_cast<hipStream_t>(stream), dOut, T, Hm, dT,
-                       dHm, B, D, k);
+                       dHm, accumulate_dhm, B, D, k);
     return swr_launch_status();
 }
 

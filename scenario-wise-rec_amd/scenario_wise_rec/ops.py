@@ -1328,17 +1328,43 @@ class BatchStandardize(Function):
         return dx, None, dgamma, dbeta
 
 
+_rm_pending = []          # per-sample factors whose gradient is still being collected in this backward pass
+
+
+def _rm_check():
+    """End of a backward pass: every shared factor must have handed its collected gradient to autograd."""
+    left = [t for t in _rm_pending if getattr(t, "_swr_rm", None) is not None]
+    del _rm_pending[:]
+    for t in left:
+        t._swr_rm = None
+    if left:
+        raise H.SwrError("RowMat: a per-sample factor feeds several products but not all of them took part in this backward "
+                         "pass -- its gradient was being collected across them (set SWR_ROWMAT_SHARE=0)")
+
+
+ROWMAT_SHARE = os.environ.get("SWR_ROWMAT_SHARE", "1") != "0"
+
+
 class RowMat(Function):
-    """out[b, d, :] = T[b, d, :] @ Hm[b]: the per-sample k x k factor of HAMUR's adapter (hamur.py:175-186)."""
+    """out[b, d, :] = T[b, d, :] @ Hm[b]: the per-sample k x k factor of HAMUR's adapter (hamur.py:175-186).
+
+    The SAME Hm feeds both products of an adapter cell: their backward passes add into ONE gradient buffer
+    (`accumulate_dhm`) and only the last of them hands it to autograd -- the engine would otherwise sum two [B, k, k]
+    tensors with an extra pass (74 us for 160 MB at config 5).  The uses are counted on the Hm object in forward."""
 
     @staticmethod
     def forward(ctx, T, Hm):
         H.require_device(T, Hm)
-        T, Hm = H.f32c(T).contiguous(), H.f32c(Hm).contiguous()
+        Hc = H.f32c(Hm).contiguous()
+        T = H.f32c(T).contiguous()
         B, D, k = T.shape
         out = torch.empty_like(T)
-        H.check(lib.swr_rowmat_fwd(H.ptr(T), H.ptr(Hm), H.ptr(out), B, D, k, H.stream()), "swr_rowmat_fwd")
-        ctx.save_for_backward(T, Hm)
+        H.check(lib.swr_rowmat_fwd(H.ptr(T), H.ptr(Hc), H.ptr(out), B, D, k, H.stream()), "swr_rowmat_fwd")
+        ctx.save_for_backward(T, Hc)
+        ctx.owner = None
+        if ROWMAT_SHARE and Hm.requires_grad:
+            ctx.owner = Hm                                   # the caller's object: the uses are counted on it
+            Hm._swr_rm_uses = getattr(Hm, "_swr_rm_uses", 0) + 1
         return out
 
     @staticmethod
@@ -1348,11 +1374,28 @@ class RowMat(Function):
         B, D, k = T.shape
         dout = H.f32c(dout).contiguous()
         dT = torch.empty_like(T) if ctx.needs_input_grad[0] else None
-        dHm = torch.empty_like(Hm) if ctx.needs_input_grad[1] else None
+        owner = ctx.owner
+        shared = ctx.needs_input_grad[1] and owner is not None and getattr(owner, "_swr_rm_uses", 1) > 1
+        dHm, acc, ret = None, 0, None
+        if shared:
+            st = getattr(owner, "_swr_rm", None)
+            if st is None:
+                st = owner._swr_rm = {"left": owner._swr_rm_uses, "buf": torch.empty_like(Hm)}
+                _rm_pending.append(owner)
+                if len(_rm_pending) == 1:
+                    torch.autograd.Variable._execution_engine.queue_callback(_rm_check)
+            else:
+                acc = 1
+            dHm = st["buf"]
+            st["left"] -= 1
+            if st["left"] == 0:
+                ret, owner._swr_rm = dHm, None
+        elif ctx.needs_input_grad[1]:
+            dHm = ret = torch.empty_like(Hm)
         if dT is not None or dHm is not None:
-            H.check(lib.swr_rowmat_bwd(H.ptr(dout), H.ptr(T), H.ptr(Hm), H.ptr(dT), H.ptr(dHm), B, D, k, H.stream()),
+            H.check(lib.swr_rowmat_bwd(H.ptr(dout), H.ptr(T), H.ptr(Hm), H.ptr(dT), H.ptr(dHm), acc, B, D, k, H.stream()),
                     "swr_rowmat_bwd")
-        return dT, dHm
+        return dT, ret
 
 
 def batch_standardize(x, eps, gamma=None, beta=None):

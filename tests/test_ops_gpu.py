@@ -980,3 +980,36 @@ def test_rowmat_sample_blocks(B, D, k, offset):
     torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(T.grad.double(), T64.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(Hm.grad.double(), H64.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("uses", [2, 3])
+def test_rowmat_shared_factor_collects_its_gradient_in_one_buffer(uses, monkeypatch):
+    """One H_b feeding several RowMat products (HAMUR's adapter cell): the backward passes add into one buffer and the last
+    one hands it to autograd -- the same bits as letting autograd sum the separate gradients; a product left out of the
+    backward pass raises instead of dropping the collected gradient."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(uses)
+    B, D, k = 515, 4, 35
+    Ts = [torch.randn(B, D, k, device="cuda", generator=g) for _ in range(uses)]
+    dOs = [torch.randn(B, D, k, device="cuda", generator=g) for _ in range(uses)]
+    H0 = torch.randn(B, k, k, device="cuda", generator=g)
+    res = []
+    for share in (False, True):
+        monkeypatch.setattr(ops, "ROWMAT_SHARE", share)
+        Hm = H0.clone().requires_grad_(True)
+        Tr = [t.clone().requires_grad_(True) for t in Ts]
+        outs = [ops.RowMat.apply(t, Hm) for t in Tr]
+        torch.autograd.backward(outs, dOs)
+        res.append((Hm.grad.clone(), [t.grad.clone() for t in Tr]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    ref = sum(torch.einsum("bdi,bdj->bij", t.double(), d.double()) for t, d in zip(Ts, dOs))
+    torch.testing.assert_close(res[1][0].double(), ref, rtol=1e-5, atol=1e-5)
+    # second backward pass over a retained graph, and a product that takes no part
+    monkeypatch.setattr(ops, "ROWMAT_SHARE", True)
+    Hm = H0.clone().requires_grad_(True)
+    outs = [ops.RowMat.apply(t, Hm) for t in Ts]
+    with pytest.raises(H.SwrError, match="not all of them"):
+        outs[0].backward(dOs[0])
