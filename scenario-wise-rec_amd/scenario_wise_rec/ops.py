@@ -1337,6 +1337,7 @@ def _rm_check():
     del _rm_pending[:]
     for t in left:
         t._swr_rm = None
+        t._swr_rm_uses = 0
     if left:
         raise H.SwrError("RowMat: a per-sample factor feeds several products but not all of them took part in this backward "
                          "pass -- its gradient was being collected across them (set SWR_ROWMAT_SHARE=0)")
@@ -1390,8 +1391,11 @@ class RowMat(Function):
             st["left"] -= 1
             if st["left"] == 0:
                 ret, owner._swr_rm = dHm, None
+                owner._swr_rm_uses = 0                       # a factor that outlives the step (a leaf) starts over
         elif ctx.needs_input_grad[1]:
             dHm = ret = torch.empty_like(Hm)
+            if owner is not None:
+                owner._swr_rm_uses = 0
         if dT is not None or dHm is not None:
             H.check(lib.swr_rowmat_bwd(H.ptr(dout), H.ptr(T), H.ptr(Hm), H.ptr(dT), H.ptr(dHm), acc, B, D, k, H.stream()),
                     "swr_rowmat_bwd")
