@@ -71,8 +71,9 @@ class MMOE(SwrModule):
                 return mlp_bank_select(list(self.towers), pooled, domain_id)
             y = self._first_bank()(embed_x, self.training)                       # [B, ne*H0 + D*ne]
             if experts[0].n_blocks > 1:
-                ex = mlp_bank_forward(experts, y[:, :ne * h0], shared_input=False, first_block=1)
-                y = torch.cat([ex, y[:, ne * h0:]], dim=1)
+                y_ex, y_gate = ops.split_cols(y, [ne * h0, y.shape[1] - ne * h0])     # (one gradient tensor in the backward)
+                ex = mlp_bank_forward(experts, y_ex, shared_input=False, first_block=1)
+                y = torch.cat([ex, y_gate], dim=1)
         else:
             ex = torch.cat([m(embed_x) for m in experts], dim=1)
             y = torch.cat([ex, mlp_bank_forward(gates, embed_x, shared_input=True)], dim=1)

@@ -106,7 +106,7 @@ class CGC(SwrModule):
         if shared and self._fusable():
             y = self._bank_shared()(x, self.training)                  # [B, nE*H0 | gate columns]
             h0 = ex[0].block(0)[0].out_features
-            xe, g_all = y[:, :nE * h0], y[:, nE * h0:]
+            xe, g_all = ops.split_cols(y, [nE * h0, y.shape[1] - nE * h0])     # (one gradient tensor in the backward)
             if ex[0].n_blocks > 1:
                 xe = mlp_bank_forward(ex, xe, shared_input=False, first_block=1)
                 y = torch.cat([xe, g_all], dim=1)

@@ -94,11 +94,10 @@ class PPNet(SwrModule):
         mlp0, gate0 = self._first_banks()
         hidden = mlp0(gate_in, self.training)                        # [B, D*n_1]
         gh_all = gate0(gate_in, self.training)                       # [B, sum_l D*n_l]
-        off = 0
+        gh_blocks = ops.split_cols(gh_all, [D * dims[l + 1] for l in range(L)])      # one gradient tensor in the backward
         for l in range(L):
             n = dims[l + 1]
-            gh = gh_all[:, off:off + D * n]
-            off += D * n
+            gh = gh_blocks[l]
             gate = LayerBank([t.gate_layers[l].network[2] for t in T], None, ["sigmoid"] * D, grouped=True)(gh, self.training)
             if l > 0:
                 hidden = LayerBank([t.mlp_layers[l].block(0)[0] for t in T], [t.mlp_layers[l].block(0)[1] for t in T],

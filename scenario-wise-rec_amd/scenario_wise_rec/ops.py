@@ -1711,6 +1711,48 @@ class StopGradCols(Function):
         return g, None, None
 
 
+class SplitCols(Function):
+    """Consecutive column blocks of x as views: `x[:, 0:w0], x[:, w0:w0+w1], ...`.  The backward pass writes the blocks'
+    gradients side by side into ONE tensor.  Plain slicing leaves that to autograd, which allocates a zero-filled
+    full-width tensor per block, copies the block's gradient into it and adds the L tensors up: at PPNet's config 6
+    (gate hidden layers of all D*L GateNUs in one [32 768, 1 792] tensor, three blocks) 3 fills + 3 copies + 2 adds of
+    235 MB each, ~0.6 ms of a 4.6 ms step."""
+
+    @staticmethod
+    def forward(ctx, x, *widths):
+        ctx.widths, ctx.meta = widths, (tuple(x.shape), x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        outs, off = [], 0
+        for w in widths:
+            outs.append(x[:, off:off + w])
+            off += w
+        if off > x.shape[1]:
+            raise ValueError("split_cols: the blocks are wider than the tensor")
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        shape, dtype, dev = ctx.meta
+        if all(g is None for g in gs):
+            return (None,) * (1 + len(ctx.widths))
+        out = torch.empty(shape, dtype=dtype, device=dev)
+        off = 0
+        for w, g in zip(ctx.widths, gs):
+            if g is None:
+                out[:, off:off + w].zero_()
+            else:
+                out[:, off:off + w].copy_(g)
+            off += w
+        if off < shape[1]:
+            out[:, off:].zero_()
+        return (out,) + (None,) * len(ctx.widths)
+
+
+def split_cols(x, widths):
+    return SplitCols.apply(x, *[int(w) for w in widths])
+
+
 # =========================================================================== evaluation metrics (SURVEY.md 8 row f2)
 def eval_metrics(prob, label, domain, n_domains):
     """Per-domain and overall log-loss / ROC-AUC ingredients of a prediction run, computed on the device

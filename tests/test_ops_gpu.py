@@ -1013,3 +1013,27 @@ def test_rowmat_shared_factor_collects_its_gradient_in_one_buffer(uses, monkeypa
     outs = [ops.RowMat.apply(t, Hm) for t in Ts]
     with pytest.raises(H.SwrError, match="not all of them"):
         outs[0].backward(dOs[0])
+
+
+def test_split_cols_collects_the_block_gradients_in_one_tensor():
+    """ops.split_cols against plain slicing: same values, same gradient (bitwise: every element has one contributor), also
+    with an unused block and a tail of columns outside the blocks."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x0 = torch.randn(513, 100, device="cuda", generator=g)
+    ws = [24, 40, 16]                                      # 20 columns stay outside
+    w = [torch.randn(513, k, device="cuda", generator=g) for k in ws]
+    res = []
+    for split in (False, True):
+        x = x0.clone().requires_grad_(True)
+        y = x * 2.0
+        if split:
+            a, b, c = ops.split_cols(y, ws)
+        else:
+            a, b, c = y[:, :24], y[:, 24:64], y[:, 64:80]
+        assert a.shape == (513, 24) and c.shape == (513, 16)
+        ((a * w[0]).sum() + (c * w[2]).sum()).backward()   # block b takes no part
+        res.append((a.detach().clone(), c.detach().clone(), x.grad.clone()))
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(u, v)
+    assert bool((res[1][2][:, 24:64] == 0).all()) and bool((res[1][2][:, 80:] == 0).all())
