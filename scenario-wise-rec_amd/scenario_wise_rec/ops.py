@@ -835,6 +835,7 @@ class LinearBNAct(Function):
                                            Ntot, H.stream()), "swr_affine_act_fwd")
         ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
         ctx.grad_cols = getattr(x_in, "_swr_grad_cols", None)
+        ctx.grad_dst = getattr(x_in, "_swr_grad_dst", None) if x.data_ptr() == x_in.data_ptr() else None
         oh = oh_in
         ctx.onehot = oh if (oh is not None and G == 1 and (oh.fold or (x.data_ptr() == x_in.data_ptr()
                                                                         and x.stride(0) == oh.oh_col + oh.oh_width))) else None
@@ -974,7 +975,9 @@ class LinearBNAct(Function):
             dx = _zero_scalar(dev).expand(M, K)
         elif ctx.needs_input_grad[1]:
             if G > 1:
-                dx = torch.empty((M, G * K), dtype=torch.float32, device=dev)
+                dx = _grad_dst_view(ctx.grad_dst, M, G * K, dev)           # a block of a split_cols gradient, or
+                if dx is None:
+                    dx = torch.empty((M, G * K), dtype=torch.float32, device=dev)
                 gemm("nn", dZ, W, dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
             else:
                 dx = torch.empty((M, _pad4(K)), dtype=torch.float32, device=dev)
@@ -1722,9 +1725,14 @@ class SplitCols(Function):
     def forward(ctx, x, *widths):
         ctx.widths, ctx.meta = widths, (tuple(x.shape), x.dtype, x.device)
         ctx.set_materialize_grads(False)
+        # a consuming layer that computes the whole gradient of its block (LinearBNAct) writes it straight into the shared
+        # tensor (`_swr_grad_dst`, picked up through _grad_dst_view): no copy for that block in backward()
+        ctx.box = box = {"buf": None, "shape": tuple(x.shape), "dtype": x.dtype, "device": x.device}
         outs, off = [], 0
         for w in widths:
-            outs.append(x[:, off:off + w])
+            v = x[:, off:off + w]
+            v._swr_grad_dst = (box, off, w)
+            outs.append(v)
             off += w
         if off > x.shape[1]:
             raise ValueError("split_cols: the blocks are wider than the tensor")
@@ -1736,17 +1744,32 @@ class SplitCols(Function):
         shape, dtype, dev = ctx.meta
         if all(g is None for g in gs):
             return (None,) * (1 + len(ctx.widths))
-        out = torch.empty(shape, dtype=dtype, device=dev)
+        out, ctx.box["buf"] = ctx.box["buf"], None
+        if out is None:
+            out = torch.empty(shape, dtype=dtype, device=dev)
         off = 0
         for w, g in zip(ctx.widths, gs):
             if g is None:
                 out[:, off:off + w].zero_()
-            else:
-                out[:, off:off + w].copy_(g)
+            elif not (g.data_ptr() == out.data_ptr() + 4 * off and g.stride(0) == shape[1] and g.stride(1) == 1
+                      and out.dtype == torch.float32):
+                out[:, off:off + w].copy_(g)               # (else: the consumer wrote it in place)
             off += w
         if off < shape[1]:
             out[:, off:].zero_()
         return (out,) + (None,) * len(ctx.widths)
+
+
+def _grad_dst_view(dst, M, width, dev):
+    """The block of a split_cols gradient tensor that belongs to the view a layer consumed, or None."""
+    if dst is None:
+        return None
+    box, off, w = dst
+    if w != width or box["dtype"] != torch.float32 or box["shape"][0] != M or box["shape"][1] % 4 or off % 4:
+        return None
+    if box["buf"] is None:
+        box["buf"] = torch.empty(box["shape"], dtype=torch.float32, device=dev)
+    return box["buf"][:, off:off + w]
 
 
 def split_cols(x, widths):

@@ -1037,3 +1037,29 @@ def test_split_cols_collects_the_block_gradients_in_one_tensor():
     for u, v in zip(res[0], res[1]):
         assert torch.equal(u, v)
     assert bool((res[1][2][:, 24:64] == 0).all()) and bool((res[1][2][:, 80:] == 0).all())
+
+
+def test_split_cols_blocks_written_in_place_by_grouped_layers():
+    """Grouped layers reading split_cols blocks write their input gradient straight into the shared gradient tensor
+    (ops._grad_dst_view): same bits as plain slicing, whose gradients autograd assembles itself."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(13)
+    M, G, K, N = 777, 4, 16, 8
+    widths = [G * K, G * K, 32]
+    x0 = torch.randn(M, sum(widths), device="cuda", generator=g)
+    Ws = [[torch.nn.Parameter(torch.randn(N, K, device="cuda", generator=g) * 0.3) for _ in range(G)] for _ in range(2)]
+    tail_w = torch.randn(M, 32, device="cuda", generator=g)
+    res = []
+    for split in (False, True):
+        x = x0.clone().requires_grad_(True)
+        y = x * 1.5
+        blocks = ops.split_cols(y, widths) if split else (y[:, :G * K], y[:, G * K:2 * G * K], y[:, 2 * G * K:])
+        outs = [ops.linear_bn_act(blocks[i], Ws[i], None, bn=None, acts=("sigmoid" if i else "relu"), groups=G,
+                                  training=True) for i in range(2)]
+        for w_ in Ws[0] + Ws[1]:
+            w_.grad = None
+        (outs[0].sum() + (outs[1] * outs[1]).sum() + (blocks[2] * tail_w).sum()).backward()
+        res.append((x.grad.clone(), [w_.grad.clone() for w_ in Ws[0] + Ws[1]]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
