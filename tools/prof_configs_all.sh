@@ -2,7 +2,7 @@
 # (gpurun_out/<tag>_bench_cfgN.json) and the per-step kernel breakdown (gpurun_out/<tag>_cfgN_per_step.txt)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=${1:-x}; cd $R
-for c in 1 3 4 5 6; do
+for c in ${CONFIGS:-1 3 4 5 6}; do
   timeout 600 python bench.py --config $c --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${T}_bench_cfg$c.json
   rm -rf $O/prof_cfg$c
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_cfg$c -- python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof_cfg$c.log 2>&1
