@@ -223,7 +223,7 @@ def test_grouped_gemm_and_prologue():
     np.testing.assert_allclose(C.cpu().numpy(), want, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("M,N", [(250, 148), (33, 5), (4099, 64)])
+@pytest.mark.parametrize("M,N", [(250, 148), (33, 5), (4099, 64), (300, 1540), (130, 1792)])   # last two: rows wider than 1024 floats
 def test_linear_bn_act_block_vs_oracle(M, N):
     """One [Linear -> BatchNorm1d(train) -> ReLU | softmax] block, forward, running stats and every
     gradient, against the oracle tape in fp64.  Tolerance 2e-5 absolute on O(1) values."""
