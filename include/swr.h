@@ -469,6 +469,9 @@ int swr_select_bce_bwd(const float* p, const void* y, int y_dtype, int D, const 
 int swr_mul_fwd(const float* A, const float* B, float* C, int64_t n, void* stream);
 /* C = A * (scale * B), contiguous [n]: `hidden * gate_out` with the GateNU's gamma folded in (ppnet.py:27, layers.py:318-320) */
 int swr_mul_scale_fwd(const float* A, const float* B, float scale, float* C, int64_t n, void* stream);
+/* its backward in one pass: dA = dC * (scale * B), dB = dC * (scale * A) (the bits of two swr_mul_scale_fwd calls) */
+int swr_mul_scale_bwd(const float* dC, const float* A, const float* B, float scale, float* dA, float* dB, int64_t n,
+                      void* stream);
 /* C = A + B, contiguous [n]: residual connections (hamur.py:197,366 `adapter + h`; m3oe.py:147 `star_mlp(emb) + skip`) */
 int swr_add_fwd(const float* A, const float* B, float* C, int64_t n, void* stream);
 /* column sums: out[n] (+)= sum_m X[m, n]  (bias gradients of layers without BatchNorm) */

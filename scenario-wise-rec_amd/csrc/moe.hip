@@ -775,6 +775,38 @@ extern "C" int swr_mul_scale_fwd(const float* A, const float* B, float scale, fl
     return swr_launch_status();
 }
 
+// backward of C = A * (s * B) in one pass over dC: dA = dC * (s * B), dB = dC * (s * A) (the roundings of two swr_mul_scale_fwd
+// calls; dC is read once, one launch)
+__global__ __launch_bounds__(EW_THREADS) void mul_scale_bwd_kernel(const float* __restrict__ dC, const float* __restrict__ A,
+                                                                   const float* __restrict__ B, float s, float* __restrict__ dA,
+                                                                   float* __restrict__ dB, int64_t n, int vec) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
+    if (vec && 4 * i + 3 < n) {
+        const float4 g = *reinterpret_cast<const float4*>(dC + 4 * i), a = *reinterpret_cast<const float4*>(A + 4 * i),
+                     b = *reinterpret_cast<const float4*>(B + 4 * i);
+        *reinterpret_cast<float4*>(dA + 4 * i) = make_float4(g.x * (b.x * s), g.y * (b.y * s), g.z * (b.z * s), g.w * (b.w * s));
+        *reinterpret_cast<float4*>(dB + 4 * i) = make_float4(g.x * (a.x * s), g.y * (a.y * s), g.z * (a.z * s), g.w * (a.w * s));
+    } else {
+        const int64_t j0 = vec ? 4 * i : i, j1 = vec ? n : min<int64_t>(i + 1, n);
+        for (int64_t j = j0; j < j1; ++j) {
+            const float g = dC[j];
+            dA[j] = g * (B[j] * s);
+            dB[j] = g * (A[j] * s);
+        }
+    }
+}
+
+extern "C" int swr_mul_scale_bwd(const float* dC, const float* A, const float* B, float scale, float* dA, float* dB, int64_t n,
+                                 void* stream) {
+    SWR_REQUIRE(dC && A && B && dA && dB && n >= 0, SWR_ERR_ARG);
+    if (n == 0) return SWR_OK;
+    const int vec = swr_aligned16(dC) && swr_aligned16(A) && swr_aligned16(B) && swr_aligned16(dA) && swr_aligned16(dB);
+    const int64_t items = vec ? swr_ceil_div(n, 4) : n;
+    hipLaunchKernelGGL(mul_scale_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, EW_THREADS))), dim3(EW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), dC, A, B, scale, dA, dB, n, vec);
+    return swr_launch_status();
+}
+
 extern "C" int swr_mul_fwd(const float* A, const float* B, float* C, int64_t n, void* stream) {
     SWR_REQUIRE(A && B && C && n >= 0, SWR_ERR_ARG);
     if (n == 0) return SWR_OK;

@@ -1661,6 +1661,11 @@ class Mul(Function):
         a, b = ctx.saved_tensors
         dc = H.f32c(dc).contiguous()
         da = db = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            da, db = torch.empty_like(a), torch.empty_like(b)
+            H.check(lib.swr_mul_scale_bwd(H.ptr(dc), H.ptr(a), H.ptr(b), ctx.scale, H.ptr(da), H.ptr(db), a.numel(), H.stream()),
+                    "swr_mul_scale_bwd")
+            return da, db, None
         if ctx.needs_input_grad[0]:
             da = torch.empty_like(a)
             H.check(lib.swr_mul_scale_fwd(H.ptr(dc), H.ptr(b), ctx.scale, H.ptr(da), a.numel(), H.stream()), "swr_mul_scale_fwd")

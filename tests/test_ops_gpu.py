@@ -1063,3 +1063,20 @@ def test_split_cols_blocks_written_in_place_by_grouped_layers():
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,offset", [(4099 * 33, 0), (1000, 1), (7, 0)])
+def test_mul_backward_in_one_pass(n, offset):
+    """ops.mul's backward (swr_mul_scale_bwd: both gradients from one pass over dC) against the two products it replaces."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(n)
+    buf = [torch.randn(n + offset, device="cuda", generator=g)[offset:] for _ in range(3)]
+    a, b = buf[0].clone().requires_grad_(True), buf[1].clone().requires_grad_(True)
+    dc, s = buf[2], 1.7
+    ops.mul(a, b, s).backward(dc)
+    assert torch.equal(a.grad, dc * (b.detach() * s)) and torch.equal(b.grad, dc * (a.detach() * s))
+    a2 = buf[0].clone().requires_grad_(True)
+    ops.mul(a2, b.detach(), s).backward(dc)                   # one-sided: the forward kernel on (dC, b)
+    assert torch.equal(a2.grad, a.grad)
+    H.check_errors()
