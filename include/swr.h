@@ -472,6 +472,12 @@ int swr_mul_scale_fwd(const float* A, const float* B, float scale, float* C, int
 /* its backward in one pass: dA = dC * (scale * B), dB = dC * (scale * A) (the bits of two swr_mul_scale_fwd calls) */
 int swr_mul_scale_bwd(const float* dC, const float* A, const float* B, float scale, float* dA, float* dB, int64_t n,
                       void* stream);
+/* C = A * (scale * sigmoid(Z)) and its backward (dA = dC * (scale * y), dZ = ((dC * (scale * A)) * y) * (1 - y)): the output
+ * activation of a GateNU and the gating product without the gate tensor in between (ppnet.py:27, layers.py:318-320); the
+ * bits of swr_affine_act_fwd(sigmoid) + swr_mul_scale_fwd / swr_mul_scale_bwd + swr_act_bwd_apply(sigmoid). */
+int swr_mul_sigmoid_fwd(const float* A, const float* Z, float scale, float* C, int64_t n, void* stream);
+int swr_mul_sigmoid_bwd(const float* dC, const float* A, const float* Z, float scale, float* dA, float* dZ, int64_t n,
+                        void* stream);
 /* C = A + B, contiguous [n]: residual connections (hamur.py:197,366 `adapter + h`; m3oe.py:147 `star_mlp(emb) + skip`) */
 int swr_add_fwd(const float* A, const float* B, float* C, int64_t n, void* stream);
 /* column sums: out[n] (+)= sum_m X[m, n]  (bias gradients of layers without BatchNorm) */

@@ -807,6 +807,65 @@ extern "C" int swr_mul_scale_bwd(const float* dC, const float* A, const float* B
     return swr_launch_status();
 }
 
+// C = A * (s * sigmoid(Z)): a GateNU's output layer activation and the gating product in one pass (ppnet.py:27 with
+// layers.py:318-320: `hidden * (gamma * sigmoid(z))`) -- the sigmoid of swr_affine_act_fwd and the product of
+// swr_mul_scale_fwd, same roundings, without the gate tensor in between.  Backward: dA = dC * (s * y),
+// dZ = ((dC * (s * A)) * y) * (1 - y), y = sigmoid(Z) (swr_mul_scale_bwd followed by the sigmoid rule of swr_act_bwd_apply).
+__global__ __launch_bounds__(EW_THREADS) void mul_sigmoid_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Z, float s,
+                                                                     float* __restrict__ C, int64_t n, int vec) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
+    if (vec && 4 * i + 3 < n) {
+        const float4 a = *reinterpret_cast<const float4*>(A + 4 * i), z = *reinterpret_cast<const float4*>(Z + 4 * i);
+        *reinterpret_cast<float4*>(C + 4 * i) = make_float4(a.x * (swr_sigmoid(z.x) * s), a.y * (swr_sigmoid(z.y) * s),
+                                                            a.z * (swr_sigmoid(z.z) * s), a.w * (swr_sigmoid(z.w) * s));
+    } else {
+        const int64_t j0 = vec ? 4 * i : i, j1 = vec ? n : min<int64_t>(i + 1, n);
+        for (int64_t j = j0; j < j1; ++j) C[j] = A[j] * (swr_sigmoid(Z[j]) * s);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void mul_sigmoid_bwd_kernel(const float* __restrict__ dC, const float* __restrict__ A,
+                                                                     const float* __restrict__ Z, float s, float* __restrict__ dA,
+                                                                     float* __restrict__ dZ, int64_t n, int vec) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * EW_THREADS + threadIdx.x;
+    const int64_t j0 = vec ? 4 * i : i, j1 = vec ? min<int64_t>(4 * i + 4, n) : min<int64_t>(i + 1, n);
+    if (vec && 4 * i + 3 < n) {
+        const float4 g = *reinterpret_cast<const float4*>(dC + 4 * i), a = *reinterpret_cast<const float4*>(A + 4 * i),
+                     z = *reinterpret_cast<const float4*>(Z + 4 * i);
+        const float y0 = swr_sigmoid(z.x), y1 = swr_sigmoid(z.y), y2 = swr_sigmoid(z.z), y3 = swr_sigmoid(z.w);
+        *reinterpret_cast<float4*>(dA + 4 * i) = make_float4(g.x * (y0 * s), g.y * (y1 * s), g.z * (y2 * s), g.w * (y3 * s));
+        *reinterpret_cast<float4*>(dZ + 4 * i) = make_float4((g.x * (a.x * s)) * y0 * (1.f - y0), (g.y * (a.y * s)) * y1 * (1.f - y1),
+                                                             (g.z * (a.z * s)) * y2 * (1.f - y2), (g.w * (a.w * s)) * y3 * (1.f - y3));
+    } else {
+        for (int64_t j = j0; j < j1; ++j) {
+            const float y = swr_sigmoid(Z[j]), g = dC[j];
+            dA[j] = g * (y * s);
+            dZ[j] = (g * (A[j] * s)) * y * (1.f - y);
+        }
+    }
+}
+
+extern "C" int swr_mul_sigmoid_fwd(const float* A, const float* Z, float scale, float* C, int64_t n, void* stream) {
+    SWR_REQUIRE(A && Z && C && n >= 0, SWR_ERR_ARG);
+    if (n == 0) return SWR_OK;
+    const int vec = swr_aligned16(A) && swr_aligned16(Z) && swr_aligned16(C);
+    const int64_t items = vec ? swr_ceil_div(n, 4) : n;
+    hipLaunchKernelGGL(mul_sigmoid_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, EW_THREADS))), dim3(EW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), A, Z, scale, C, n, vec);
+    return swr_launch_status();
+}
+
+extern "C" int swr_mul_sigmoid_bwd(const float* dC, const float* A, const float* Z, float scale, float* dA, float* dZ, int64_t n,
+                                   void* stream) {
+    SWR_REQUIRE(dC && A && Z && dA && dZ && n >= 0, SWR_ERR_ARG);
+    if (n == 0) return SWR_OK;
+    const int vec = swr_aligned16(dC) && swr_aligned16(A) && swr_aligned16(Z) && swr_aligned16(dA) && swr_aligned16(dZ);
+    const int64_t items = vec ? swr_ceil_div(n, 4) : n;
+    hipLaunchKernelGGL(mul_sigmoid_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, EW_THREADS))), dim3(EW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), dC, A, Z, scale, dA, dZ, n, vec);
+    return swr_launch_status();
+}
+
 extern "C" int swr_mul_fwd(const float* A, const float* B, float* C, int64_t n, void* stream) {
     SWR_REQUIRE(A && B && C && n >= 0, SWR_ERR_ARG);
     if (n == 0) return SWR_OK;

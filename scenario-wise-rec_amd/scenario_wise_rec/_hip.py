@@ -224,6 +224,8 @@ _SIGS = {
     "swr_mul_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "swr_mul_scale_fwd": (C.c_int, [_P, _P, _F, _P, _L, _P]),
     "swr_mul_scale_bwd": (C.c_int, [_P, _P, _P, _F, _P, _P, _L, _P]),
+    "swr_mul_sigmoid_fwd": (C.c_int, [_P, _P, _F, _P, _L, _P]),
+    "swr_mul_sigmoid_bwd": (C.c_int, [_P, _P, _P, _F, _P, _P, _L, _P]),
     "swr_add_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "swr_colsum_workspace_bytes": (_Z, [_L, _I]),
     "swr_colsum": (C.c_int, [_P, _L, _L, _I, _P, _I, _P, _Z, _P]),

@@ -98,10 +98,10 @@ class PPNet(SwrModule):
         for l in range(L):
             n = dims[l + 1]
             gh = gh_blocks[l]
-            gate = LayerBank([t.gate_layers[l].network[2] for t in T], None, ["sigmoid"] * D, grouped=True)(gh, self.training)
+            gate_z = LayerBank([t.gate_layers[l].network[2] for t in T], None, [None] * D, grouped=True)(gh, self.training)
             if l > 0:
                 hidden = LayerBank([t.mlp_layers[l].block(0)[0] for t in T], [t.mlp_layers[l].block(0)[1] for t in T],
                                    ["relu"] * D, grouped=True)(hidden, self.training)
-            hidden = ops.mul(hidden, gate, T[0].gate_layers[l].gemma)      # gamma * sigmoid folded into the product
+            hidden = ops.mul_sigmoid(hidden, gate_z, T[0].gate_layers[l].gemma)      # hidden * (gamma * sigmoid(z)), one pass
         logits = LayerBank([t.final_layer for t in T], None, [None] * D, grouped=True)(hidden, self.training)   # [B, D]
         return ops.domain_select(logits, domain_id, apply_sigmoid=True)

@@ -1679,6 +1679,35 @@ def mul(a, b, scale=1.0):
     return Mul.apply(a, b, float(scale))
 
 
+class MulSigmoid(Function):
+    """c = a * (scale * sigmoid(z)): the sigmoid of a GateNU's output layer and the gating product in one pass each way
+    (ppnet.py:27: `hidden * gate_out`, layers.py:318-320: `gamma * sigmoid(.)`); the gate tensor is never stored."""
+
+    @staticmethod
+    def forward(ctx, a, z, scale):
+        H.require_device(a, z)
+        a, z = H.f32c(a).contiguous(), H.f32c(z).contiguous()
+        c = torch.empty_like(a)
+        H.check(lib.swr_mul_sigmoid_fwd(H.ptr(a), H.ptr(z), scale, H.ptr(c), a.numel(), H.stream()), "swr_mul_sigmoid_fwd")
+        ctx.save_for_backward(a, z)
+        ctx.scale = scale
+        return c
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dc):
+        a, z = ctx.saved_tensors
+        dc = H.f32c(dc).contiguous()
+        da, dz = torch.empty_like(a), torch.empty_like(z)
+        H.check(lib.swr_mul_sigmoid_bwd(H.ptr(dc), H.ptr(a), H.ptr(z), ctx.scale, H.ptr(da), H.ptr(dz), a.numel(), H.stream()),
+                "swr_mul_sigmoid_bwd")
+        return da, dz, None
+
+
+def mul_sigmoid(a, z, scale=1.0):
+    return MulSigmoid.apply(a, z, float(scale))
+
+
 class Add(Function):
     """c = a + b of two equally shaped tensors (residual connections); the backward passes the gradient to both."""
 

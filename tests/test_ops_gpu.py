@@ -1080,3 +1080,22 @@ def test_mul_backward_in_one_pass(n, offset):
     ops.mul(a2, b.detach(), s).backward(dc)                   # one-sided: the forward kernel on (dC, b)
     assert torch.equal(a2.grad, a.grad)
     H.check_errors()
+
+
+@pytest.mark.parametrize("n,offset", [(4099 * 17, 0), (1001, 1), (5, 0)])
+def test_mul_sigmoid_against_torch(n, offset):
+    """ops.mul_sigmoid (GateNU sigmoid + gating product in one pass each way) against torch in fp64."""
+    from scenario_wise_rec import ops
+    g = torch.Generator(device="cuda").manual_seed(n + 3)
+    buf = [torch.randn(n + offset, device="cuda", generator=g)[offset:] * 3 for _ in range(3)]
+    a, z = buf[0].clone().requires_grad_(True), buf[1].clone().requires_grad_(True)
+    dc, s = buf[2], 2.0
+    c = ops.mul_sigmoid(a, z, s)
+    c.backward(dc)
+    a64, z64 = a.detach().double().requires_grad_(True), z.detach().double().requires_grad_(True)
+    ref = a64 * (s * torch.sigmoid(z64))
+    ref.backward(dc.double())
+    torch.testing.assert_close(c.double(), ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(a.grad.double(), a64.grad, rtol=1e-6, atol=1e-6)
+    # (1 - y) is formed in fp32 from y, as in the two-kernel path and in torch's own sigmoid backward: absolute, not relative
+    torch.testing.assert_close(z.grad.double(), z64.grad, rtol=0, atol=2e-6 * float(z64.grad.abs().max()) + 1e-7)
