@@ -251,6 +251,10 @@ typedef struct {
     int32_t a_exact_from;  /* 0 = none: columns k >= a_exact_from of A hold values that are exactly representable in bf16
                               (the one-hot block of a folded first layer: 0 / 1).  The bf16-split kernel then issues
                               three products instead of six for those k and skips their split; same bits either way */
+    int32_t c_act;         /* nt / nn: 0 none, 1 ReLU, 2 sigmoid applied to (product + bias) as C is stored -- the activation of a
+                              layer without BatchNorm (GateNU, layers.py:314-320) without a pass of its own; not with
+                              `accumulate` or `stat_partials` */
+    int32_t pad1;
 } swr_gemm_args;
 
 int swr_gemm_nt(const swr_gemm_args* args_host, void* stream);

@@ -51,6 +51,11 @@ __device__ __forceinline__ float4 load_k4(const float* __restrict__ row, int k, 
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 // epilogue shared by the row-parallel kernels: lane (i, s) holds column n0 + 32t + i, rows m0 + (r & 3) + 8 (r >> 2) + 4 s
+// c_act (swr.h): the activation of a layer WITHOUT BatchNorm applied while C is stored (1 ReLU, 2 sigmoid)
+__device__ __forceinline__ float epi_act(int act, float v) {
+    return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? swr_sigmoid(v) : v);
+}
+
 template <int NT>
 __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tiles_m, f32x16 (&acc)[NT], int g, int64_t tile_m,
                                               int64_t m0, int n0, int i, int s) {
@@ -71,7 +76,7 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
             float* __restrict__ tile_base = Cg + m0 * a.ldc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[t][r] + bn;
+                const float v = epi_act(a.c_act, acc[t][r] + bn);
                 (tile_base + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * a.ldc)[lane_off] = v;
                 sum += v;
                 acc[t][r] = v;
@@ -80,7 +85,7 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-                float v = acc[t][r] + bn;
+                float v = epi_act(a.c_act, acc[t][r] + bn);
                 const bool ok = row < nvalid && n < N;
                 if (ok) {
                     float* c = Cg + (m0 + row) * a.ldc + n;
@@ -703,6 +708,7 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     SWR_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0 && a.A && a.B && a.C && a.groups >= 1, SWR_ERR_ARG);
     SWR_REQUIRE(a.lda >= a.K && a.ldc >= a.N && a.ldb >= (BT ? a.K : a.N), SWR_ERR_ARG);
     SWR_REQUIRE((a.a_scale == nullptr) == (a.a_shift == nullptr), SWR_ERR_ARG);
+    SWR_REQUIRE(a.c_act >= 0 && a.c_act <= 2 && (a.c_act == 0 || (!a.accumulate && !a.stat_partials)), SWR_ERR_ARG);
     if (a.M == 0) return SWR_OK;
     GemmK kk;
     kk.a = a;

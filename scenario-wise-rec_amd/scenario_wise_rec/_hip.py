@@ -71,7 +71,7 @@ class GemmArgs(C.Structure):
                 ("accumulate", C.c_int32), ("stat_partials", C.c_void_p), ("groups", C.c_int32),
                 ("gsA", C.c_int64), ("gsB", C.c_int64), ("gsC", C.c_int64), ("gsBias", C.c_int64),
                 ("gsScale", C.c_int64), ("B_split", C.c_void_p), ("ld_split", C.c_int64), ("plane_stride", C.c_int64),
-                ("n_compute", C.c_int32), ("a_exact_from", C.c_int32)]
+                ("n_compute", C.c_int32), ("a_exact_from", C.c_int32), ("c_act", C.c_int32), ("pad1", C.c_int32)]
 
 
 class GemmTnArgs(C.Structure):

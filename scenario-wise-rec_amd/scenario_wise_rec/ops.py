@@ -26,12 +26,13 @@ def _ld(t):
 
 def gemm(kind, A, B, C_out, M, N, K, bias=None, a_scale=None, a_shift=None, a_relu=False, accumulate=False,
          stat_partials=None, groups=1, gsA=0, gsB=0, gsC=0, gsBias=0, gsScale=0, lda=None, ldb=None, ldc=None,
-         B_split=None, n_compute=0, a_exact_from=0):
+         B_split=None, n_compute=0, a_exact_from=0, c_act=0):
     """kind 'nt': C[m,n] = sum_k A[m,k] B[n,k];  'nn': C[m,n] = sum_k A[m,k] B[k,n].
     B_split: (planes, ld, plane_stride) from split_weights -- B already split into bf16 planes ('nt', one group).
     a_exact_from: columns k >= this of A hold bf16-exact values (0 / 1 of a one-hot block): half the products there."""
     a = H.GemmArgs()
     a.a_exact_from = int(a_exact_from)
+    a.c_act = int(c_act)                # 1 ReLU / 2 sigmoid applied as C is stored (layers without BatchNorm)
     if B_split is not None:
         a.B_split, a.ld_split, a.plane_stride = B_split[0].data_ptr(), B_split[1], B_split[2]
     a.M, a.N, a.K = M, N, K
@@ -182,6 +183,7 @@ _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
          "epoch": 0, "extras_ev": None}
+EPILOGUE_ACT = os.environ.get("SWR_EPILOGUE_ACT", "1") != "0"
 LATE_SORT_JOIN = os.environ.get("SWR_LATE_SORT_JOIN", "1") != "0"
 
 
@@ -794,9 +796,19 @@ class LinearBNAct(Function):
                     "swr_fold_first_layer_fwd")
             gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp if EXACT_ONEHOT else 0)
             planes_t = None
+            epi_act = 0
         else:
+            # a layer without BatchNorm whose columns all take the same ReLU / sigmoid: applied while the product is stored
+            na = _norm_acts(cfg["acts"], Ntot)
+            epi_act = 0
+            if (EPILOGUE_ACT and cfg["bn"] is None and na and na[0][2] in ("relu", "sigmoid")
+                    and all(r[2] == na[0][2] for r in na)
+                    and sorted((r[0], r[1]) for r in na)[0][0] == 0
+                    and all(a_[1] == b_[0] for a_, b_ in zip(sorted((r[0], r[1]) for r in na), sorted((r[0], r[1]) for r in na)[1:]))
+                    and max(r[1] for r in na) == Ntot):
+                epi_act = 1 if na[0][2] == "relu" else 2
             gemm("nt", x, W, Z, M, N, K, bias=b, stat_partials=partials, groups=G,
-                 gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N, B_split=planes)
+                 gsA=(K if G > 1 else 0), gsB=N * K, gsC=N, gsBias=N, B_split=planes, c_act=epi_act)
         ctx.planes_t = planes_t
         acts, n_acts = H.act_ranges(cfg["acts"], Ntot)
         mean = rstd = scale = shift = None
@@ -827,8 +839,8 @@ class LinearBNAct(Function):
             gate_p = torch.empty((M, D * ne), dtype=torch.float32, device=dev)     # kept for the backward (tiny)
             a.G = gate_p.data_ptr()
             H.check(lib.swr_bnmix_fwd(C.byref(a), H.stream()), "swr_bnmix_fwd")
-        elif identity:
-            out = Y = Z
+        elif identity or epi_act:
+            out = Y = Z                      # (epi_act: Z already holds the activated values; the backward reads only Y)
         else:
             out = Y = torch.empty_like(Z)
             H.check(lib.swr_affine_act_fwd(H.ptr(Z), Ntot, H.ptr(scale), H.ptr(shift), acts, n_acts, H.ptr(Y), Ntot, M,
