@@ -157,8 +157,11 @@ def _run_plan(plan, weights):
         out._swr_onehot = info
     # columns that can take a gradient: everything up to the end of the last embedding column (dense-feature columns are
     # inputs).  A layer that reads this tensor need not compute d/dx beyond it (ops.LinearBNAct: `n_compute` of dX).
-    out._swr_grad_cols = max([col + dim for _w, _i, _v, dim, col, _s in plan.sparse] +
-                             [b["col"] + b["dim"] * (b["L"] if b["mode"] == 2 else 1) for b in plan.bags], default=0)
+    # (tables looked up detached -- PPNet's agnostic group, ppnet.py:54 -- take none either: at config 6 only the first 128
+    # of the 452 columns do, and the two first-layer dX products skip the rest)
+    out._swr_grad_cols = max([col + dim for w_, _i, _v, dim, col, _s in plan.sparse if weights[w_].requires_grad] +
+                             [b["col"] + b["dim"] * (b["L"] if b["mode"] == 2 else 1) for b in plan.bags
+                              if weights[b["wpos"]].requires_grad], default=0)
     return out
 
 
