@@ -67,7 +67,14 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n0 + 32 * t + i;
-        const float bn = (bias && n < N) ? bias[n] : 0.f;
+        float bn = (bias && n < N) ? bias[n] : 0.f;
+        if (a.c_act) {
+            // (wave-uniform, outside the store loops: with the activation inside them the plain case -- every product of
+            // config 2 -- lost 9 us per step to the epilogue)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = epi_act(a.c_act, acc[t][r] + bn);
+            bn = 0.f;
+        }
         float sum = 0.f;
         if (nvalid == 32 && n0 + 32 * t + 32 <= N && !a.accumulate) {
             // whole tile inside C (wave-uniform test): no per-element predicates; wave-uniform row bases + one 32-bit
@@ -76,7 +83,7 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
             float* __restrict__ tile_base = Cg + m0 * a.ldc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = epi_act(a.c_act, acc[t][r] + bn);
+                const float v = acc[t][r] + bn;
                 (tile_base + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * a.ldc)[lane_off] = v;
                 sum += v;
                 acc[t][r] = v;
@@ -85,7 +92,7 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-                float v = epi_act(a.c_act, acc[t][r] + bn);
+                float v = acc[t][r] + bn;
                 const bool ok = row < nvalid && n < N;
                 if (ok) {
                     float* c = Cg + (m0 + row) * a.ldc + n;
