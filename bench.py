@@ -188,8 +188,8 @@ N_ROTATE = 4      # device-resident batches rotated through the captured step in
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: the configuration's batch PER GPU (default); strong: that batch is the GLOBAL batch, "
