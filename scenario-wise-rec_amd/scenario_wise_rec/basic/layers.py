@@ -374,6 +374,12 @@ class GateNU(SwrModule):
         self.network = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, output_dim),
                                      nn.Sigmoid())
 
+    def logits(self, inputs):
+        """The output layer before its sigmoid: `ops.mul_sigmoid(x, gate.logits(g), gate.gemma)` is `x * gate(g)` in one
+        pass each way (no gate tensor, no scaling pass)."""
+        h = LayerBank([self.network[0]], None, ["relu"])(inputs, self.training)
+        return LayerBank([self.network[2]], None, [None])(h, self.training)
+
     def forward(self, inputs):
         h = LayerBank([self.network[0]], None, ["relu"])(inputs, self.training)
         return LayerBank([self.network[2]], None, ["sigmoid"])(h, self.training) * self.gemma

@@ -31,6 +31,6 @@ class EPNet(SwrModule):
         both = fused_lookup(x, [(self.sce_embedding, self.sce_features), (self.agn_embedding, self.agn_features)])
         agn_x = both[:, self.sce_dims:]
         gate_in = ops.StopGradCols.apply(both, self.sce_dims, self.dims)        # cat(sce_x, agn_x.detach())
-        gated = ops.mul(agn_x, self.gatenu(gate_in))
+        gated = ops.mul_sigmoid(agn_x, self.gatenu.logits(gate_in), self.gatenu.gemma)      # agn_x * (gamma * sigmoid(.))
         out = LayerBank([self.mlp.mlp[0]], None, ["sigmoid"])(gated, self.training)
         return out.squeeze()
