@@ -157,7 +157,9 @@ class M3oE(SwrModule):
         for _ in range(D - 1):
             self._weight_exp_d()
         eye = torch.eye(D, device=e.device, dtype=torch.float32)
-        M = we * (wd * eye + (1.0 - wd) / (D - 1) * (1.0 - eye))                            # [D, D], M[i, j]
+        # (D == 1: the reference's `j != i` loop is empty -- no off-diagonal term, and no division by D - 1 = 0)
+        off = (1.0 - wd) / (D - 1) * (1.0 - eye) if D > 1 else torch.zeros_like(eye)
+        M = we * (wd * eye + off)                                                           # [D, D], M[i, j]
         Wk = torch.kron(M, torch.eye(H_, device=e.device, dtype=torch.float32))            # [D*H, D*H] Linear layout [out, in]
         dom = both[:, ne * H_:]
         fused = ops.add(mixed, ops.linear_bn_act(dom, [Wk], None, bn=None, acts=None, groups=1, training=False))

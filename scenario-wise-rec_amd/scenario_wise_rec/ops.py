@@ -531,6 +531,10 @@ class EmbedGather(Function):
             if lazy is not None:
                 lazy.catchup(idx.reshape(-1) if bag["mode"] == 2 or bag["pad"] is None else
                              torch.where(idx == bag["pad"], torch.full_like(idx, -1), idx).reshape(-1), bag["seed"])
+                if bag["mode"] != 2:
+                    # masked positions reach the backward as (row 0, weight 0): row 0 then sits in the row list the optimizer's
+                    # row kernel marks current, so its pending decay-only steps must be replayed here too (un-hashed row id)
+                    lazy.catchup(_zero_index(dev), 0)
             want = w.requires_grad and getattr(plan, "want_grad", False)
             bkeys = torch.empty(B * bag["L"], dtype=torch.int32, device=dev) if want else None
             bwts = torch.empty(B * bag["L"], dtype=torch.float32, device=dev) if want else None
@@ -1034,6 +1038,14 @@ class LinearBNAct(Function):
 
 
 _ZEROS = {}
+_ZERO_IDX = {}
+
+
+def _zero_index(dev):
+    z = _ZERO_IDX.get(str(dev))
+    if z is None:
+        z = _ZERO_IDX[str(dev)] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return z
 
 
 def _zero_scalar(dev):

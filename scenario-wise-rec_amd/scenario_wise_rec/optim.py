@@ -66,9 +66,18 @@ def catchup_many(items):
     groups = {}
     for lazy, idx, seed in items:
         groups.setdefault((lazy.hist.data_ptr(), lazy.hyper.data_ptr()), []).append((lazy, idx, seed))
-    for members in groups.values():
+    for members_all in groups.values():
+        # a table looked up through several id columns (`shared_with`) enters the multi launch ONCE: two entries with the
+        # same claim / last arrays could both win the ticket of a row (tickets are table-local positions) and replay its
+        # pending steps twice.  The repeats run as ordinary catch-ups behind it (ordered by the stream: exact).
+        members, repeats, seen = [], [], set()
+        for mbr in members_all:
+            (repeats if id(mbr[0]) in seen else members).append(mbr)
+            seen.add(id(mbr[0]))
         if len(members) == 1:
             members[0][0].catchup(members[0][1], members[0][2])
+            for lazy, idx, seed in repeats:
+                lazy.catchup(idx, seed)
             continue
         lazy0 = members[0][0]
         if lazy0.hyper.data_ptr() in _EARLY_ADVANCED:
@@ -89,6 +98,8 @@ def catchup_many(items):
                 off += 2 * max(n, 1)
             H.check(lib.swr_adam_catchup_multi(tabs, len(chunk), H.ptr(lazy0.hist), H.ptr(lazy0.hyper), H.stream()),
                     "swr_adam_catchup_multi")
+        for lazy, idx, seed in repeats:
+            lazy.catchup(idx, seed)
 
 
 class FusedAdam(torch.optim.Optimizer):

@@ -162,7 +162,9 @@ class CTRTrainer(object):
             if self._dp is not None:
                 x_dict, y = self._my_rows(x_dict, y)
             loss = self._step_maybe_graphed(x_dict, y)
-            total_loss = loss if total_loss is None else total_loss + loss
+            # (a replayed step returns its static loss buffer, which the next replay overwrites: the first loss of a log
+            # interval is copied, the sums are new tensors)
+            total_loss = loss.clone() if total_loss is None else total_loss + loss
             if (i + 1) % log_interval == 0:
                 tk0.set_postfix(loss=total_loss.item() / log_interval)      # the only host sync of the loop
                 H.check_errors()
@@ -209,6 +211,7 @@ class CTRTrainer(object):
                     print("Current lr : {}".format(self.optimizer.state_dict()['param_groups'][0]['lr']))
                 self.scheduler.step()
             if val_dataloader:
+                self._sync_running_stats()      # (gpus=[...]) every rank evaluates rank 0's model: one decision for all ranks
                 auc, logloss = self.evaluate(self.model, val_dataloader)
                 print(f'epoch:{epoch_i} | val auc: {auc} | val logloss: {logloss}')
                 if self.early_stopper.stop_training(auc, self.model.state_dict()):
@@ -220,6 +223,21 @@ class CTRTrainer(object):
         state = self.model.state_dict()
         if self._dp is None or self._rank == 0:         # replicas are identical; rank 0's running statistics are the model's
             torch.save(state, os.path.join(self.model_path, name))
+
+    def _sync_running_stats(self):
+        """Data parallel: parameters are replica-identical by construction, BatchNorm running statistics are per shard
+        (nn.DataParallel keeps replica 0's, `ctr_trainer.py:45-47`).  Before anything is DECIDED from an evaluation -- early
+        stopping, the best weights, the checkpoint -- every rank takes rank 0's buffers, so all ranks compute the same
+        validation AUC, leave `fit` in the same epoch (a rank that broke out alone would leave the others waiting in the
+        next epoch's collectives) and keep the same best weights."""
+        if self._dp is None:
+            return
+        import torch.distributed as dist
+        a = self.model.arena() if hasattr(self.model, "arena") else None
+        bufs = [a["b"], a["i"]] if a is not None else [b for b in self.model.buffers()]
+        for b in bufs:
+            if b.numel():
+                dist.broadcast(b, src=0)
 
     def _forward_all(self, model, data_loader, desc, with_domain=False):
         model.eval()

@@ -81,4 +81,4 @@ class GraphedStep(object):
         if hasattr(opt, "note_replays"):
             opt.note_replays(1)            # host step count, scheduler lr, history-ring flush (optim.FusedAdam)
         self.graph.replay()
-        return self.loss
+        return self.loss                   # the STATIC buffer: the next replay overwrites it (keep a `.clone()`, not this)

@@ -47,3 +47,45 @@ def test_lazy_rows_equal_dense_sweep_bitwise(name):
     assert np.array_equal(ev_l, ev_d)
     for k in dense:
         assert np.array_equal(lazy[k], dense[k]), f"{k}: max diff {np.abs(lazy[k].astype(np.float64) - dense[k]).max()}"
+
+
+def test_shared_lazy_table_is_caught_up_once_per_row():
+    """Two large (row-sparse, lazily updated) tables, one of them looked up through TWO id columns (`shared_with`) that hold
+    the same id at the same batch position: the batched catch-up (optim.catchup_many) must replay a row's pending
+    decay-only steps once -- lazy == per-step sweep, bitwise, over steps that leave rows untouched for a while."""
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.basic.module import SwrModule
+    from scenario_wise_rec.models.multi_domain import MMOE
+    from scenario_wise_rec.trainers import CTRTrainer
+
+    def train(lazy):
+        old = SwrModule.dense_table_limit_bytes
+        SwrModule.dense_table_limit_bytes = 1024
+        try:
+            torch.manual_seed(11)
+            feats = [SparseFeature("a", 3000, 16), SparseFeature("b", 2000, 16), SparseFeature("a2", 3000, 16, shared_with="a"),
+                     SparseFeature("small", 7, 16), DenseFeature("d0")]
+            model = MMOE(feats, domain_num=3, n_expert=2, expert_params={"dims": [16]}, tower_params={"dims": [8]})
+            with torch.no_grad():
+                for n, p in model.named_parameters():
+                    if "embed_dict" in n:
+                        p.normal_(0, 0.3)
+            tr = CTRTrainer(model, "shared-lazy", optimizer_params={"lr": 1e-3, "weight_decay": 1e-2, "lazy_rows": lazy}, device="cuda")
+            model.train()
+            rng = np.random.default_rng(3)
+            for step in range(7):
+                B = 256
+                a = rng.integers(0, 3000 if step % 3 else 300, size=B)       # every third step revisits a small set of rows
+                a2 = a.copy()
+                a2[B // 2:] = rng.integers(0, 3000, size=B - B // 2)          # first half: the same id at the same position
+                x = {"a": a, "a2": a2, "b": rng.integers(0, 2000, size=B), "small": rng.integers(0, 7, size=B),
+                     "d0": rng.random(B).astype(np.float32), "domain_indicator": rng.integers(0, 3, size=B)}
+                y = (rng.random(B) < 0.3).astype(np.float32)
+                tr.train_step({k: torch.from_numpy(v).cuda() for k, v in x.items()}, torch.from_numpy(y).cuda())
+            torch.cuda.synchronize()
+            return {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+        finally:
+            SwrModule.dense_table_limit_bytes = old
+    lazy, dense = train(True), train(False)
+    for k in dense:
+        assert np.array_equal(lazy[k], dense[k]), f"{k}: max diff {np.abs(lazy[k].astype(np.float64) - dense[k]).max()}"
