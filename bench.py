@@ -168,7 +168,8 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         port.step(*batches[n % 2])
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n * B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": n * B / dt, "unit": "samples/s", "cores": cores, "cores_tried": sorted(tried), "host_logical_cpus": ncpu,
+            "kind": "port",
             "sample": f"{n} full steps (fwd+BCE+bwd+dense Adam on all {sum(cfg['vocabs'])} table rows) at batch {B} after warm-up: "
                       f"torch-CPU port of the reference step (oracle/torch_port.py) at the fastest of {sorted(tried)} threads "
                       f"({cores}; host has {ncpu} logical CPUs, one step took " + ", ".join(f"{th}: {t:.2f} s" for th, t in sorted(tried.items())) + ")",
@@ -202,11 +203,26 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start one process per GPU ourselves (the driver's form: torch.distributed.run, one rank per GPU over
+        # RCCL) and hand its exit code on -- `--gpus 8` must never quietly measure ONE rank and print n_gpus 1
+        import socket
+        import subprocess
+        backend = os.environ.get("SWR_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (SWR_BENCH_BACKEND=gloo runs the "
+                             f"{args.gpus}-rank code path with the ranks sharing the visible GPUs)")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would claim the wrong number of GPUs")
     # SWR_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (ranks share cuda:0); the driver's
     # multi-GPU runs use the default: backend nccl (= RCCL), one GPU per rank
     backend = os.environ.get("SWR_BENCH_BACKEND", "nccl")

@@ -4,6 +4,11 @@
 //   0. direct     : lookups of SMALL dense-gradient tables (<= DIRECT_MAX_PARTS x 64 KB of accumulators) skip the
 //                   sort: a workgroup owns a span of adjacent lookup columns and a chunk of samples, adds the
 //                   fixed-point gradients into LDS accumulators (ds_add_u64) and flushes the non-zero ones
+//   0'. segsum    : MID-SIZE dense-gradient tables (17 .. 4096 rows, dim a multiple of 8 up to 64) at batches >= 2048 are
+//                   summed on the matrix pipes: dEmb_t = OneHot_t^T dE_t, the one-hot fragment built in registers from
+//                   the keys (0 / 1 are exact in bf16), dE split into three bf16 terms (exact), fp32 accumulation by
+//                   v_mfma_f32_16x16x32_bf16 in a fixed order, per-batch-split partial tables added in split order by
+//                   the finalise launch: deterministic, no atomics, no LDS
 //   1. build_keys : the other entries (row, slot << 24 | sample) written grouped by table (one segment per table)
 //   2. sort       : segmented LSD radix sort of every table segment by row, 8 bits per pass, stable; pass p
 //                   only does work for tables whose row ids need more than 8p bits (others copy through).
@@ -26,6 +31,7 @@
 
 #include "common.h"
 #include "radix_sort.h"
+#include "split3.h"
 
 #define CHUNK_MAX 32     // sorted entries per reduce walker; 8 / 16 when there are few entries
 #define RB_THREADS 256
@@ -61,6 +67,39 @@ struct DirectMeta {
     int64_t B;
 };
 
+// ---- MFMA segment sums (mid-size tables)
+#define SEG_WAVES 4               // the waves of a workgroup take the four quarters of its batch range; summed through LDS
+// 16-row tiles per job: a job has its class's big or small count (tables are padded to the small one), so the main loop
+// has no per-tile conditions.  Accumulators: tiles x column blocks x 4 VGPRs (64 for the big jobs of dim <= 16; wider
+// tables keep one size: their split of dE already feeds 2 / 4 column blocks per tile)
+static inline int seg_tpw_big(int cls) { return cls == 0 ? 16 : (cls == 1 ? 4 : 2); }
+static inline int seg_tpw_small(int cls) { return cls == 2 ? 2 : 4; }
+static inline int seg_jobs(int64_t vocab, int cls, int& n_big, int& rows_pad) {
+    const int small_rows = 16 * seg_tpw_small(cls), big_rows = 16 * seg_tpw_big(cls);
+    rows_pad = static_cast<int>(swr_ceil_div(vocab, small_rows)) * small_rows;
+    n_big = rows_pad / big_rows;
+    return n_big + (rows_pad - n_big * big_rows) / small_rows;
+}
+#define SEG_MAX_JOBS 96
+struct SegJob {
+    int64_t part_off;     // float offset of this lookup's partial tables [split][rows_pad][dim]
+    int32_t slot, col;    // key column / first column in dE
+    int32_t dim, rows_pad;
+    int32_t tile0, tpw;   // first 16-row tile of the job, its number of tiles (the class's big or small count)
+};
+struct SegMeta {
+    SegJob job[SEG_MAX_JOBS];
+    int32_t n_jobs, n_splits;
+    int64_t rows_per_split;   // multiple of 32 * SEG_WAVES
+    int64_t B;
+};
+struct SegFin {               // per table: where the finalise launch finds the partial tables (n == 0: not a segsum table)
+    int64_t off[MAX_SLOTS];
+    int32_t n[MAX_SLOTS];     // lookups of the table x batch splits
+    int32_t stride[MAX_SLOTS];   // rows_pad * dim
+};
+static inline int seg_class(int dim) { return dim <= 16 ? 0 : (dim <= 32 ? 1 : 2); }
+
 struct TableMeta {
     int64_t vocab;
     int64_t acc_off;     // dense: offset (in elements) into the dense accumulator region
@@ -92,12 +131,28 @@ struct HostPlan {
     BwdMeta m;
     SortMeta sm;
     DirectMeta dm;
+    SegMeta sg[3];           // column-block classes: dim <= 16, <= 32, <= 64
+    SegFin sf;
+    int64_t part_elems;      // floats of segsum partial tables
+    size_t off_part;
     int64_t dense_acc_elems;
     int64_t sparse_acc_elems;
     size_t off_k0, off_k1, off_v0, off_v1, off_hist, off_acc_hi, off_acc_lo, total;
     int n_passes;
     int n_chunks;
 };
+
+static bool seg_enabled() {          // SWR_K3_MFMA=0: mid-size tables take the exact fixed-point paths (direct / sorted) instead
+    const char* e = getenv("SWR_K3_MFMA");   // (read per call: tests/test_ops_gpu.py compares the two paths in one process)
+    return !(e && e[0] == '0');
+}
+
+// Largest table that takes the MFMA segment sums.  Their work grows with rows x samples (every 16-row tile multiplies
+// every sample), the fixed-point direct sums' with samples only; measured at batch 65 536, dim 16 (tools/micro/k3_probe.py)
+static int64_t seg_max_rows() {
+    const char* e = getenv("SWR_K3_MFMA_MAX_ROWS");
+    return e ? atoll(e) : 256;
+}
 
 static int bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
     int b = 0;
@@ -143,6 +198,59 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         m.slot_dim[s] = sl.dim;
         if (sl.dim > dim_max) dim_max = sl.dim;
     }
+    // ---- MFMA segment sums: which tables, the (lookup, tile range) jobs and the batch splits
+    bool segsum[MAX_SLOTS] = {false};
+    for (int c = 0; c < 3; ++c) { p.sg[c].n_jobs = 0; p.sg[c].n_splits = 0; p.sg[c].rows_per_split = 0; p.sg[c].B = B; }
+    for (int t = 0; t < MAX_SLOTS; ++t) { p.sf.off[t] = 0; p.sf.n[t] = 0; p.sf.stride[t] = 0; }
+    p.part_elems = 0;
+    if (seg_enabled() && B >= 2048) {        // (the kernel's 32-bit element offsets: B * ld < 2^31 is checked at launch)
+        int n_jobs_all = 0, count_cls[3] = {0, 0, 0};
+        for (int t = 0; t < n_tables; ++t) {
+            if (!seen[t] || m.tab[t].mode == 1) continue;
+            const TableMeta& tm = m.tab[t];
+            if (tm.vocab <= 16 || tm.vocab > seg_max_rows() || tm.dim % 8 != 0 || tm.dim > 64) continue;
+            int uses = 0;
+            for (int s = 0; s < n_slots; ++s) uses += slots[s].table_id == t;
+            const int cls = seg_class(tm.dim);
+            int n_big, rows_pad;
+            const int jobs = seg_jobs(tm.vocab, cls, n_big, rows_pad);
+            if (count_cls[cls] + uses * jobs > SEG_MAX_JOBS) continue;
+            count_cls[cls] += uses * jobs;
+            n_jobs_all += uses * jobs;
+            segsum[t] = true;
+        }
+        if (n_jobs_all > 0) {
+            const char* env = getenv("SWR_K3_MFMA_WGS");
+            const int wgs_target = env ? atoi(env) : 768;              // x 4 waves: three waves per SIMD over the chip
+            int64_t want = std::max<int64_t>(1, wgs_target / n_jobs_all);
+            want = std::min<int64_t>(want, std::max<int64_t>(1, B / (128 * SEG_WAVES)));
+            const int64_t rps = swr_ceil_div(swr_ceil_div(B, want), 32 * SEG_WAVES) * (32 * SEG_WAVES);
+            const int n_splits = static_cast<int>(swr_ceil_div(B, rps));
+            for (int c = 0; c < 3; ++c) { p.sg[c].n_splits = n_splits; p.sg[c].rows_per_split = rps; }
+            int64_t off = 0;
+            for (int t = 0; t < n_tables; ++t) {
+                if (!segsum[t]) continue;
+                const TableMeta& tm = m.tab[t];
+                const int cls = seg_class(tm.dim);
+                int n_big, rows_pad;
+                const int jobs = seg_jobs(tm.vocab, cls, n_big, rows_pad);
+                p.sf.off[t] = off;
+                p.sf.stride[t] = rows_pad * tm.dim;
+                for (int s = 0; s < n_slots; ++s) {
+                    if (slots[s].table_id != t) continue;
+                    for (int j = 0, tile = 0; j < jobs; ++j) {
+                        SegJob& J = p.sg[cls].job[p.sg[cls].n_jobs++];
+                        J.part_off = off; J.slot = s; J.col = slots[s].in_col; J.dim = tm.dim; J.rows_pad = rows_pad;
+                        J.tile0 = tile; J.tpw = j < n_big ? seg_tpw_big(cls) : seg_tpw_small(cls);
+                        tile += J.tpw;
+                    }
+                    off += static_cast<int64_t>(n_splits) * rows_pad * tm.dim;
+                    p.sf.n[t] += n_splits;
+                }
+            }
+            p.part_elems = off;
+        }
+    }
     // ---- direct path: which tables, and the workgroup layout (groups of adjacent lookup columns x sample chunks)
     bool direct[MAX_SLOTS] = {false};
     DirectMeta& dm = p.dm;
@@ -151,7 +259,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     {
         int need_members = 0, need_groups = 0;     // worst case: one group per member
         for (int t = 0; t < n_tables; ++t) {
-            if (!seen[t] || m.tab[t].mode == 1 || m.tab[t].dim > DIRECT_THREADS) continue;
+            if (!seen[t] || segsum[t] || m.tab[t].mode == 1 || m.tab[t].dim > DIRECT_THREADS) continue;
             const int64_t elems = m.tab[t].vocab * m.tab[t].dim;
             if (elems > static_cast<int64_t>(DIRECT_CAP_ELEMS) * DIRECT_MAX_PARTS || m.tab[t].dim > DIRECT_CAP_ELEMS) continue;
             int uses = 0;
@@ -166,7 +274,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     m.n_sorted_slots = 0;
     for (int s = 0; s < n_slots; ++s) {
         const int t = slots[s].table_id;
-        if (direct[t]) continue;
+        if (direct[t] || segsum[t]) continue;
         m.sorted_slot[m.n_sorted_slots++] = static_cast<int16_t>(s);
         m.slot_dst[s] = count[t];                    // offset inside the table segment (segment base added below)
         count[t] += B;
@@ -205,7 +313,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         pos += count[t];
     }
     for (int s = 0; s < n_slots; ++s)
-        if (!direct[slots[s].table_id]) m.slot_dst[s] += m.tab[slots[s].table_id].sorted_off;
+        if (!direct[slots[s].table_id] && !segsum[slots[s].table_id]) m.slot_dst[s] += m.tab[slots[s].table_id].sorted_off;
     // direct groups (needs the accumulator offsets assigned above)
     {
         int open = -1;                               // group still accepting adjacent small lookups
@@ -279,6 +387,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     const size_t ab = align_up(static_cast<size_t>(p.dense_acc_elems * ACC_STRIPES + p.sparse_acc_elems) * 8);
     p.off_acc_hi = off; off += ab;
     p.off_acc_lo = off; off += ab;
+    p.off_part = off; off += align_up(static_cast<size_t>(p.part_elems) * 4);
     p.total = off;
     return SWR_OK;
 }
@@ -435,6 +544,227 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ segsum (MFMA)
+// dEmb_t[v, :] = sum over the samples b with key_t(b) == v of dE[b, cols_t]  =  OneHot_t^T dE_t, a product whose reduction
+// index is the batch.  A wave owns up to TPW 16-row tiles of one table and the batch range of its split; per 32 samples:
+//   * A fragment (16 table rows x 32 samples) of tile r0: lane (i, kq) holds (key[b0 + 8 kq + e] == r0 + i) for e = 0..7,
+//     built from the 8 keys of the lane's sample octet -- nothing is read but the keys;
+//   * B fragment (32 samples x 16 columns): lane (j, kq) holds dE[b0 + 8 kq + e][col + j], split exactly into three bf16
+//     terms; three MFMAs (low term first) accumulate in fp32.
+// |dE| >= 2^20, Inf and NaN contribute nothing and raise the sticky error word, as on the fixed-point paths (and a
+// non-finite value would otherwise poison the other rows of its tile through 0 * Inf).
+// The order of additions is fixed by the code: results are bitwise reproducible and identical on every data-parallel rank.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// one-hot fragment of the tile whose first row is `c` rows behind the lane's reference row: dd[q] holds two 16-bit
+// differences (key - reference row) of consecutive samples; a half that equals c becomes bf16 1.0 (0x3F80), any other 0.
+// Three packed 16-bit VALU per PAIR of samples, no scalar mask registers:  x = dd - c;  ne = min(x, 1);  w = 0x3F80 - 0x3F80 ne.
+// (Inline asm: written as vector arithmetic, hipcc turns the min into compares + selects + byte permutes, 2.5x the work.
+// Packed 16-bit operations issue every ~4.4 cycles per SIMD (tools/micro/valu_rate.hip), a 16x16x32 MFMA every 16: the
+// four pairs of a fragment cost about as much VALU time as its three MFMAs cost matrix time, so the two are interleaved.)
+__device__ __forceinline__ uint32_t seg_onehot2(uint32_t ddq, uint32_t cc, uint32_t one, uint32_t negv, uint32_t posv) {
+    uint32_t x;
+    asm volatile("v_pk_sub_u16 %0, %1, %2\n\t"
+                 "v_pk_min_u16 %0, %0, %3\n\t"
+                 "v_pk_mad_u16 %0, %0, %4, %5"
+                 : "=&v"(x) : "v"(ddq), "s"(cc), "v"(one), "v"(negv), "v"(posv));
+    return x;
+}
+__device__ __forceinline__ bf16x8 seg_onehot8(const u32x4 dd, uint32_t cc, uint32_t one, uint32_t negv, uint32_t posv) {
+    u32x4 w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = seg_onehot2(dd[q], cc, one, negv, posv);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int CB, int TPW>
+__device__ __forceinline__ void seg_body(const SegMeta& sm, const SegJob& J, int split, const uint32_t* __restrict__ keys,
+                                         const float* __restrict__ dE, int64_t ld, float* __restrict__ part, uint32_t* err,
+                                         float* seg_red) {                // seg_red: [SEG_WAVES - 1][TPW * CB * 4][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int i = lane & 15, kq = lane >> 4;
+    // this wave's quarter of the split's batch range, in 32-sample steps
+    const int64_t s_begin = static_cast<int64_t>(split) * sm.rows_per_split;
+    const int64_t quarter = sm.rows_per_split / SEG_WAVES;             // multiple of 32
+    const int64_t b_begin = min(s_begin + wave * quarter, sm.B);
+    const int64_t b_end = min(b_begin + quarter, sm.B);
+    const int n_full = static_cast<int>((b_end - b_begin) / 32);
+    const int rows_tail = static_cast<int>(b_end - b_begin) - 32 * n_full;      // valid rows of the ragged last step (0: none)
+    const uint32_t ld32 = static_cast<uint32_t>(ld);
+    const uint32_t row_ref = static_cast<uint32_t>(16 * J.tile0 + i);
+    // wave-uniform bases (scalar registers) + lane-constant 32-bit offsets: the loads of a step are
+    // `global_load_dword v, v_lane_offset, s[base]` with the step / row advance folded into the scalar base
+    const uint32_t* __restrict__ kp = keys + static_cast<int64_t>(J.slot) * sm.B + b_begin;
+    const float* __restrict__ xp = dE + b_begin * ld + J.col;
+    const uint32_t koff = static_cast<uint32_t>(8 * kq);
+    bool colv[CB];
+    uint32_t coff[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        colv[cb] = 16 * cb + i < J.dim;
+        coff[cb] = static_cast<uint32_t>(8 * kq) * ld32 + (colv[cb] ? 16 * cb + i : 0);
+    }
+
+    f32x4 acc[TPW][CB];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[t][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t amax = 0u;                                            // largest |x| bit pattern seen (range / NaN / Inf check)
+    uint32_t k_one = 0x00010001u, k_neg = 0xC080C080u, k_pos = 0x3F803F80u;      // packed constants of seg_onehot8, in VGPRs
+    asm volatile("" : "+v"(k_one), "+v"(k_neg), "+v"(k_pos));
+
+    // raw loads of a full 32-sample step
+    auto load_step = [&](int step, uint32_t (&k)[8], float (&x)[CB][8]) {
+        const uint32_t* kps = kp + 32 * step;                           // (scalar)
+        const float* xps = xp + static_cast<int64_t>(32 * step) * ld;    // (scalar)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            k[e] = (kps + e)[koff];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) x[cb][e] = (xps + static_cast<int64_t>(e) * ld)[coff[cb]];
+        }
+    };
+    // d: (key - reference row) mod 2^16 per sample, two per dword; v: the gradient values (non-finite / out-of-range -> 0)
+    auto mma_step = [&](const u32x4 dd, const float (&v)[CB][8]) {
+        bf16x8 bh[CB], bm[CB], bl[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) SPLIT3_PAIR(v[cb][e], v[cb][e + 1], bh[cb], bm[cb], bl[cb], e);
+        // software pipeline inside the wave: the pairs of the NEXT tile's one-hot fragment are generated between the three
+        // (dependent) MFMAs of the current tile, so the matrix pipe works while the VALU builds its next operand
+        u32x4 wn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wn[q] = seg_onehot2(dd[q], 0u, k_one, k_neg, k_pos);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wn);
+            const uint32_t cn = static_cast<uint32_t>(16 * (t + 1)) * 0x00010001u;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4 c_ = acc[t][cb];
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl[cb], c_, 0, 0, 0);
+                if (cb == 0 && t + 1 < TPW) { __builtin_amdgcn_sched_barrier(0); wn[0] = seg_onehot2(dd[0], cn, k_one, k_neg, k_pos); __builtin_amdgcn_sched_barrier(0); }
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bm[cb], c_, 0, 0, 0);
+                if (cb == 0 && t + 1 < TPW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    wn[1] = seg_onehot2(dd[1], cn, k_one, k_neg, k_pos);
+                    wn[2] = seg_onehot2(dd[2], cn, k_one, k_neg, k_pos);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[cb], c_, 0, 0, 0);
+                if (cb == 0 && t + 1 < TPW) { __builtin_amdgcn_sched_barrier(0); wn[3] = seg_onehot2(dd[3], cn, k_one, k_neg, k_pos); __builtin_amdgcn_sched_barrier(0); }
+                acc[t][cb] = c_;
+            }
+        }
+    };
+    // |x| >= 2^20, Inf, NaN (exponent field >= 147) contribute nothing; the largest magnitude pattern is kept for the flag
+    auto clean = [&](float xv, bool live) -> float {
+        const uint32_t ab = __float_as_uint(xv) & 0x7FFFFFFFu;
+        amax = max(amax, live ? ab : 0u);
+        return (ab < 0x49800000u && live) ? xv : 0.f;
+    };
+    auto full_step = [&](const uint32_t (&k)[8], const float (&x)[CB][8]) {
+        u32x4 dd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dd[q] = ((k[2 * q] - row_ref) & 0xFFFFu) | ((k[2 * q + 1] - row_ref) << 16);
+        float v[CB][8];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[cb][e] = clean(x[cb][e], colv[cb]);
+        mma_step(dd, v);
+    };
+    if (n_full > 0) {
+        uint32_t kr[2][8];
+        float xr[2][CB][8];
+        load_step(0, kr[0], xr[0]);
+        int st = 0;
+        for (; st + 2 <= n_full; st += 2) {
+            load_step(st + 1, kr[1], xr[1]);
+            full_step(kr[0], xr[0]);
+            load_step(min(st + 2, n_full - 1), kr[0], xr[0]);          // (the last pair re-loads a valid step; unused)
+            full_step(kr[1], xr[1]);
+        }
+        if (st < n_full) full_step(kr[0], xr[0]);
+    }
+    if (rows_tail > 0) {                                               // ragged last step of the batch: rows masked one by one
+        const uint32_t* kps = kp + 32 * n_full;
+        const float* xps = xp + static_cast<int64_t>(32 * n_full) * ld;
+        u32x4 dd;
+        float v[CB][8];
+        uint32_t d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool live = 8 * kq + e < rows_tail;
+            d[e] = live ? ((kps + e)[koff] - row_ref) & 0xFFFFu : 0x8000u;      // 0x8000: the row of no tile
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                v[cb][e] = clean((live && colv[cb]) ? (xps + static_cast<int64_t>(e) * ld)[coff[cb]] : 0.f, true);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dd[q] = d[2 * q] | (d[2 * q + 1] << 16);
+        mma_step(dd, v);
+    }
+    if (amax >= 0x49800000u && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
+
+    // ---- the four quarters of the split, summed in wave order through LDS: ((w0 + w1) + w2) + w3
+    constexpr int REGS = TPW * CB * 4;
+    if (wave > 0) {
+        float* dst = seg_red + static_cast<size_t>(wave - 1) * REGS * 64;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[((t * CB + cb) * 4 + r) * 64 + lane] = acc[t][cb][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < SEG_WAVES; ++w) {
+        const float* src = seg_red + static_cast<size_t>(w - 1) * REGS * 64;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][cb][r] += src[((t * CB + cb) * 4 + r) * 64 + lane];
+    }
+    // partial table of this split: lane holds rows 16 t + 4 kq + r, column 16 cb + i
+    float* __restrict__ P = part + J.part_off + static_cast<int64_t>(split) * J.rows_pad * J.dim;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            if (colv[cb]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    P[static_cast<int64_t>(16 * (J.tile0 + t) + 4 * kq + r) * J.dim + 16 * cb + i] = acc[t][cb][r];
+            }
+        }
+    }
+}
+
+// jobs come in two sizes per column-block class (SegJob.tpw): BIG tiles per wave where a table has that many left -- the
+// per-step work that does not depend on the tile count (key arithmetic, the split of dE: ~130 instructions against 12 per
+// tile) is then spread over 16 tiles instead of 4 -- and SMALL for the remainders and the small tables
+template <int CB, int BIG, int SMALL>
+__global__ __launch_bounds__(SEG_WAVES * 64) void segsum_mfma_kernel(const SegMeta sm, const uint32_t* __restrict__ keys,
+                                                                      const float* __restrict__ dE, int64_t ld,
+                                                                      float* __restrict__ part, uint32_t* err) {
+    extern __shared__ __attribute__((aligned(16))) float seg_red[];
+    const int jb = static_cast<int>(blockIdx.x) % sm.n_jobs, split = static_cast<int>(blockIdx.x) / sm.n_jobs;
+    const SegJob& J = sm.job[jb];
+    if (J.tpw == BIG) seg_body<CB, BIG>(sm, J, split, keys, dE, ld, part, err, seg_red);
+    else seg_body<CB, SMALL>(sm, J, split, keys, dE, ld, part, err, seg_red);
 }
 
 // first position in [lo, hi) whose key is >= key
@@ -615,11 +945,32 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
 __global__ __launch_bounds__(RB_THREADS) void finalize_kernel(const BwdMeta m, const uint32_t* __restrict__ ck,
                                                               const long long* __restrict__ acc_hi,
                                                               const long long* __restrict__ acc_lo, int64_t dense_acc_elems,
-                                                              int gx, int dense_blocks) {
+                                                              int gx, int dense_blocks, const SegFin sf,
+                                                              const float* __restrict__ part) {
     if (static_cast<int>(blockIdx.x) < dense_blocks) {
-        const TableMeta& t = m.tab[blockIdx.x / gx];
+        const int ti = blockIdx.x / gx;
+        const TableMeta& t = m.tab[ti];
         if (t.mode == 1) return;
         const int64_t n = t.vocab * t.dim;
+        if (sf.n[ti] > 0) {
+            // MFMA segment sums: the partial tables of the table's lookups and batch splits, added in a fixed order
+            const float* __restrict__ p0 = part + sf.off[ti];
+            const int64_t stride = sf.stride[ti];
+            const int np = sf.n[ti];
+            for (int64_t j = static_cast<int64_t>(blockIdx.x % gx) * RB_THREADS + threadIdx.x; j < n;
+                 j += static_cast<int64_t>(gx) * RB_THREADS) {
+                float g = 0.f;
+                int q = 0;
+                for (; q + 4 <= np; q += 4) {
+                    const float v0 = p0[q * stride + j], v1 = p0[(q + 1) * stride + j], v2 = p0[(q + 2) * stride + j],
+                                v3 = p0[(q + 3) * stride + j];
+                    g += v0; g += v1; g += v2; g += v3;
+                }
+                for (; q < np; ++q) g += p0[q * stride + j];
+                t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;
+            }
+            return;
+        }
         for (int64_t j = static_cast<int64_t>(blockIdx.x % gx) * RB_THREADS + threadIdx.x; j < n;
              j += static_cast<int64_t>(gx) * RB_THREADS) {
             long long hi = 0, lo = 0;                                     // integer sums: order-free, exact
@@ -691,6 +1042,19 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
     const uint32_t* ck = kbuf[p.n_passes & 1];               // where the last pass left the sorted entries
     const uint32_t* sv = vbuf[p.n_passes & 1];
 
+    if (phases & 4) {
+        float* part = reinterpret_cast<float*>(ws + p.off_part);
+        for (int c = 0; c < 3; ++c) {
+            const SegMeta& sg = p.sg[c];
+            if (sg.n_jobs == 0) continue;
+            const dim3 grid(static_cast<unsigned>(sg.n_jobs * sg.n_splits));
+            const int cbk = c == 0 ? 1 : (c == 1 ? 2 : 4);
+            const unsigned lds = static_cast<unsigned>((SEG_WAVES - 1) * seg_tpw_big(c) * cbk * 4 * 64 * sizeof(float));
+            if (c == 0) hipLaunchKernelGGL((segsum_mfma_kernel<1, 16, 4>), grid, dim3(SEG_WAVES * 64), lds, st, sg, keys, dE, ld, part, err_flag);
+            else if (c == 1) hipLaunchKernelGGL((segsum_mfma_kernel<2, 4, 4>), grid, dim3(SEG_WAVES * 64), lds, st, sg, keys, dE, ld, part, err_flag);
+            else hipLaunchKernelGGL((segsum_mfma_kernel<4, 2, 2>), grid, dim3(SEG_WAVES * 64), lds, st, sg, keys, dE, ld, part, err_flag);
+        }
+    }
     if ((phases & 4) && p.dm.n_blocks > 0) {
         // LDS sized by the largest group (small groups -> more workgroups per CU); 16-byte loads when every lookup
         // column span is 4-float aligned
@@ -737,7 +1101,7 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
     if (dense_blocks + sparse_blocks > 0)
         hipLaunchKernelGGL(finalize_kernel, dim3(static_cast<unsigned>(dense_blocks + sparse_blocks)), dim3(RB_THREADS), 0, st,
                            m, ck, reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo),
-                           p.dense_acc_elems, gx > 0 ? gx : 1, dense_blocks);
+                           p.dense_acc_elems, gx > 0 ? gx : 1, dense_blocks, p.sf, reinterpret_cast<const float*>(ws + p.off_part));
     return swr_launch_status();
 }
 

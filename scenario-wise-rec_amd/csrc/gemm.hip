@@ -266,60 +266,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_lds_kernel(const GemmK
 // 1e-4 logit bar needs (a plain bf16 product misses it by two orders of magnitude).
 // Structure as the LDS kernel above: B (weights, [N, K] only) split once per workgroup while it is staged into LDS as
 // three bf16 planes [plane][col][k]; A split in registers after its 16-byte loads.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#include "split3.h"
 #define X6_KC 32                        // k per chunk (2 MFMA groups of 16)
 #define X6_PITCH 40                     // bf16 per LDS row: 32 + 8 pad -> 80-byte pitch, conflict-free ds_read_b128
 #define X6_DOUBLE_BUFFER(NT) 0         // measured: two buffers / one barrier per chunk is no faster than one / two
-
-struct Bf3 {
-    __bf16 h, m, l;
-};
-__device__ __forceinline__ Bf3 split3(float x) {
-    Bf3 r;
-    r.h = static_cast<__bf16>(x);
-    const float r1 = x - static_cast<float>(r.h);
-    r.m = static_cast<__bf16>(r1);
-    const float r2 = r1 - static_cast<float>(r.m);
-    r.l = static_cast<__bf16>(r2);
-    return r;
-}
-#define SPLIT3_INTO(x, H, M, L, idx)       \
-    do {                                   \
-        const Bf3 s3_ = split3(x);         \
-        H[idx] = s3_.h;                    \
-        M[idx] = s3_.m;                    \
-        L[idx] = s3_.l;                    \
-    } while (0)
-
-// Two values at a time: v_cvt_pk_bf16_f32 rounds both, v_pk_add_f32 takes both remainders -- 4.5 VALU per value instead
-// of 7 (the split is the VALU work that sits in front of every MFMA group); bit-identical to split3().
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#ifdef SWR_SPLIT_SCALAR
-#define SPLIT3_PAIR(x0, x1, H, M, L, idx) do { SPLIT3_INTO(x0, H, M, L, idx); SPLIT3_INTO(x1, H, M, L, (idx) + 1); } while (0)
-#else
-#define SPLIT3_PAIR(x0, x1, H, M, L, idx)                                   \
-    do {                                                                    \
-        const f32x2 sx_ = {x0, x1};                                         \
-        const bf16x2 sh_ = __builtin_convertvector(sx_, bf16x2);            \
-        const f32x2 s1_ = sx_ - __builtin_convertvector(sh_, f32x2);        \
-        const bf16x2 sm_ = __builtin_convertvector(s1_, bf16x2);            \
-        const f32x2 s2_ = s1_ - __builtin_convertvector(sm_, f32x2);        \
-        const bf16x2 sl_ = __builtin_convertvector(s2_, bf16x2);            \
-        H[idx] = sh_[0]; H[(idx) + 1] = sh_[1];                             \
-        M[idx] = sm_[0]; M[(idx) + 1] = sm_[1];                             \
-        L[idx] = sl_[0]; L[(idx) + 1] = sl_[1];                             \
-    } while (0)
-#endif
-
-#define CVT_PAIR(x0, x1, H, idx)                                            \
-    do {                                                                    \
-        const f32x2 cx_ = {x0, x1};                                         \
-        const bf16x2 ch_ = __builtin_convertvector(cx_, bf16x2);            \
-        H[idx] = ch_[0]; H[(idx) + 1] = ch_[1];                             \
-    } while (0)
-
 template <int NT, bool PRO, bool PS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD
     constexpr int NCOL = NT * 32;

@@ -159,7 +159,11 @@ def perturb_product(model, seed):
             dev = p.device
             def put(t):
                 p.copy_(t.to(dev))
-            if "embed_dict" in name:
+            if "embed_dict" in name and p.numel() > (1 << 26):
+                # a 50 M-row table (BASELINE config 5 / 6 at full size): drawn where it lives, not through host memory
+                dg = torch.Generator(device=dev).manual_seed(seed + p.shape[0] % 1000)
+                p.normal_(0.0, 0.3, generator=dg)
+            elif "embed_dict" in name:
                 put(torch.randn(p.shape, generator=g) * 0.3)
             elif name.startswith(("u.", "v.")):
                 put(torch.rand(p.shape, generator=g) * 0.3 + 0.1)

@@ -95,9 +95,12 @@ def test_embedding_backward(B, dim, vocabs, limit):
 
 
 @pytest.mark.parametrize("limit", [1 << 30, 1024])
-def test_embedding_backward_wide_dynamic_range(limit):
+def test_embedding_backward_wide_dynamic_range(limit, monkeypatch):
     """Gradients from 1e-15 to 5e5, signed zeros, a subnormal: the general (three-case) fixed-point conversion and
-    the short mid-range one must agree with an fp64 sum; dense (direct / sorted) and sparse-mode tables."""
+    the short mid-range one must agree with an fp64 sum; dense (direct / sorted) and sparse-mode tables.  (The exact
+    fixed-point paths: SWR_K3_MFMA=0 keeps the 3 000-row table off the fp32-accumulating MFMA segment sums, which are
+    tested in test_embedding_backward_mfma_segment_sums.)"""
+    monkeypatch.setenv("SWR_K3_MFMA", "0")
     from scenario_wise_rec.basic.features import SparseFeature
     from scenario_wise_rec.basic.layers import EmbeddingLayer
     rng = np.random.default_rng(11)
@@ -160,6 +163,75 @@ def test_embedding_backward_is_deterministic():
     for r in res[1:]:
         for a, b in zip(res[0], r):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,dim,vocabs", [(5000, 16, [40, 1000, 17, 4096]), (2048, 8, [100, 3]), (4100, 32, [300, 2000]),
+                                          (3000, 64, [1000, 33]), (2500, 24, [50]), (70000, 16, [1472, 455])])
+def test_embedding_backward_mfma_segment_sums(B, dim, vocabs, monkeypatch):
+    """Mid-size dense-gradient tables at batches >= 2048: dEmb = OneHot^T dE on the matrix pipes (csrc/embed_bwd.hip,
+    segsum_mfma_kernel).  fp32 accumulation in a fixed order: against np.add.at in fp64 within 1e-6 of the sum of the
+    addends' magnitudes, bitwise equal from run to run, and equal to the exact fixed-point path (SWR_K3_MFMA=0) to the
+    same bound; a shared table (two lookups) and a run of one row included."""
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(B + dim)
+    feats = [SparseFeature(f"s{i}", v, dim) for i, v in enumerate(vocabs)]
+    feats.append(SparseFeature("shared", vocabs[0], dim, shared_with="s0"))
+    layer = EmbeddingLayer(feats).to("cuda")
+    x = {f.name: rng.integers(0, f.vocab_size, size=B) for f in feats}
+    x["s0"][: B // 3] = vocabs[0] - 1
+    xd = {k: _dev(v) for k, v in x.items()}
+    g = (rng.standard_normal((B, (len(vocabs) + 1) * dim)) * 10.0 ** rng.integers(-4, 1, size=(B, 1))).astype(np.float32)
+    gd = _dev(g)
+
+    def run():
+        layer.zero_grad()
+        layer(xd, feats, squeeze_dim=True).backward(gd)
+        torch.cuda.synchronize()
+        return [layer.embed_dict[f.name].weight.grad.clone() for f in feats[:-1]]
+    got = run()
+    again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("SWR_K3_MFMA", "0")
+    exact = run()
+    monkeypatch.delenv("SWR_K3_MFMA")
+    for i, f in enumerate(feats[:-1]):
+        want = np.zeros((f.vocab_size, dim), np.float64)
+        mag = np.zeros((f.vocab_size, dim), np.float64)
+        cols = [(x[f.name], slice(i * dim, (i + 1) * dim))]
+        if i == 0:
+            cols.append((x["shared"], slice(len(vocabs) * dim, (len(vocabs) + 1) * dim)))
+        for idx, sl in cols:
+            np.add.at(want, idx, g[:, sl].astype(np.float64))
+            np.add.at(mag, idx, np.abs(g[:, sl]).astype(np.float64))
+        bound = 1e-6 * mag + 1e-30
+        assert np.all(np.abs(got[i].cpu().numpy() - want) <= bound), f.name
+        assert np.all(np.abs(exact[i].cpu().numpy() - want) <= 1.5e-7 * np.abs(want) + 1e-12), f.name
+
+
+def test_embedding_backward_mfma_flags_non_finite_gradients_without_spreading_them():
+    """An Inf in one sample's gradient must not reach the other rows of its 16-row tile (0 * Inf inside the one-hot product):
+    it contributes nothing and raises the sticky error word, like the fixed-point paths."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    feats = [SparseFeature("a", 64, 16)]
+    layer = EmbeddingLayer(feats).to("cuda")
+    B = 4096
+    idx = torch.arange(B, device="cuda") % 64
+    g = torch.ones(B, 16, device="cuda")
+    g[5, 3] = float("inf")
+    g[70, 1] = float("nan")
+    layer({"a": idx}, feats, squeeze_dim=True).backward(g)
+    torch.cuda.synchronize()
+    got = layer.embed_dict["a"].weight.grad.cpu().numpy()
+    want = np.full((64, 16), B / 64.0)
+    want[5, 3] -= 1.0
+    want[70 % 64, 1] -= 1.0
+    assert np.array_equal(got, want)
+    with pytest.raises(H.SwrError):
+        H.check_errors()
 
 
 @pytest.mark.parametrize("M,N,K", [(250, 148, 516), (64, 1, 16), (1000, 33, 7), (31, 300, 52), (4096, 256, 376),
