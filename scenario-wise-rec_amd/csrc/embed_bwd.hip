@@ -142,16 +142,23 @@ struct HostPlan {
     int n_chunks;
 };
 
-static bool seg_enabled() {          // SWR_K3_MFMA=0: mid-size tables take the exact fixed-point paths (direct / sorted) instead
-    const char* e = getenv("SWR_K3_MFMA");   // (read per call: tests/test_ops_gpu.py compares the two paths in one process)
-    return !(e && e[0] == '0');
+// SWR_K3_MFMA=1 opts in (read per call: tests/test_ops_gpu.py compares the paths in one process).  OFF by default: built
+// for VERDICT round 2 item 2 and measured at config 2 (tools/micro/k3_probe.py, profiles/r03_k3_probe.txt): the eight
+// mid-size tables take 46 us stand-alone against 42 us for the fixed-point direct sums, and 64 - 134 us inside the step,
+// where they share VALU and matrix pipes with the weight-gradient product that runs beside them (the direct sums are
+// bound by LDS atomics, a resource that product leaves free).  Building a one-hot fragment costs 3 packed 16-bit VALU
+// per pair of samples at ~4.4 cycles each (tools/micro/valu_rate.hip) = 53 cycles per fragment, its three MFMAs 48: the
+// kernel cannot be matrix-bound, and its work grows with rows x samples where a scatter's grows with samples.
+static bool seg_enabled() {
+    const char* e = getenv("SWR_K3_MFMA");
+    return e && e[0] == '1';
 }
 
 // Largest table that takes the MFMA segment sums.  Their work grows with rows x samples (every 16-row tile multiplies
 // every sample), the fixed-point direct sums' with samples only; measured at batch 65 536, dim 16 (tools/micro/k3_probe.py)
 static int64_t seg_max_rows() {
     const char* e = getenv("SWR_K3_MFMA_MAX_ROWS");
-    return e ? atoll(e) : 256;
+    return e ? atoll(e) : 4096;
 }
 
 static int bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value

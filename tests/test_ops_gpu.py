@@ -100,7 +100,7 @@ def test_embedding_backward_wide_dynamic_range(limit, monkeypatch):
     the short mid-range one must agree with an fp64 sum; dense (direct / sorted) and sparse-mode tables.  (The exact
     fixed-point paths: SWR_K3_MFMA=0 keeps the 3 000-row table off the fp32-accumulating MFMA segment sums, which are
     tested in test_embedding_backward_mfma_segment_sums.)"""
-    monkeypatch.setenv("SWR_K3_MFMA", "0")
+    monkeypatch.setenv("SWR_K3_MFMA", "0")             # (the default)
     from scenario_wise_rec.basic.features import SparseFeature
     from scenario_wise_rec.basic.layers import EmbeddingLayer
     rng = np.random.default_rng(11)
@@ -189,13 +189,13 @@ def test_embedding_backward_mfma_segment_sums(B, dim, vocabs, monkeypatch):
         layer(xd, feats, squeeze_dim=True).backward(gd)
         torch.cuda.synchronize()
         return [layer.embed_dict[f.name].weight.grad.clone() for f in feats[:-1]]
+    monkeypatch.setenv("SWR_K3_MFMA", "1")             # (opt-in path: see csrc/embed_bwd.hip seg_enabled)
     got = run()
     again = run()
     for a, b in zip(got, again):
         assert torch.equal(a, b)
     monkeypatch.setenv("SWR_K3_MFMA", "0")
     exact = run()
-    monkeypatch.delenv("SWR_K3_MFMA")
     for i, f in enumerate(feats[:-1]):
         want = np.zeros((f.vocab_size, dim), np.float64)
         mag = np.zeros((f.vocab_size, dim), np.float64)
@@ -210,12 +210,13 @@ def test_embedding_backward_mfma_segment_sums(B, dim, vocabs, monkeypatch):
         assert np.all(np.abs(exact[i].cpu().numpy() - want) <= 1.5e-7 * np.abs(want) + 1e-12), f.name
 
 
-def test_embedding_backward_mfma_flags_non_finite_gradients_without_spreading_them():
+def test_embedding_backward_mfma_flags_non_finite_gradients_without_spreading_them(monkeypatch):
     """An Inf in one sample's gradient must not reach the other rows of its 16-row tile (0 * Inf inside the one-hot product):
     it contributes nothing and raises the sticky error word, like the fixed-point paths."""
     from scenario_wise_rec import _hip as H
     from scenario_wise_rec.basic.features import SparseFeature
     from scenario_wise_rec.basic.layers import EmbeddingLayer
+    monkeypatch.setenv("SWR_K3_MFMA", "1")
     feats = [SparseFeature("a", 64, 16)]
     layer = EmbeddingLayer(feats).to("cuda")
     B = 4096
