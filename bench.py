@@ -350,6 +350,7 @@ def main():
     if rank != 0:
         return
 
+    bf16_mode = H.lib.swr_gemm_precision_mode() == 2
     # ---- roofline of the dominant kernel (see DESIGN.md "Measurement") ------------------------------------
     print(f"[bench] timed region done: {ms:.3f} ms/step", file=sys.stderr, flush=True)
     roof = None
@@ -361,12 +362,16 @@ def main():
                   else "train samples/sec, " + cfg["name"],
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16" if bf16_mode else "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "global_batch": world * B, "per_gpu_batch": B,
                    "step": "fwd+BCE+bwd+Adam(all params; dense-Adam semantics on every table row, applied lazily but exactly)", "parallelism": f"dp{world}",
                    "ids": "uniform" if args.uniform_ids else "zipf1.05(large tables)+uniform", "hipgraph": graph is not None,
                    "batches_rotated": n_rot, "ms_per_step_single_batch_replayed": single_ms,
-                   "final_loss": final_loss},
+                   "final_loss": final_loss,
+                   "precision_mode": ("bf16 perf mode (SWR_GEMM=bf16): ONE bf16 MFMA product per k-group, operands rounded to bf16 -- "
+                                      "NOT the parity path (max logit error ~1e-3..1e-2 at these widths, tests/test_perf_mode_gpu.py); "
+                                      "reported beside the fp32-accurate line, never instead of it") if bf16_mode else
+                                     "fp32-accurate: every fp32 product as six bf16 MFMA products, fp32 accumulate (parity path)"},
         "roofline": roof,
     }
     if not args.no_cpu_baseline and world == 1 and args.config == 2:

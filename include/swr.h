@@ -58,6 +58,9 @@ typedef enum {
 #define SWR_FLAG_GRAD_RANGE 2u     /* |embedding grad| >= 2^20: outside the fixed-point accumulator */
 
 int swr_abi_version(void);
+/* Test instrument (tests/test_skew_gpu.py): keeps `stream` busy for `us` microseconds with one idle-spinning wave.  The
+ * Python layer injects it at its stream forks when SWR_SKEW is set, to expose missing cross-stream dependencies. */
+int swr_spin_us(int us, void* stream);
 const char* swr_status_str(int status);
 /* 1 when a HIP device is visible to the calling process (no compute is done) */
 int swr_device_available(void);
@@ -263,6 +266,11 @@ int swr_gemm_nn(const swr_gemm_args* args_host, void* stream);
  * of W^T (`planes_t`, rows = K, columns = N padded to ld_t = swr_split_ld(N)); x = h + m + l with h = bf16(x),
  * m = bf16(x - h), l = bf16(x - h - m).  Either output may be null.  Plane p starts at p * rows * ld. */
 int64_t swr_split_ld(int64_t cols);
+/* Which arithmetic the nt / tn products use (environment SWR_GEMM, read once): 1 = the default, every fp32 product as six
+ * bf16 MFMA products (fp32-class accuracy: the parity path); 0 = f32 MFMA; 2 = ONE bf16 product per k-group (operands
+ * rounded to bf16) -- the perf mode of the north star's "MFMA bf16 for the dense expert GEMMs", outside the 1e-4 logit
+ * tolerance by two orders of magnitude (measured: tests/test_perf_mode_gpu.py) and never used for parity. */
+int swr_gemm_precision_mode(void);
 int swr_split_weights(const float* W, int64_t ldw, int N, int K, void* planes, void* planes_t, void* stream);
 
 typedef struct {

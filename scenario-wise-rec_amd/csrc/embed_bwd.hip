@@ -35,8 +35,10 @@
 
 #define CHUNK_MAX 32     // sorted entries per reduce walker; 8 / 16 when there are few entries
 #define RB_THREADS 256
+#ifndef ACC_STRIPES
 #define ACC_STRIPES 16   // copies of the dense accumulators: chunk c adds into stripe c % 16, so a hot row of a tiny
                        // table (V = 2: 1000+ partial runs per row) does not serialise its atomics on one address
+#endif
 
 #define DIRECT_THREADS 512
 #define DIRECT_CAP_ELEMS 4096     // (hi, lo) int64 accumulator pairs per workgroup = 64 KB of LDS, 2 workgroups per CU

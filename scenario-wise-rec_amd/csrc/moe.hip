@@ -952,6 +952,21 @@ int swr_zero_async(void* p, size_t bytes, hipStream_t st) {
     return swr_launch_status();
 }
 
+// Stream-skew harness (tests/test_skew_gpu.py, SWR_SKEW): one wave that occupies its stream for `us` microseconds
+// (wall_clock64 ticks at 100 MHz).  Injected at the fork points of the step (ops._skew) it stretches one branch of the
+// stream graph against the others: a missing cross-stream edge then shows as a changed bit in the results.
+__global__ void swr_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int swr_spin_us(int us, void* stream) {
+    SWR_REQUIRE(us >= 0 && us <= 100000, SWR_ERR_ARG);
+    if (us == 0) return SWR_OK;
+    hipLaunchKernelGGL(swr_spin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<long long>(us) * 100);
+    return swr_launch_status();
+}
+
 extern "C" int swr_abi_version(void) { return SWR_ABI_VERSION; }
 
 extern "C" const char* swr_status_str(int status) {

@@ -171,6 +171,7 @@ class AdamHyper(C.Structure):
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _SIGS = {
     "swr_abi_version": (C.c_int, []),
+    "swr_spin_us": (C.c_int, [C.c_int, _P]),
     "swr_status_str": (C.c_char_p, [_I]),
     "swr_device_available": (C.c_int, []),
     "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
@@ -190,6 +191,7 @@ _SIGS = {
     "swr_gemm_nt": (C.c_int, [_P, _P]),
     "swr_gemm_nn": (C.c_int, [_P, _P]),
     "swr_split_ld": (C.c_int64, [_L]),
+    "swr_gemm_precision_mode": (C.c_int, []),
     "swr_split_weights": (C.c_int, [_P, _L, _I, _I, _P, _P, _P]),
     "swr_gemm_tn_workspace_bytes": (_Z, [_P]),
     "swr_gemm_tn": (C.c_int, [_P, _P, _Z, _P]),

@@ -187,6 +187,30 @@ EPILOGUE_ACT = os.environ.get("SWR_EPILOGUE_ACT", "1") != "0"
 LATE_SORT_JOIN = os.environ.get("SWR_LATE_SORT_JOIN", "1") != "0"
 
 
+# ---- stream-skew harness (tests/test_skew_gpu.py): with a seed set (SWR_SKEW=<seed> or ops.set_skew(seed)) every fork
+# point of the step injects an idle-spinning kernel of pseudo-random length (0 .. 400 us, swr_spin_us) on the forked
+# stream and / or on the forking one, stretching the branches of the stream graph against each other.  Results must not
+# change by a bit: a missing cross-stream edge (a reader that merely happened to start after its writer) shows up as a
+# difference.  Works under hipGraph capture (the spin becomes a kernel node of fixed length).
+_SKEW = {"seed": int(os.environ["SWR_SKEW"]) if os.environ.get("SWR_SKEW") else None, "n": 0}
+_SKEW_US = (0, 15, 50, 140, 400)
+
+
+def set_skew(seed):
+    """seed (int) switches the harness on, None off; the sequence of spin lengths restarts."""
+    _SKEW["seed"], _SKEW["n"] = (None if seed is None else int(seed)), 0
+
+
+def _skew(point):
+    if _SKEW["seed"] is None:
+        return
+    _SKEW["n"] += 1
+    h = (_SKEW["seed"] * 1000003 + _SKEW["n"] * 7919 + point * 104729) % 2147483647
+    us = _SKEW_US[(h >> 3) % len(_SKEW_US)]
+    if us:
+        H.check(lib.swr_spin_us(us, H.stream()), "swr_spin_us")
+
+
 def add_side_job(fn):
     """Run `fn()` on the side stream inside the next forward-time fork (EmbedGather.forward); `run_side_jobs()` runs
     whatever is still pending on the current stream."""
@@ -295,7 +319,9 @@ def _fork_dw(dev, fn, keep):
     st = _dw["streams"][key]
     st.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(st):
+        _skew(3)
         fn()
+    _skew(4)
     _dw["pending"] += 1
     _side["keep"].append(keep)
     if not _side["queued"]:
@@ -319,7 +345,9 @@ def _fork_side(dev, fn, after_event=None):
     else:
         side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
+        _skew(1)
         fn()
+    _skew(2)
     _side["pending"] += 1
 
 

@@ -268,6 +268,7 @@ class DataParallelStep(object):
             arena, big, sparse = self._sparse()
             xb = self._exchange_buffers(arena["g"], big, sparse)
             work = self._send_rows(xb, sparse)
+            ops._skew(7)
             ops.run_late_jobs()                                   # overlaps the row lists' all-gather
             self._send_dense(xb, arena["g"], pack=True)
             if work is not None:
@@ -349,8 +350,10 @@ class DataParallelStep(object):
             # launches, its stream synchronisation kept the second graph's first kernel waiting ~30 us
             self._rows_ready.record(cur)
             g1b.replay()
+            ops._skew(6)
             with torch.cuda.stream(self._merge_stream):
                 self._merge_stream.wait_event(self._rows_ready)                 # (also: after the previous step's readers)
+                ops._skew(5)
                 work = dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group, async_op=True)
                 work.wait()
                 self._merge_rows(xb, self._big)                                 # needs only this all-gather: hidden too
