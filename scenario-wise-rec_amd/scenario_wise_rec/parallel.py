@@ -28,6 +28,15 @@ from . import ops
 AG_AFTER_LAUNCH = os.environ.get("SWR_DP_AG_AFTER_LAUNCH", "1") != "0"
 
 
+def allreduce_min_bytes():
+    """Gradient arenas above this size are ALL-REDUCED (SURVEY.md 8e / north star: "a single RCCL all-reduce over xGMI on
+    the dense parameters") instead of all-gathered and summed locally: an all-gather delivers N x arena bytes to every
+    rank -- fine for the 0.5 MB arena of the KuaiRand MMoE, where one latency-bound collective + a rank-ordered local sum
+    is the cheapest exchange, wasteful for STAR's 4 MB (30 MB received per rank per step at 8 ranks).  Every rank receives
+    the same reduced bytes from an all-reduce, so replicas stay bitwise equal either way."""
+    return int(os.environ.get("SWR_DP_ALLREDUCE_BYTES", 1 << 20))
+
+
 def hip_merge_rows(urow, ugrad, vocab):
     """Deterministic merge of gathered row entries on the device: (row id or -1, gradient) x n ->
     the same representation with every distinct row listed once (K3's reduction, swr_embed_bwd)."""
@@ -126,7 +135,14 @@ def _hip_finish(dense_grad, recv, A, offs, total, world_size):
 def exchange_gradients(dense_grad, sparse_grads, world_size, group=None, merge_rows=hip_merge_rows):
     """The exchange step.  `dense_grad`: the flat gradient arena (averaged in place).
     `sparse_grads`: list of (urow int32 [n], ugrad fp32 [n, dim], vocab) per large table.
-    Returns the merged, averaged (urow, ugrad) per table."""
+    Returns the merged, averaged (urow, ugrad) per table.  An arena above `allreduce_min_bytes()` is all-reduced; the
+    row lists (and a small arena) travel in one all-gather."""
+    if dense_grad is not None and dense_grad.numel() * 4 > allreduce_min_bytes():
+        dist.all_reduce(dense_grad, group=group)
+        dense_grad.mul_(1.0 / world_size)
+        if not sparse_grads:
+            return []
+        return finish(None, communicate(None, sparse_grads, world_size, group), world_size, merge_rows)
     return finish(dense_grad, communicate(dense_grad, sparse_grads, world_size, group), world_size, merge_rows)
 
 
@@ -191,7 +207,9 @@ class DataParallelStep(object):
             f32 = dict(dtype=torch.float32, device=dev)
             # the arena itself is the dense message when its length keeps every rank's copy 16-byte aligned in `recv_d`
             self._xb = {"A": A, "A4": A4, "offs": offs, "total": total, "in_place": A > 0 and A % 4 == 0 and dense.is_contiguous(),
-                        "send_d": torch.zeros(max(A4, 4), **f32), "recv_d": torch.empty(W * max(A4, 4), **f32),      # A4 == A when in place
+                        "allreduce": A * 4 > allreduce_min_bytes() and dense.is_contiguous(),
+                        "send_d": torch.zeros(max(A4, 4), **f32),                                                    # A4 == A when in place
+                        "recv_d": torch.empty((1 if A * 4 > allreduce_min_bytes() and dense.is_contiguous() else W) * max(A4, 4), **f32),
                         "send_r": torch.zeros(max(total, 4), **f32), "recv_r": torch.empty(W * max(total, 4), **f32)}
             send = self._xb["send_r"]
             for p, (r0, r1, n, dim, _v) in zip(big, offs):
@@ -225,6 +243,9 @@ class DataParallelStep(object):
     def _send_dense(self, xb, dense, pack):
         """All-gather of the gradient arena (sent in place when its length allows; else through a packed copy, made
         here when `pack`, or by the captured graph)."""
+        if xb["allreduce"]:
+            dist.all_reduce(dense.reshape(-1), group=self.group)          # in place: every rank ends with the same sum
+            return
         if xb["in_place"]:
             dist.all_gather_into_tensor(xb["recv_d"], dense.reshape(-1), group=self.group)
             return
@@ -248,7 +269,11 @@ class DataParallelStep(object):
         flat = dense.reshape(-1)
         if flat.data_ptr() != dense.data_ptr():
             raise H.SwrError("exchange: the gradient arena must be contiguous")
-        if xb["A"]:
+        if xb["A"] and xb["allreduce"]:
+            # the arena holds the all-reduced SUM: one pass scales it to the mean (swr_dp_finish over one "rank", in place)
+            H.check(H.lib.swr_dp_finish(H.ptr(flat), max(xb["A4"], 4), xb["A"], H.ptr(flat), None, 0, None, 0,
+                                        1, 1.0 / W, H.stream()), "swr_dp_finish(scale)")
+        elif xb["A"]:
             H.check(H.lib.swr_dp_finish(H.ptr(xb["recv_d"]), max(xb["A4"], 4), xb["A"], H.ptr(flat), None, 0, None, 0,
                                         W, 1.0 / W, H.stream()), "swr_dp_finish(dense)")
 
@@ -315,7 +340,7 @@ class DataParallelStep(object):
         with torch.cuda.graph(g1b, pool=g1.pool(), capture_error_mode="thread_local"):
             ops.run_late_jobs()
             ops.join_side_streams()
-            if not xb["in_place"]:
+            if not xb["in_place"] and not xb["allreduce"]:
                 xb["send_d"][:xb["A"]].copy_(arena["g"].reshape(-1))           # the only packing copy
         g2 = torch.cuda.CUDAGraph()
         for p, rg in zip(big, xb["merged"]):          # (the merge itself is launched eagerly, on the side stream, in replay)

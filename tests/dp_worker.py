@@ -92,6 +92,24 @@ def main():
     mode, name, out_dir = sys.argv[1:4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "torch-only":
+        # control experiment of tools/dp8_soak.py: the SAME process topology (`world` processes on cuda:0, gloo collectives
+        # over device tensors) running nothing but PyTorch's own kernels -- libswr is never loaded.  A runtime GPU fault
+        # here cannot come from this repository's kernels or stream edges.
+        torch.cuda.set_device(0)
+        g = torch.Generator(device="cuda").manual_seed(rank)
+        a = torch.randn(1024, 1024, device="cuda", generator=g)
+        acc = torch.zeros(1024, 1024, device="cuda")
+        for _ in range(20):
+            acc = torch.relu(acc + a @ a.t() * 1e-3)
+            buf = torch.empty(world * 4096, device="cuda")
+            dist.all_gather_into_tensor(buf, acc.reshape(-1)[:4096].contiguous())
+            acc = acc + buf[:4096].sum() * 1e-9
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(acc).all())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     case = Case(name)
     x, y = shard(case, rank, world)
     if mode == "exchange-cpu":
@@ -180,6 +198,10 @@ def main():
             np.savez(os.path.join(out_dir, f"grads_rank{rank}.npz"), **dump_gradients(model))
             # what this rank RECEIVED: every rank's gradient arena (pre-exchange local gradients, by parameter name)
             xb, arena = step._xb, model.arena()
+            if xb["allreduce"]:                      # (all-reduced arena: no per-rank copies exist on the receiver)
+                dist.barrier()
+                dist.destroy_process_group()
+                return
             recv = xb["recv_d"].cpu().numpy().reshape(world, -1)
             names = {id(p): k for k, p in model.named_parameters()}
             local = {}

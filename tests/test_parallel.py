@@ -58,9 +58,11 @@ def run_workers(mode, case, world, extra=(), env_extra=None, _attempt=0):
     return out
 
 
-@pytest.mark.parametrize("name,world", [("mmoe_dp2", 2), ("mmoe_dp8", 8)])
-def test_exchange_step_reproduces_dataparallel_gradients(name, world):
-    out = run_workers("exchange-cpu", name, world)
+@pytest.mark.parametrize("name,world,allreduce", [("mmoe_dp2", 2, False), ("mmoe_dp8", 8, False), ("mmoe_dp2", 2, True), ("mmoe_dp8", 8, True)])
+def test_exchange_step_reproduces_dataparallel_gradients(name, world, allreduce):
+    """allreduce: the gradient arena travels in ONE all-reduce (arenas above parallel.allreduce_min_bytes(); forced here),
+    the row lists in the all-gather; otherwise one all-gather carries both."""
+    out = run_workers("exchange-cpu", name, world, env_extra={"SWR_DP_ALLREDUCE_BYTES": "0"} if allreduce else None)
     got = np.load(os.path.join(out, "exchanged.npz"))
     c = Case(name)
     for k, g in c.group("grad").items():
@@ -69,24 +71,27 @@ def test_exchange_step_reproduces_dataparallel_gradients(name, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world,limit", [("mmoe_dp2", 2, None), ("mmoe_dp2", 2, 2048), ("mmoe_dp8", 8, 2048)])
-def test_two_ranks_full_hip_step(name, world, limit):
+@pytest.mark.parametrize("name,world,limit,allreduce", [("mmoe_dp2", 2, None, False), ("mmoe_dp2", 2, 2048, False),
+                                                        ("mmoe_dp8", 8, 2048, False), ("mmoe_dp2", 2, 2048, True)])
+def test_two_ranks_full_hip_step(name, world, limit, allreduce):
     """limit=2048 bytes forces every table above 32 rows x 16 onto the row-sparse exchange; the 8-rank case (all ranks
     on cuda:0, gloo) runs the split backward, both all-gathers and the sort-free merge at the world size of a full
     node against the reference's 8-shard DataParallel result."""
-    out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),),
-                      env_extra={"DP_TAKE_TURNS": "1"} if world > 2 else None)      # (see dp_worker.take_turns_on_the_gpu)
+    env = {"DP_TAKE_TURNS": "1"} if world > 2 else {}                               # (see dp_worker.take_turns_on_the_gpu)
+    if allreduce:
+        env["SWR_DP_ALLREDUCE_BYTES"] = "0"        # the arena goes through dist.all_reduce (parallel.allreduce_min_bytes)
+    out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),), env_extra=env or None)
     c = Case(name)
     # 0. what the ranks sent each other: every rank received the same bytes, and rank r's local gradient arena is the
     #    oracle's gradient of the local mean loss on shard r (locates a failure: a rank's kernels, or the exchange)
     from _golden import make_oracle
-    recv = [np.load(os.path.join(out, f"received_rank{r}.npz")) for r in range(world)]
-    for r in range(1, world):
+    recv = [np.load(os.path.join(out, f"received_rank{r}.npz")) for r in range(world)] if not allreduce else [None]
+    for r in range(1, world if not allreduce else 0):
         for k in recv[0].files:
             assert np.array_equal(recv[r][k], recv[0][k]), f"rank {r} received different bytes for {k}"
     x, y = c.batch(0)
     sh = len(y) // world
-    for r in range(world):
+    for r in range(world if not allreduce else 0):
         _, _, og = make_oracle(c).loss_and_grads({k: v[r * sh:(r + 1) * sh] for k, v in x.items()}, y[r * sh:(r + 1) * sh])
         for k in recv[0].files:
             scale = max(1e-6, float(np.abs(og[k]).max()))
@@ -117,12 +122,14 @@ def test_two_ranks_full_hip_step(name, world, limit):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("limit", [None, 2048])
-def test_two_rank_captured_step_matches_eager(limit):
-    """DataParallelStep.capture (three hipGraphs around eager collectives) vs three eager steps: identical state."""
+@pytest.mark.parametrize("limit,env", [(None, {}), (2048, {}), (2048, {"SWR_DP_ALLREDUCE_BYTES": "0"}), (2048, {"SWR_SKEW": "4"})],
+                         ids=["dense", "rows", "rows_allreduce", "rows_skewed"])
+def test_two_rank_captured_step_matches_eager(limit, env):
+    """DataParallelStep.capture (three hipGraphs around eager collectives) vs three eager steps: identical state -- also
+    with the arena all-reduced, and with the stream-skew harness stretching the merge / compute streams (ops._skew)."""
     extra = () if limit is None else (str(limit),)
-    a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra), "state1.npz"))
-    b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra, env_extra={"DP_EAGER_REFERENCE": "1"}),
+    a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra, env_extra=env or None), "state1.npz"))
+    b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 2, extra=extra, env_extra=dict(env, DP_EAGER_REFERENCE="1", SWR_SKEW="")),
                              "state1.npz"))
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
