@@ -310,7 +310,7 @@ def main():
             graph.load(xb, yb)
         return graph.replay()
 
-    def timed(n_steps, first):
+    def timed(n_steps, first, run=run):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -347,6 +347,33 @@ def main():
         single_ms = dts / args.steps * 1e3
         n_rot = n_rot_saved
 
+    # ---- N > 1: the OTHER scaling regime beside the reported one, in the same line (`config.other_scaling`): weak = the
+    # configuration's batch per GPU, strong = that batch split by row over the GPUs (65 536 -> 8 192 per GPU at 8, where
+    # the ~40 launches of a step are a latency floor).  A second capture of the step at the other batch shape.
+    other = None
+    if world > 1 and graph is not None and (args.scaling == "strong" or cfg["batch"] % world == 0):
+        B2 = cfg["batch"] if args.scaling == "strong" else cfg["batch"] // world
+        b2 = []
+        for j in range(n_rot):
+            xh, yh = synth_batch(cfg, B2, seed=5022 + args.config + 1000 * rank + 77 * j, zipf=not args.uniform_ids)
+            b2.append(({k: torch.from_numpy(v).to(dev) for k, v in xh.items()}, torch.from_numpy(yh).to(dev)))
+        if use_dp:
+            g2 = stepper.capture(b2[0][0], b2[0][1], warmup=max(2, args.warmup))
+        else:
+            from scenario_wise_rec.trainers.graph import GraphedStep
+            g2 = GraphedStep(trainer, b2[0][0], b2[0][1], warmup=max(2, args.warmup))
+
+        def run2(i):
+            if n_rot > 1:
+                g2.load(*b2[i % n_rot])
+            return g2.replay()
+        for i in range(2 * n_rot):
+            run2(i)
+        dt2, _ = timed(args.steps, 0, run2)
+        H.check_errors()
+        other = {"scaling": "weak" if args.scaling == "strong" else "strong", "global_batch": world * B2, "per_gpu_batch": B2,
+                 "ms_per_step": dt2 / args.steps * 1e3, "value": world * B2 * args.steps / dt2, "unit": "samples/s"}
+
     if rank != 0:
         return
 
@@ -356,7 +383,9 @@ def main():
     roof = None
     if not args.no_roofline:
         roof = measure_roofline(cfg, model, trainer, x, dev, args.steps, B) if args.config == 2 else \
-            gather_roofline(cfg, model, x, dev, args.steps, B)
+            gather_roofline(cfg, model, x, dev, args.steps, B, args.config)
+        if roof is not None:
+            roof.setdefault("also", {})["step"] = step_roofline(ms, args.config)
     out = {
         "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X" if args.config == 2
                   else "train samples/sec, " + cfg["name"],
@@ -367,7 +396,7 @@ def main():
                    "step": "fwd+BCE+bwd+Adam(all params; dense-Adam semantics on every table row, applied lazily but exactly)", "parallelism": f"dp{world}",
                    "ids": "uniform" if args.uniform_ids else "zipf1.05(large tables)+uniform", "hipgraph": graph is not None,
                    "batches_rotated": n_rot, "ms_per_step_single_batch_replayed": single_ms,
-                   "final_loss": final_loss,
+                   "final_loss": final_loss, "scaling": args.scaling, "other_scaling": other,
                    "precision_mode": ("bf16 perf mode (SWR_GEMM=bf16): ONE bf16 MFMA product per k-group, operands rounded to bf16 -- "
                                       "NOT the parity path (max logit error ~1e-3..1e-2 at these widths, tests/test_perf_mode_gpu.py); "
                                       "reported beside the fp32-accurate line, never instead of it") if bf16_mode else
@@ -441,7 +470,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
 
     # the one-hot columns of A' are bf16-exact: the forward kernel issues 3 products instead of 6 for whole pairs of
     # 32-column chunks behind `a_exact_from` (include/swr.h), as the model's own launch does
-    ex_from = info.Kp if (folded and ops.EXACT_ONEHOT) else 0
+    ex_from = info.Kp if folded else 0
     k_half = max(0, kf - (ex_from + 63) // 64 * 64) if ex_from > 0 else 0      # columns on the 3-product body
 
     def f_fwd():
@@ -452,7 +481,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         dZ, _A = nxt()
         ops.gemm("nt", dZ, Wsel, dX, B, n_sel, n1)
 
-    x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f" and os.environ.get("SWR_TN_X6", "1") != "0"
+    x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f"
     peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
     alg_flops = 2.0 * B * n1 * k0
 
@@ -481,26 +510,93 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W, columns of the K3 tables only)", f_dx,
                                          "void gemm_rows_x6_kernel<5", n_sel, 2.0 * B * n1 * fs * e),
         "embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters, B),
+        "k3_direct_sums": k3_roofline(cfg, dev, iters, B),
     }
     return roof
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (tools/prof_round.sh ->
-    tools/pmc_to_json.py), or None: counters cannot be collected from inside the bench process."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+def _pmc_file(config):
+    """The committed PMC summary of THIS configuration's bench command (tools/prof_round2.sh / tools/prof_configs_all.sh ->
+    tools/pmc_to_json.py): config 2 -> profiles/pmc_hbm_latest.json, config N -> profiles/pmc_hbm_cfgN.json; None if absent
+    (counters cannot be collected from inside the bench process)."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json" if config == 2 else f"pmc_hbm_cfg{config}.json")
     try:
         with open(path) as f:
-            kernels = json.load(f)["kernels"]
-        for name, ent in kernels.items():          # template arguments may follow (`<5, true>`)
-            if name.startswith(kernel):
-                return ent["hbm_bytes_per_launch"]
-        return None
+            return json.load(f)["kernels"]
     except (OSError, KeyError, ValueError):
         return None
 
 
-def gather_roofline(cfg, model, x, dev, iters, B):
+def pmc_traffic(kernel, config=2):
+    """HBM bytes per launch of `kernel` in configuration `config`'s step, or None."""
+    kernels = _pmc_file(config)
+    if not kernels:
+        return None
+    for name, ent in kernels.items():          # template arguments may follow (`<5, true>`)
+        if name.startswith(kernel):
+            return ent["hbm_bytes_per_launch"]
+    return None
+
+
+def step_roofline(ms_per_step, config=2):
+    """The whole step against the HBM roofline: sum of the PMC bytes of every kernel of one step / ms_per_step / 8 TB/s.
+    Steps in the PMC run = launches of a kernel that runs exactly once per step."""
+    kernels = _pmc_file(config)
+    if not kernels:
+        return None
+    once = [v["launches"] for k, v in kernels.items() if k.startswith(("adam_advance_kernel", "adam_dense"))]
+    steps = min(once) if once else 0
+    if steps <= 0:
+        return None
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items() if not k.startswith("__amd_rocclr")) / steps
+    gbs = total / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "hbm_bytes_per_step": total, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "ms_per_step": ms_per_step,
+            "note": "sum of rocprofv3 PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE) of every kernel of one step / measured step time"}
+
+
+def k3_roofline(cfg, dev, iters, B, config=2):
+    """K3's sums of the mid-size dense-gradient tables (the tables above 16 rows that stay below the row-sparse limit:
+    8 at config 2), timed stand-alone through the C ABI on the step's compact dX layout.  Algorithmic bytes per sample:
+    n_tables * (4 E + 4) (one gradient row + one key each, SURVEY.md 8d's backward figure without the accumulator
+    traffic, which stays in LDS / L2)."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec._hip import lib
+    E = cfg["embed_dim"]
+    mids = [v for v in cfg["vocabs"] if v > 16 and v * E * 4 <= (1 << 20)]
+    if not mids:
+        return None
+    ld = len(mids) * E
+    g = torch.Generator(device=dev).manual_seed(3)
+    sets = [(torch.stack([torch.randint(0, v, (B,), device=dev, generator=g, dtype=torch.int32) for v in mids]).contiguous(),
+             torch.randn(B, ld, device=dev, generator=g) * 1e-3) for _ in range(4)]
+    grads = [torch.zeros(v, E, device=dev) for v in mids]
+    slots = (H.EmbedGradSlot * len(mids))()
+    for s_, v in enumerate(mids):
+        slots[s_] = H.EmbedGradSlot(v, E, E * s_, s_, 0, grads[s_].data_ptr(), None, None)
+    nbytes = lib.swr_embed_bwd_workspace_bytes(slots, len(mids), B)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    flag = H.err_flag(dev)
+    st = {"i": 0}
+
+    def launch():
+        keys, dE = sets[st["i"] % 4]
+        st["i"] += 1
+        H.check(lib.swr_embed_bwd_reduce_part(slots, len(mids), H.ptr(keys), H.ptr(dE), ld, B, 2, H.ptr(ws), nbytes, H.ptr(flag),
+                                              H.stream()), "swr_embed_bwd_reduce_part")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        H.check(lib.swr_embed_bwd_sort(slots, len(mids), H.ptr(sets[0][0]), B, H.ptr(ws), nbytes, H.stream()), "swr_embed_bwd_sort")
+    ms = time_kernel_events(launch, max(10, iters), stream)
+    alg = float(len(mids) * B * (4 * E + 4))
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"kernel": "direct_kernel + finalize_kernel (K3 sums of the %d mid-size tables)" % len(mids), "bound": "hbm",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "traffic": pmc_traffic("void direct_kernel<", config),
+            "note": "bound by 64-bit LDS atomics on random rows, not by HBM (DESIGN.md): the fraction is what it is"}
+
+
+def gather_roofline(cfg, model, x, dev, iters, B, config=2):
     """HBM roofline of K1 (the north star's >= 50 % target): algorithmic bytes per sample
     F_s (idx + 4 E) + 4 F_d + 4 K0 over the measured launch time of the fused lookup."""
     from scenario_wise_rec.basic.layers import fused_lookup
@@ -533,21 +629,22 @@ def gather_roofline(cfg, model, x, dev, iters, B):
         for p, st in lazies.items():
             p._swr_lazy = st
     nbytes = gather_bytes_per_sample(cfg) * B
-    achieved = nbytes / (ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-           "traffic": pmc_traffic("void embed_gather_kernel<4>"), "kernel": "embed_gather_kernel"}
+    ref = {"algorithmic_bytes_per_launch": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9,
+           "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "SURVEY.md 8(d)'s per-sample bytes of the REFERENCE lookup (F_s (idx + 4E) + 4 F_d + 4 K0) over this launch's "
+                   "time: a speed-up figure against the reference's traffic, not an HBM efficiency"}
+    exe, layout = nbytes, "plain concat [B, K0]: executed = algorithmic"
     last = state["keep"][-1] if state["keep"] else None
     info = getattr(last, "_swr_onehot", None)
     if info is not None and info.fold:
-        # folded layout: the small tables' embeddings are not written (nor read) at all -- SURVEY.md 8(d)'s per-sample
-        # figure above is the reference's lookup; this is what the launch really moves
+        # folded layout: the small tables' embeddings are neither read nor written; what the launch really moves
         fs_, e_ = len(cfg["vocabs"]), cfg["embed_dim"]
         exe = B * (fs_ * 8 + 4 * (info.Kp + info.oh_width) + 4 * e_ * len(info.compact) + 4 * cfg["n_dense"])
-        out["executed_bytes_per_launch"] = exe
-        out["executed_frac"] = exe / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        out["layout"] = f"folded: [{len(info.compact)} tables x {e_} | {cfg['n_dense']} dense | {info.oh_width} one-hot columns]"
-    return out
+        layout = f"folded: [{len(info.compact)} tables x {e_} | {cfg['n_dense']} dense | {info.oh_width} one-hot columns]"
+    achieved = exe / (ms * 1e-3) / 1e9
+    return {"kernel": "embed_gather_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "executed_bytes_per_launch": exe, "avg_launch_ms": ms, "layout": layout,
+            "traffic": pmc_traffic("void embed_gather_kernel<4>", config), "vs_reference_bytes": ref}
 
 
 if __name__ == "__main__":

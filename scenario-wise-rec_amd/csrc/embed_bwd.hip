@@ -36,8 +36,8 @@
 #define CHUNK_MAX 32     // sorted entries per reduce walker; 8 / 16 when there are few entries
 #define RB_THREADS 256
 #ifndef ACC_STRIPES
-#define ACC_STRIPES 16   // copies of the dense accumulators: chunk c adds into stripe c % 16, so a hot row of a tiny
-                       // table (V = 2: 1000+ partial runs per row) does not serialise its atomics on one address
+#define ACC_STRIPES 4    // copies of the dense accumulators: chunk c adds into stripe c % ACC_STRIPES, so a hot row of a small
+                       // table does not serialise its atomics on one address (16 -> 4 stripes: -8 us of zero-fill and finalise per step at config 2)
 #endif
 
 #define DIRECT_THREADS 512

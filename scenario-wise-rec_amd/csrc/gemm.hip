@@ -1225,7 +1225,7 @@ static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps
     ta = static_cast<int>(swr_ceil_div(tiles1, pblk));
     const int qblk = static_cast<int>(swr_ceil_div(a.K2, 32 * TN_TB));
     const int64_t tiles = static_cast<int64_t>(pblk) * qblk * a.groups;
-    static const int waves_target = getenv("SWR_TN_WAVES") ? atoi(getenv("SWR_TN_WAVES")) : 1024;
+    constexpr int waves_target = 1024;
     int64_t want = std::max<int64_t>(1, waves_target / tiles);         // one wave per SIMD over the chip: measured 145 us vs 157 (2 per SIMD) and
                                                                        // 174 (4): more resident waves only thrash the dword-load path
     want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / 64));    // at least 64 rows per wave
@@ -1237,19 +1237,17 @@ static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps
 
 // bf16-split tn kernel: one group, A narrow enough to stage whole (<= 5 column tiles), 16-byte rows, a batch worth it
 static bool tn_x6_ok(const swr_gemm_tn_args& a) {
-    static const int off = getenv("SWR_TN_X6") ? atoi(getenv("SWR_TN_X6")) == 0 : 0;
-    return use_x6() && !off && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX * 32 && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
+    return use_x6() && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX * 32 && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
            a.ldb % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0 && a.M >= 4096 &&
            a.M * a.lda < (1ll << 31) && a.M * a.ldb < (1ll << 31);      // 32-bit element offsets inside the kernel
 }
 // ragged last column tile folded into the full 128-column blocks (see TnK): K2 = 128 j + r with j >= 1, 0 < r <= 32
 static bool tn_x6_tail(const swr_gemm_tn_args& a) {
-    static const int off = getenv("SWR_TN_X6_TAIL") ? atoi(getenv("SWR_TN_X6_TAIL")) == 0 : 0;
     const int r = a.K2 % TX_QCOLS;
-    return !off && a.K2 > TX_QCOLS && r > 0 && r <= 32;
+    return a.K2 > TX_QCOLS && r > 0 && r <= 32;
 }
 static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
-    static const int blocks_target = getenv("SWR_TN_X6_BLOCKS") ? atoi(getenv("SWR_TN_X6_BLOCKS")) : 256;   // one per CU
+    constexpr int blocks_target = 256;   // one per CU
     const int qblk = tn_x6_tail(a) ? a.K2 / TX_QCOLS : static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
     const int pblk = static_cast<int>(swr_ceil_div(swr_ceil_div(a.K1, 32), TN_TA_MAX));
     int64_t want = std::max<int64_t>(1, blocks_target / (qblk * pblk));

@@ -95,9 +95,6 @@ class SwrModule(nn.Module):
     def _install_touch_hooks(self, params):
         """Record which parameters took a gradient in the last backward: Adam must skip the others
         entirely (torch leaves their `.grad` None: PPNet's agn tables, ppnet.py:54)."""
-        import os
-        if os.environ.get("SWR_NO_TOUCH_HOOKS"):
-            return
         for p in params:
             if p.requires_grad and not hasattr(p, "_swr_hooked"):
                 p._swr_hooked = True

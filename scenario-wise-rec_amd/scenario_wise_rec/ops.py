@@ -16,7 +16,6 @@ from ._hip import lib
 
 
 import os
-DIRECT_GRADS = int(os.environ.get("SWR_DIRECT_GRADS", "7"))      # A/B bitmask (bench only): 1 W/b, 2 BN, 4 tables
 
 
 # =========================================================================== raw launchers
@@ -124,8 +123,6 @@ def _grad_alias(params, kind=1):
     """The `.grad` tensors of `params` as ONE tensor when they sit back to back in the gradient arena
     (basic/module.py), else None.  Backward kernels then accumulate straight into the arena instead of
     returning per-parameter gradients for autograd to add one tiny launch at a time."""
-    if not (DIRECT_GRADS & kind):
-        return None
     gs = []
     for p in params:
         if not p.is_leaf or not p.requires_grad:       # (derived tensors, e.g. STAR's effective weights: autograd carries those)
@@ -161,30 +158,19 @@ def _mark_touched(params):
 # 1. Embedding backward, sort half: grouping the large tables' entries by row needs only the lookup keys, so
 #    EmbedGather.forward forks it onto a side stream and the backward joins before its reduction.  A chain of a dozen
 #    latency-bound launches (~75 us) disappears behind the dense forward / backward.
-# 2. (SWR_SIDE_DW=1, off) weight gradients: nothing in the backward pass reads them, so the dW products that write
-#    straight into the gradient arena can be forked after dX is enqueued and joined when the autograd engine finishes
-#    (queue_callback).  Measured on config 2: the dW product fills the chip and only slows whatever it overlaps.
+# 2. Weight gradients of mid-size products (_fork_dw): nothing in the backward pass reads them, so a dW chain that writes
+#    straight into the gradient arena is forked after dX is enqueued and joined when the autograd engine finishes
+#    (queue_callback).
 # Under hipGraph capture the forks / joins become parallel branches of the graph.
-SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"
-PRESPLIT = os.environ.get("SWR_PRESPLIT", "0") == "1"      # weights pre-split into bf16 planes once per step: measured
-                                                             # 16 us SLOWER per step than splitting in every workgroup (opt-in)
-SIDE_DW = SIDE_STREAM and os.environ.get("SWR_SIDE_DW", "0") == "1"     # measured: the chip-filling dW product only slows
-                                                                        # whatever it is overlapped with; off by default
-SIDE_MODE = int(os.environ.get("SWR_SIDE_MODE", "4"))   # measured: 4 (edge at once, launches after the next main kernel) 0.700 ms,
-                                                        # 1 (fork at once) 0.709, 3 (edge and launches later) 0.711, 2 (event nodes) stalls the branch
-EXACT_ONEHOT = os.environ.get("SWR_EXACT_ONEHOT", "1") != "0"   # one-hot columns: three bf16 products instead of six
-SIDE_DW_MIN_FLOP = float(os.environ.get("SWR_SIDE_DW_MIN_FLOP", "2e9"))
-SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MAX_FLOP", "2e10"))  # weight-gradient products below this size run on a
-                                                                        # stream of their own (_fork_dw) next to the dX -> K3
-                                                                        # chain: 0.535 -> 0.506 ms at config 2 now that the
-                                                                        # product is half its round-1 size (round 1, on the SORT's
-                                                                        # side stream and joined by K3: no gain)
+SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"      # "0": everything on one stream (debugging aid; tests/test_graph_gpu.py)
+# weight-gradient products of 2e9 .. 2e10 flop run on a stream of their own (_fork_dw) next to the dX -> K3 chain: 0.535 ->
+# 0.506 ms at config 2; a fork / join pair costs ~10-20 us of edges, so smaller products stay on the main stream (forking
+# every product LOSES 0.02 ms at configs 1, 3, 4) and chip-filling ones only slow what they overlap
+SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = 2e9, 2e10
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
          "epoch": 0, "extras_ev": None}
-EPILOGUE_ACT = os.environ.get("SWR_EPILOGUE_ACT", "1") != "0"
-LATE_SORT_JOIN = os.environ.get("SWR_LATE_SORT_JOIN", "1") != "0"
 
 
 # ---- stream-skew harness (tests/test_skew_gpu.py): with a seed set (SWR_SKEW=<seed> or ops.set_skew(seed)) every fork
@@ -236,9 +222,8 @@ def _fork_extras():
         else:
             ent["buf"].copy_(ent["src"].t())
         ent["epoch"] = _side["epoch"]
-    if LATE_SORT_JOIN:
-        _side["extras_ev"] = torch.cuda.Event()
-        _side["extras_ev"].record(torch.cuda.current_stream())
+    _side["extras_ev"] = torch.cuda.Event()
+    _side["extras_ev"].record(torch.cuda.current_stream())
 
 
 def join_side_extras():
@@ -339,7 +324,7 @@ def _fork_side(dev, fn, after_event=None):
     everything enqueued so far on the current stream)."""
     side = _side_stream(dev)
     if isinstance(after_event, str):
-        pass                               # mode 4: the dependency was taken when the work was deferred
+        pass                               # the dependency was taken when the work was deferred (_defer_side)
     elif after_event is not None:
         side.wait_event(after_event)
     else:
@@ -352,24 +337,13 @@ def _fork_side(dev, fn, after_event=None):
 
 
 def _defer_side(dev, fn):
-    """Fork `fn` onto the side stream, but only AFTER the next kernel of the main stream has been enqueued
-    (`_flush_deferred()` is called by the GEMM launcher): launched immediately, the side kernels are dispatched
-    ahead of the main stream's next kernel and delay it by their launch latency.  The side work is ordered after
-    the point where `_defer_side` was called (an event recorded now)."""
-    if SIDE_MODE == 1:                 # immediate fork
-        _fork_side(dev, fn)
-        return
-    if SIDE_MODE == 4:                 # edge now, launches later: the side stream takes its dependency on the main stream
-        # HERE (after the gather), but its kernels are enqueued only after the main stream's next kernel -- in a
-        # captured graph the nodes of that kernel then come first in capture order
-        _side_stream(dev).wait_stream(torch.cuda.current_stream(dev))
-        _side["deferred"].append((dev, fn, "nowait"))
-        return
-    ev = None
-    if SIDE_MODE == 2:                 # deferred, ordered after an event recorded here
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-    _side["deferred"].append((dev, fn, ev))       # mode 3: deferred, ordered after the main stream's next kernel
+    """Fork `fn` onto the side stream: the side stream takes its dependency on the main stream HERE (after the gather),
+    but its kernels are enqueued only after the main stream's next kernel (`_flush_deferred()` is called by the GEMM
+    launcher) -- launched at once they are dispatched ahead of that kernel and delay it by their launch latency; in a
+    captured graph the main stream's kernel then comes first in capture order.  (Measured at config 2: this form 0.700
+    ms, fork at once 0.709, edge and launches both later 0.711, event-record nodes stall the branch until the join.)"""
+    _side_stream(dev).wait_stream(torch.cuda.current_stream(dev))
+    _side["deferred"].append((dev, fn, "nowait"))
 
 
 def _flush_deferred():
@@ -416,10 +390,13 @@ def _split_like(flat, tensors):
     return out
 
 
+_PREFOLD = {}       # (table pointers, lookup width) -> {"launch": closure, "Wf": buffer}: see EmbedGather.forward
+
+
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide", "prefold")
     # onehot: the caller promises that ONE LinearBNAct consumes the lookup (see OneHotInfo); oh: the block laid out by forward
     # bags: SequenceFeature lookups, dicts(wpos, idx [B, L], vocab, dim, col, L, mode 0 sum / 1 mean / 2 concat, pad, seed)
 
@@ -438,7 +415,7 @@ class OneHotInfo(object):
       * computes dX only for the columns of the other tables (`sel`), compactly, and passes it to the lookup's backward
         through `ctx` (autograd carries a zero-stride placeholder)."""
     __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact",
-                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K")
+                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K", "prefold")
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -539,6 +516,16 @@ class EmbedGather(Function):
         elif behind:
             from .optim import catchup_many
             catchup_many(behind)               # one claim + one replay launch for all large tables of the lookup
+        # folded first layer: its folded weights depend on parameters only, so the consuming layer's fold (registered by its
+        # first forward, LinearBNAct) is launched HERE on the side stream, beside the lookup, instead of between the lookup
+        # and the product (6 us of kernel + 5 us of launch gap off the critical path; the join is free: the fold has long
+        # finished when the 37 us lookup ends)
+        plan.prefold = None
+        if fold is not None and SIDE_STREAM and weights:
+            pf = _PREFOLD.get((tuple(w.data_ptr() for w in weights), plan.width))
+            if pf is not None:
+                _fork_side(dev, pf["launch"])
+                plan.prefold = pf
         need_keys = ctx.n_grad_slots > 0
         keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
         flag = H.err_flag(dev)
@@ -790,6 +777,7 @@ class LinearBNAct(Function):
         x_in = x
         nw = cfg["n_w"]
         Ws, rest = params[:nw], params[nw:]
+        cfg_params_w = Ws
         bs = rest[:nw] if cfg["has_bias"] else ()
         rest = rest[nw:] if cfg["has_bias"] else rest
         gammas, betas = (rest[:cfg["n_bn"]], rest[cfg["n_bn"]:]) if cfg["bn"] is not None else ((), ())
@@ -807,10 +795,8 @@ class LinearBNAct(Function):
         n_tiles = (M + 31) // 32
         partials = torch.empty((n_tiles, Ntot, 2), dtype=torch.float32, device=dev) if training else None
         planes = planes_t = None
-        if (PRESPLIT and G == 1 and M >= 4096 and K % 4 == 0 and K >= 32 and W.is_contiguous() and x.stride(0) % 4 == 0
-                and x.data_ptr() % 16 == 0):
-            # weights split into bf16 planes once per step (and W^T's planes for the dX product of the backward)
-            planes, planes_t = split_weights(W, bool(ctx.needs_input_grad[1]) and Ntot % 4 == 0)
+        # (weights pre-split into bf16 planes once per step -- ops.split_weights + gemm(B_split=...) -- were measured 16 us
+        # per step SLOWER at config 2 than the split inside every workgroup; the entry points stay, the layers do not use them)
         oh_in = getattr(x_in, "_swr_onehot", None)
         if oh_in is not None and oh_in.fold:
             # the lookup wrote [E_big | dense | one-hot] only (OneHotInfo / include/swr.h "folded first layer"): multiply
@@ -819,21 +805,33 @@ class LinearBNAct(Function):
                 raise H.SwrError("a lookup made with onehot=True must feed ONE ungrouped Linear over all its columns")
             Kf = oh_in.Kp + oh_in.oh_width
             x = oh_in.wide[:, oh_in.col0:oh_in.col0 + Kf]
-            Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
-            tabs = (H.OnehotTable * len(oh_in.tables_p))()
-            for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
-                tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
-            H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
-                                                 H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
-                    "swr_fold_first_layer_fwd")
-            gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp if EXACT_ONEHOT else 0)
+            pf = getattr(oh_in, "prefold", None)
+            if pf is not None and pf["W_ptr"] == W.data_ptr() and pf["shape"] == (Ntot, Kf):
+                Wf = pf["Wf"]                      # launched beside the lookup (EmbedGather.forward): wait for that branch only
+                torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+            else:
+                Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
+                tabs = (H.OnehotTable * len(oh_in.tables_p))()
+                for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
+                    tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
+
+                def fold_now(Wf=Wf, tabs=tabs, W=W, oh=oh_in, Ntot=Ntot, K=K, Kf=Kf):
+                    H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh.Kp, oh.oh_width, H.ptr(oh.src),
+                                                         H.ptr(oh.inv), H.ptr(oh.ohtab), tabs, len(oh.tables_p), H.ptr(Wf), Kf, H.stream()),
+                            "swr_fold_first_layer_fwd")
+                fold_now()
+                if SIDE_STREAM and W.is_contiguous() and _grad_alias(list(cfg_params_w), 1) is not None and len(_PREFOLD) < 16:
+                    # parameters living in the arena keep their addresses: from the next step on the lookup launches this fold
+                    key = (tuple(w.data_ptr() for w in oh_in.ctx.weights), oh_in.K)
+                    _PREFOLD[key] = {"launch": fold_now, "Wf": Wf, "W_ptr": W.data_ptr(), "shape": (Ntot, Kf)}
+            gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp)
             planes_t = None
             epi_act = 0
         else:
             # a layer without BatchNorm whose columns all take the same ReLU / sigmoid: applied while the product is stored
             na = _norm_acts(cfg["acts"], Ntot)
             epi_act = 0
-            if (EPILOGUE_ACT and cfg["bn"] is None and na and na[0][2] in ("relu", "sigmoid")
+            if (cfg["bn"] is None and na and na[0][2] in ("relu", "sigmoid")
                     and all(r[2] == na[0][2] for r in na)
                     and sorted((r[0], r[1]) for r in na)[0][0] == 0
                     and all(a_[1] == b_[0] for a_, b_ in zip(sorted((r[0], r[1]) for r in na), sorted((r[0], r[1]) for r in na)[1:]))
@@ -999,7 +997,7 @@ class LinearBNAct(Function):
                     gsC=N * K, gsColsum=N, ldc=K)
         # (a fork / join pair costs ~10-20 us of edges: only a product worth several of those goes to its own stream --
         # measured: forking every small product LOSES 0.02 ms at configs 1, 3 and 4)
-        side_dw = direct_w and SIDE_STREAM and (SIDE_DW or SIDE_DW_MIN_FLOP <= 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP)
+        side_dw = direct_w and SIDE_STREAM and SIDE_DW_MIN_FLOP <= 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP
         late_dw = direct_w and _late["on"] and ctx.needs_input_grad[1] and not side_dw
         if late_dw:
             _late["jobs"].append(launch_dw)       # split backward: dX first, this product after the row lists are out

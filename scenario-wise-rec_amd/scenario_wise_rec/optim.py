@@ -276,10 +276,6 @@ class FusedAdam(torch.optim.Optimizer):
                         r[6].append(it[6])
                         continue
                 runs.append([it[0], it[1], it[2], it[3], it[4], it[5], [it[6]]])
-            if os.environ.get("SWR_DEBUG_ADAM"):
-                print(f"[adam] dense params {len(dense)} runs {[(r[4]) for r in runs]} sparse {len(sparse)} "
-                      f"untouched {sum(1 for p in group['params'] if p.grad is not None and not getattr(p, '_swr_touched', True))}",
-                      file=sys.stderr, flush=True)
             if self.lazy_rows and len(runs) == 1 and len(sparse) == 1 and runs[0][4] > 0 and sparse[0][1][0].numel() > 0:
                 # one arena + one large table (config 2): both updates in one launch
                 p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep = runs[0]

@@ -25,7 +25,6 @@ import torch.distributed as dist
 
 from . import ops
 
-AG_AFTER_LAUNCH = os.environ.get("SWR_DP_AG_AFTER_LAUNCH", "1") != "0"
 
 
 def allreduce_min_bytes():
@@ -369,7 +368,7 @@ class DataParallelStep(object):
             self.trainer.optimizer.note_replays(1)
         g1.replay()
         rows = bool(xb["offs"])
-        if rows and AG_AFTER_LAUNCH:
+        if rows:
             # the row lists leave now, while the rest of the gradients is computed -- but the collective is ENQUEUED after the
             # second graph, from the merge stream, ordered behind an event recorded here: issued between the two graph
             # launches, its stream synchronisation kept the second graph's first kernel waiting ~30 us
@@ -383,14 +382,7 @@ class DataParallelStep(object):
                 work.wait()
                 self._merge_rows(xb, self._big)                                 # needs only this all-gather: hidden too
         else:
-            if rows:
-                work = dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group, async_op=True)
-                self._merge_stream.wait_stream(cur)                             # (after the previous step's readers)
             g1b.replay()
-            if rows:
-                with torch.cuda.stream(self._merge_stream):
-                    work.wait()
-                    self._merge_rows(xb, self._big)
         self._send_dense(xb, self._arena_g, pack=False)
         if rows:
             cur.wait_stream(self._merge_stream)

@@ -141,7 +141,7 @@ class CTRTrainer(object):
         return self._local_step(x_dict, y)
 
     def _local_step(self, x_dict, y):
-        if hasattr(self.optimizer, "advance_early") and os.environ.get("SWR_EARLY_ADVANCE", "1") != "0":
+        if hasattr(self.optimizer, "advance_early"):
             ops.add_side_job(self.optimizer.advance_early)      # the step-counter launch leaves the critical path too
         loss = self.forward_backward(x_dict, y)
         self.optimizer.step()

@@ -60,34 +60,6 @@ def dump_gradients(model):
     return out
 
 
-def take_turns_on_the_gpu(step, tr, lock_path):
-    """8 processes sharing ONE GPU are time-sliced by the driver (queue oversubscription, wave save / restore in the
-    middle of kernels, concurrent code-object loads) -- a regime the product never runs in (one process per GPU) and
-    in which ~3 % of runs on the test pool die with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in some rank.  The 8-rank test
-    is about the world-8 ARITHMETIC (split backward, two all-gathers, merge of 8 row lists, rank-ordered mean), so its
-    ranks take turns: every GPU phase of the step runs under a cross-process file lock and drains before releasing
-    it; the collectives run outside the lock.  The 2-rank tests stay unserialised (stream-ordering coverage)."""
-    import fcntl
-    from scenario_wise_rec import ops
-
-    def guarded(fn):
-        def run(*a, **k):
-            with open(lock_path, "w") as f:
-                fcntl.flock(f, fcntl.LOCK_EX)
-                try:
-                    r = fn(*a, **k)
-                    torch.cuda.synchronize()
-                    return r
-                finally:
-                    fcntl.flock(f, fcntl.LOCK_UN)
-        return run
-    step._forward_backward = guarded(step._forward_backward)
-    step._merge_rows = guarded(step._merge_rows)
-    step._mean_dense = guarded(step._mean_dense)
-    tr.optimizer.step = guarded(tr.optimizer.step)
-    ops.run_late_jobs = guarded(ops.run_late_jobs)
-
-
 def main():
     mode, name, out_dir = sys.argv[1:4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -173,8 +145,6 @@ def main():
                         device="cuda:0")
         step = DataParallelStep(tr, world)
         model.train()
-        if os.environ.get("DP_TAKE_TURNS"):
-            take_turns_on_the_gpu(step, tr, os.path.join(out_dir, "gpu.lock"))
         if mode == "graph-gpu":
             # two captured graphs + eager collectives; the captured step must land where the eager one does.
             # capture() runs 2 eager warm-up steps, so compare after 3 steps in total on the same batch.

@@ -1172,3 +1172,23 @@ def test_mul_sigmoid_against_torch(n, offset):
     torch.testing.assert_close(a.grad.double(), a64.grad, rtol=1e-6, atol=1e-6)
     # (1 - y) is formed in fp32 from y, as in the two-kernel path and in torch's own sigmoid backward: absolute, not relative
     torch.testing.assert_close(z.grad.double(), z64.grad, rtol=0, atol=2e-6 * float(z64.grad.abs().max()) + 1e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 148, 276), (5000, 96, 132)])
+def test_gemm_presplit_weights_give_the_same_bits(M, N, K):
+    """ops.split_weights + gemm(B_split=...): the weights' bf16 planes made once (swr_split_weights) instead of inside every
+    workgroup -- the same three terms per value, so the product must be bit-identical; the W^T planes serve the dX form."""
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(M + K)
+    A = _dev(rng.standard_normal((M, K)).astype(np.float32))
+    W = _dev(rng.standard_normal((N, K)).astype(np.float32))
+    planes, planes_t = ops.split_weights(W, True)
+    C0, C1 = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    ops.gemm("nt", A, W, C0, M, N, K)
+    ops.gemm("nt", A, W, C1, M, N, K, B_split=planes)
+    assert torch.equal(C0, C1)
+    G = _dev(rng.standard_normal((M, N)).astype(np.float32))
+    D0, D1 = torch.empty((M, K), device="cuda"), torch.empty((M, K), device="cuda")
+    ops.gemm("nt", G, W.t().contiguous(), D0, M, K, N)
+    ops.gemm("nt", G, W, D1, M, K, N, ldb=N, B_split=planes_t)
+    assert torch.equal(D0, D1)

@@ -29,13 +29,16 @@ GPU_FAULT_RETRIES = []      # (mode, case, world, rank, first line of the fault)
 def run_workers(mode, case, world, extra=(), env_extra=None, _attempt=0):
     """Launch `world` worker processes and wait for them.
 
-    A rank that dies of a GPU FAULT raised by the runtime (`HSA_STATUS_ERROR_*`, "Memory access fault") -- not of a Python
-    exception, not of a wrong number -- makes the whole group run again, at most twice.  Measured on the MI355X test
-    pool (round 2, 360 runs of the 8-rank test = 2 880 process launches sharing one GPU): 9 launches aborted with
-    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION before or during their first kernels, with the ranks time-slicing the GPU and
-    with the ranks taking turns on it alike, while the same binaries never faulted in single-process runs.  One process
-    per GPU is the product's regime; several processes on one GPU exist only in these tests.  A numerical mismatch is
-    never retried."""
+    A rank that dies of a GPU FAULT raised by the runtime (`HSA_STATUS_ERROR_*`, "Memory access fault": the process is
+    aborted by the driver) -- not of a Python exception, not of a wrong number -- makes the whole group run again, at most
+    twice, and the retry is recorded (GPU_FAULT_RETRIES, printed).  History: round 2 saw 9 such aborts + 2 garbage-gradient
+    runs in 360 runs of the 8-rank test on the shared test pool and answered with this retry and with ranks taking turns on
+    the GPU.  Round 3 looked for a cause instead: (i) the stream-skew harness (tests/test_skew_gpu.py, and the `rows_skewed`
+    case below) stretches every fork of the step's stream graph against the others -- all families, eager and captured,
+    bit-identical; (ii) tools/dp8_soak.py ran this 8-rank step 145 times un-serialised, 60 times with the skew harness on
+    and a PyTorch-only control 145 times, no retry: 0 faults, 0 failures in 2 800 process launches
+    (profiles/r03_dp8_soak.txt).  The ranks therefore no longer take turns; the retry stays for runtime aborts only, as a
+    guard against the pool, and a numerical mismatch is never retried."""
     out = tempfile.mkdtemp()
     port = _free_port()
     procs = []
@@ -77,7 +80,7 @@ def test_two_ranks_full_hip_step(name, world, limit, allreduce):
     """limit=2048 bytes forces every table above 32 rows x 16 onto the row-sparse exchange; the 8-rank case (all ranks
     on cuda:0, gloo) runs the split backward, both all-gathers and the sort-free merge at the world size of a full
     node against the reference's 8-shard DataParallel result."""
-    env = {"DP_TAKE_TURNS": "1"} if world > 2 else {}                               # (see dp_worker.take_turns_on_the_gpu)
+    env = {}
     if allreduce:
         env["SWR_DP_ALLREDUCE_BYTES"] = "0"        # the arena goes through dist.all_reduce (parallel.allreduce_min_bytes)
     out = run_workers("full-gpu", name, world, extra=() if limit is None else (str(limit),), env_extra=env or None)
