@@ -138,7 +138,6 @@ def _run_plan(plan, weights):
         info.compact, info.n_sel = compact, len(cols)
         info.sel = _sel_tensor(tuple(cols), out.device) if cols else None
         info.fold, info.wide, info.K = plan.fold is not None, plan.wide, plan.width
-        info.prefold = getattr(plan, "prefold", None)
         if plan.fold is not None:
             f = plan.fold
             info.col0, info.Kp = f["col0"], f["Kp"]

@@ -294,7 +294,34 @@ def join_side_streams(dw=True):
 
 # weight-gradient branch: the dW chain of the first layer (product + reduce + unfold + small-table gradients) has no
 # consumer before the optimizer, and the dX -> K3 chain does not depend on it
-_dw = {"streams": {}, "pending": 0}
+_dw = {"streams": {}, "pending": 0, "riders": []}
+
+
+def _ride_dw(fn, keep):
+    """A SMALL weight-gradient product (the towers' grouped dW: 17 + 5 us at config 2) that nothing in the backward pass
+    reads: instead of running where autograd reaches it -- on the critical path, ahead of the expert level's backward -- it
+    waits for the first layer's weight-gradient branch (_fork_dw) and runs there, behind that product, at no extra fork /
+    join edge.  Without such a branch in this backward it runs on the main stream when autograd finishes.  `keep`:
+    tensors it reads, held until the join."""
+    _dw["riders"].append(fn)
+    _side["keep"].append(keep)
+    if not _side["queued"]:
+        _side["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+
+
+def _in_backward():
+    """True while the autograd engine is running a backward pass on this thread (queue_callback is only legal there)."""
+    try:
+        return torch._C._current_graph_task_id() >= 0
+    except AttributeError:
+        return False
+
+
+def _run_dw_riders():
+    riders, _dw["riders"] = _dw["riders"], []
+    for fn in riders:
+        fn()
 
 
 def _fork_dw(dev, fn, keep):
@@ -306,6 +333,7 @@ def _fork_dw(dev, fn, keep):
     with torch.cuda.stream(st):
         _skew(3)
         fn()
+        _run_dw_riders()
     _skew(4)
     _dw["pending"] += 1
     _side["keep"].append(keep)
@@ -316,6 +344,7 @@ def _fork_dw(dev, fn, keep):
 
 def _join_side():
     _side["queued"] = False
+    _run_dw_riders()              # (no weight-gradient branch was forked in this backward: they run here)
     join_side_streams()
 
 
@@ -390,13 +419,10 @@ def _split_like(flat, tensors):
     return out
 
 
-_PREFOLD = {}       # (table pointers, lookup width) -> {"launch": closure, "Wf": buffer}: see EmbedGather.forward
-
-
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide", "prefold")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide")
     # onehot: the caller promises that ONE LinearBNAct consumes the lookup (see OneHotInfo); oh: the block laid out by forward
     # bags: SequenceFeature lookups, dicts(wpos, idx [B, L], vocab, dim, col, L, mode 0 sum / 1 mean / 2 concat, pad, seed)
 
@@ -415,7 +441,7 @@ class OneHotInfo(object):
       * computes dX only for the columns of the other tables (`sel`), compactly, and passes it to the lookup's backward
         through `ctx` (autograd carries a zero-stride placeholder)."""
     __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact",
-                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K", "prefold")
+                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K")
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -516,16 +542,6 @@ class EmbedGather(Function):
         elif behind:
             from .optim import catchup_many
             catchup_many(behind)               # one claim + one replay launch for all large tables of the lookup
-        # folded first layer: its folded weights depend on parameters only, so the consuming layer's fold (registered by its
-        # first forward, LinearBNAct) is launched HERE on the side stream, beside the lookup, instead of between the lookup
-        # and the product (6 us of kernel + 5 us of launch gap off the critical path; the join is free: the fold has long
-        # finished when the 37 us lookup ends)
-        plan.prefold = None
-        if fold is not None and SIDE_STREAM and weights:
-            pf = _PREFOLD.get((tuple(w.data_ptr() for w in weights), plan.width))
-            if pf is not None:
-                _fork_side(dev, pf["launch"])
-                plan.prefold = pf
         need_keys = ctx.n_grad_slots > 0
         keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
         flag = H.err_flag(dev)
@@ -667,6 +683,8 @@ class EmbedGather(Function):
                                                           nbytes, H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce_part")
                 reduce_part(1)
                 _late["jobs"].append(lambda: reduce_part(2))
+            # (measured and dropped: the sorted reduce + row lists on the weight-gradient branch while the direct sums stay
+            # here -- the two halves are independent when no dense table is sorted -- 0.524 vs 0.494 ms per step)
             else:
                 H.check(lib.swr_embed_bwd_reduce(slots, ns, H.ptr(ctx.keys), H.ptr(dE), dE.stride(0), B, H.ptr(ws), nbytes,
                                                  H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce")
@@ -777,7 +795,6 @@ class LinearBNAct(Function):
         x_in = x
         nw = cfg["n_w"]
         Ws, rest = params[:nw], params[nw:]
-        cfg_params_w = Ws
         bs = rest[:nw] if cfg["has_bias"] else ()
         rest = rest[nw:] if cfg["has_bias"] else rest
         gammas, betas = (rest[:cfg["n_bn"]], rest[cfg["n_bn"]:]) if cfg["bn"] is not None else ((), ())
@@ -805,25 +822,15 @@ class LinearBNAct(Function):
                 raise H.SwrError("a lookup made with onehot=True must feed ONE ungrouped Linear over all its columns")
             Kf = oh_in.Kp + oh_in.oh_width
             x = oh_in.wide[:, oh_in.col0:oh_in.col0 + Kf]
-            pf = getattr(oh_in, "prefold", None)
-            if pf is not None and pf["W_ptr"] == W.data_ptr() and pf["shape"] == (Ntot, Kf):
-                Wf = pf["Wf"]                      # launched beside the lookup (EmbedGather.forward): wait for that branch only
-                torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
-            else:
-                Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
-                tabs = (H.OnehotTable * len(oh_in.tables_p))()
-                for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
-                    tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
-
-                def fold_now(Wf=Wf, tabs=tabs, W=W, oh=oh_in, Ntot=Ntot, K=K, Kf=Kf):
-                    H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh.Kp, oh.oh_width, H.ptr(oh.src),
-                                                         H.ptr(oh.inv), H.ptr(oh.ohtab), tabs, len(oh.tables_p), H.ptr(Wf), Kf, H.stream()),
-                            "swr_fold_first_layer_fwd")
-                fold_now()
-                if SIDE_STREAM and W.is_contiguous() and _grad_alias(list(cfg_params_w), 1) is not None and len(_PREFOLD) < 16:
-                    # parameters living in the arena keep their addresses: from the next step on the lookup launches this fold
-                    key = (tuple(w.data_ptr() for w in oh_in.ctx.weights), oh_in.K)
-                    _PREFOLD[key] = {"launch": fold_now, "Wf": Wf, "W_ptr": W.data_ptr(), "shape": (Ntot, Kf)}
+            # (launching this fold on the side stream beside the lookup -- it depends on parameters only -- was measured: the
+            # extra fork / join pair costs more than the 6 us it hides, 0.4988 vs 0.4937 ms per step)
+            Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
+            tabs = (H.OnehotTable * len(oh_in.tables_p))()
+            for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
+                tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
+            H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
+                                                 H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
+                    "swr_fold_first_layer_fwd")
             gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp)
             planes_t = None
             epi_act = 0
@@ -1203,8 +1210,13 @@ def _tower_backward(ctx, saved, dV=None, sel=None):
     if not direct_w:
         dW1 = torch.empty((N, K), dtype=torch.float32, device=dev)
         db1 = torch.empty(N, dtype=torch.float32, device=dev)
-    gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
-            ldc=K)
+    def launch_dw1():
+        gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
+                ldc=K)
+    if direct_w and SIDE_STREAM and not _late["on"] and _in_backward():
+        _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
+    else:
+        launch_dw1()
     grads = []
     if direct_w:
         _mark_touched(p_W1 + p_b1)
