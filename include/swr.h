@@ -58,6 +58,9 @@ typedef enum {
 #define SWR_FLAG_GRAD_RANGE 2u     /* |embedding grad| >= 2^20: outside the fixed-point accumulator */
 
 int swr_abi_version(void);
+/* Zero-fill of `bytes` at a 16-byte aligned address as an ordinary kernel (model.zero_grad() of the gradient arena,
+ * `ctr_trainer.py:71`; hipMemsetAsync nodes misbehaved under back-to-back hipGraph replays on ROCm 7.2). */
+int swr_zero(void* p, size_t bytes, void* stream);
 /* Test instrument (tests/test_skew_gpu.py): keeps `stream` busy for `us` microseconds with one idle-spinning wave.  The
  * Python layer injects it at its stream forks when SWR_SKEW is set, to expose missing cross-stream dependencies. */
 int swr_spin_us(int us, void* stream);
@@ -148,7 +151,10 @@ int swr_embed_bag_bwd_expand(const float* d_out, int64_t ld, int in_col, int dim
  * of W's column c, or -1 - t for a column of small table t (index into `tables`).  tables[t].grad = emb_t here. */
 int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, int ohw, const int32_t* src_col,
                              const int32_t* inv_col, const int32_t* oh_table /* [ohw] (device): table of one-hot column o, -1 = padding */,
-                             const swr_onehot_table* tables_host, int n_tables, float* Wp, int64_t ldwp, void* stream);
+                             const swr_onehot_table* tables_host, int n_tables, float* Wp, int64_t ldwp,
+                             const int64_t* sel /* nullable: [n_sel] columns of W (device) */, int n_sel,
+                             float* Wt_sel /* [n_sel, ldt]: Wt_sel[r, n] = W[n, sel[r]], the operand of the backward's dX product */,
+                             int64_t ldt, void* stream);
 int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const float* dbp /* nullable */, int N, int K, int Kp, int ohw,
                              const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables_host,
                              int n_tables, float* dW, int64_t lddw, float* db /* nullable */, int accumulate, void* stream);

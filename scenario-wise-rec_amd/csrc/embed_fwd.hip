@@ -334,6 +334,7 @@ struct FoldK {
     const int32_t* inv_col;             // [K] : compact column of W's column k, or -1 - t for a column of small table t
     const float* W; int64_t ldw;
     float* Wp; int64_t ldwp;            // forward: folded weights [N, Kp + ohw]
+    const int64_t* sel; int n_sel; float* Wt; int64_t ldt;   // forward: rows `sel` of W^T for the backward's dX product (nullable)
     const float* dWp; int64_t lddwp;    // backward: gradient of the folded weights
     const float* dbp;                   // backward: bias gradient (column sums of dZ), nullable
     float* dW; int64_t lddw; float* db;
@@ -344,8 +345,16 @@ struct FoldK {
 // from `oh_table`, not from a search)
 __global__ __launch_bounds__(GATHER_THREADS) void fold_fwd_kernel(const FoldK k, const int32_t* __restrict__ oh_table) {
     const int width = k.Kp + k.ohw;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x;
-    if (i >= static_cast<int64_t>(k.N) * width) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x;
+    if (i >= static_cast<int64_t>(k.N) * width) {
+        // the tail of the grid transposes the selected columns of W (thread = one element, consecutive lanes along n)
+        i -= static_cast<int64_t>(k.N) * width;
+        if (i < static_cast<int64_t>(k.n_sel) * k.N) {
+            const int r = static_cast<int>(i / k.N), n = static_cast<int>(i - static_cast<int64_t>(r) * k.N);
+            k.Wt[r * k.ldt + n] = k.W[n * k.ldw + k.sel[r]];
+        }
+        return;
+    }
     const int n = static_cast<int>(i / width), j = static_cast<int>(i - static_cast<int64_t>(n) * width);
     float v = 0.f;
     if (j < k.Kp) {
@@ -410,13 +419,16 @@ static int fold_fill(FoldK& k, const swr_onehot_table* tables, int n_tables, int
 
 extern "C" int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, int ohw, const int32_t* src_col,
                                         const int32_t* inv_col, const int32_t* oh_table, const swr_onehot_table* tables,
-                                        int n_tables, float* Wp, int64_t ldwp, void* stream) {
+                                        int n_tables, float* Wp, int64_t ldwp, const int64_t* sel, int n_sel, float* Wt_sel,
+                                        int64_t ldt, void* stream) {
     FoldK k;
     int rc = fold_fill(k, tables, n_tables, N, K, Kp, ohw, src_col, inv_col, W, ldw);
     if (rc != SWR_OK) return rc;
     SWR_REQUIRE(W && Wp && oh_table && ldwp >= Kp + ohw, SWR_ERR_ARG);
+    SWR_REQUIRE(n_sel >= 0 && (n_sel == 0 || (sel && Wt_sel && ldt >= N)), SWR_ERR_ARG);
     k.Wp = Wp; k.ldwp = ldwp;
-    const int64_t total = static_cast<int64_t>(N) * (Kp + ohw);
+    k.sel = sel; k.n_sel = n_sel; k.Wt = Wt_sel; k.ldt = ldt;
+    const int64_t total = static_cast<int64_t>(N) * (Kp + ohw) + static_cast<int64_t>(n_sel) * N;
     hipLaunchKernelGGL(fold_fwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(total, GATHER_THREADS))), dim3(GATHER_THREADS), 0,
                        static_cast<hipStream_t>(stream), k, oh_table);
     return swr_launch_status();

@@ -952,6 +952,12 @@ int swr_zero_async(void* p, size_t bytes, hipStream_t st) {
     return swr_launch_status();
 }
 
+// zero_grad of the gradient arena (SwrModule.zero_grad) as a kernel node of this library, like every other zero-fill
+extern "C" int swr_zero(void* p, size_t bytes, void* stream) {
+    SWR_REQUIRE(p != nullptr || bytes == 0, SWR_ERR_ARG);
+    return swr_zero_async(p, bytes, static_cast<hipStream_t>(stream));
+}
+
 // Stream-skew harness (tests/test_skew_gpu.py, SWR_SKEW): one wave that occupies its stream for `us` microseconds
 // (wall_clock64 ticks at 100 MHz).  Injected at the fork points of the step (ops._skew) it stretches one branch of the
 // stream graph against the others: a missing cross-stream edge then shows as a changed bit in the results.

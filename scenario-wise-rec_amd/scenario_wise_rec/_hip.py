@@ -172,11 +172,12 @@ _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _SIGS = {
     "swr_abi_version": (C.c_int, []),
     "swr_spin_us": (C.c_int, [C.c_int, _P]),
+    "swr_zero": (C.c_int, [_P, _Z, _P]),
     "swr_status_str": (C.c_char_p, [_I]),
     "swr_device_available": (C.c_int, []),
     "swr_embed_gather_fwd": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _P]),
     "swr_embed_gather_fwd_onehot": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P]),
-    "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P]),
     "swr_fold_first_layer_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P, _I, _P]),
     "swr_onehot_table_grads": (C.c_int, [_P, _L, _P, _L, _I, _P, _I, _I, _P]),
     "swr_adam_catchup_multi": (C.c_int, [_P, _I, _P, _P, _P]),

@@ -145,7 +145,12 @@ class SwrModule(nn.Module):
         a = self.arena()
         if a is None:
             return super().zero_grad(set_to_none)
-        a["g"].zero_()
+        g = a["g"]
+        if g.is_cuda and g.data_ptr() % 16 == 0:
+            from .. import _hip as H
+            H.check(H.lib.swr_zero(H.ptr(g), g.numel() * 4, H.stream()), "swr_zero")
+        else:
+            g.zero_()
         for p, off, n in a["spans"]:
             if p.requires_grad:
                 if p.grad is None or p.grad.data_ptr() != a["g"].data_ptr() + 4 * off:

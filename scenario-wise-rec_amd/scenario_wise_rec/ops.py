@@ -812,6 +812,7 @@ class LinearBNAct(Function):
         n_tiles = (M + 31) // 32
         partials = torch.empty((n_tiles, Ntot, 2), dtype=torch.float32, device=dev) if training else None
         planes = planes_t = None
+        ctx.wt_sel = None
         # (weights pre-split into bf16 planes once per step -- ops.split_weights + gemm(B_split=...) -- were measured 16 us
         # per step SLOWER at config 2 than the split inside every workgroup; the entry points stay, the layers do not use them)
         oh_in = getattr(x_in, "_swr_onehot", None)
@@ -828,9 +829,16 @@ class LinearBNAct(Function):
             tabs = (H.OnehotTable * len(oh_in.tables_p))()
             for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
                 tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
+            # (the same launch transposes the columns of W the backward's dX product multiplies with: no W^T copy on the
+            # forward-time fork, no cross-stream edge in front of dX)
+            want_t = bool(ctx.needs_input_grad[1]) and oh_in.n_sel > 0 and Ntot % 4 == 0
+            Wt_sel = torch.empty((oh_in.n_sel, Ntot), dtype=torch.float32, device=dev) if want_t else None
             H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
-                                                 H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf, H.stream()),
+                                                 H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf,
+                                                 H.ptr(oh_in.sel) if want_t else None, oh_in.n_sel if want_t else 0,
+                                                 H.ptr(Wt_sel), Ntot, H.stream()),
                     "swr_fold_first_layer_fwd")
+            ctx.wt_sel = Wt_sel
             gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp)
             planes_t = None
             epi_act = 0
@@ -1016,7 +1024,8 @@ class LinearBNAct(Function):
             # ctx, autograd carries a zero-stride placeholder of the right shape
             if oh.n_sel > 0:
                 dsel = torch.empty((M, oh.n_sel), dtype=torch.float32, device=dev)
-                gemm("nt", dZ, _selected_wt(W, oh.sel), dsel, M, oh.n_sel, Ntot)
+                wt = getattr(ctx, "wt_sel", None)
+                gemm("nt", dZ, wt if wt is not None else _selected_wt(W, oh.sel), dsel, M, oh.n_sel, Ntot)
             else:
                 dsel = dZ
             oh.ctx.fused_dx = (dsel, oh.compact)
