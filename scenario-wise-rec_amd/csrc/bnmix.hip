@@ -38,6 +38,17 @@ __device__ __forceinline__ float4 relu4(float4 v) {
     return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
+// sum over the H4N (4 or 8) adjacent lanes of a row, every lane gets it: DPP moves instead of ds_bpermute round trips.
+// Same additions as the xor-1, -2, -4 butterfly (the last step pairs lane i with 7 - i, whose quad already holds the other
+// quad's sum: own + other either way), so the bits are those of the butterfly.
+template <int H4N>
+__device__ __forceinline__ float row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    if (H4N == 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
 // gate probabilities of one row: g[o*NE + j] = softmax_j(scale * z + shift), same operation order as act_fwd4 (bn.hip)
 template <int NE, int DD, bool EXACT>
 __device__ __forceinline__ void gate_probs(const swr_bnmix_args& a, const float* __restrict__ zg, const float* __restrict__ gsc,
@@ -69,6 +80,14 @@ __device__ __forceinline__ void gate_probs(const swr_bnmix_args& a, const float*
 template <int NE, int DD, bool EXACT>
 __device__ __forceinline__ void gate_probs_saved(const swr_bnmix_args& a, const float* __restrict__ gs, float (&g)[DD * NE]) {
     const int ne = EXACT ? NE : a.ne, D = EXACT ? DD : a.D;
+    if constexpr (EXACT && (DD * NE) % 4 == 0) {                  // rows of 16-byte multiples (swr_bnmix_bwd checks the base)
+#pragma unroll
+        for (int q = 0; q < DD * NE / 4; ++q) {
+            const float4 v = ldf4(gs + 4 * q);
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < DD; ++o)
 #pragma unroll
@@ -77,11 +96,11 @@ __device__ __forceinline__ void gate_probs_saved(const swr_bnmix_args& a, const 
 }
 
 // ------------------------------------------------------------------------------------------- forward
-template <int NE, int DD, bool EXACT>
+template <int NE, int DD, bool EXACT, int H4N>
 __global__ __launch_bounds__(256) void bnmix_fwd_kernel(const BnMixK kk) {
     const swr_bnmix_args& a = kk.a;
     const int ne = EXACT ? NE : a.ne, D = EXACT ? DD : a.D;
-    const int h4n = kk.h4n;
+    constexpr int h4n = H4N;                                     // compile time: the lane / row arithmetic is shifts
     const int lane = threadIdx.x % h4n;
     const int h = lane * 4;
     const int rows_per_pass = 256 / h4n;
@@ -105,11 +124,26 @@ __global__ __launch_bounds__(256) void bnmix_fwd_kernel(const BnMixK kk) {
         gate_probs<NE, DD, EXACT>(a, z + gc, a.scale + gc, a.shift + gc, g);
         if (a.G) {                                               // keep the probabilities for the backward pass
             float* __restrict__ gs = a.G + m * (D * ne);
+            if constexpr (EXACT) {
+                // lane l keeps columns l, l + H4N, ...: one select chain and ONE store per group of H4N columns (a store
+                // per (o, j) under its own lane predicate was 20 exec-masked stores per thread)
+                constexpr int NQ = (DD * NE + H4N - 1) / H4N;
 #pragma unroll
-            for (int o = 0; o < DD; ++o)
+                for (int q = 0; q < NQ; ++q) {
+                    float v = 0.f;
 #pragma unroll
-                for (int j = 0; j < NE; ++j)
-                    if ((EXACT || (o < D && j < ne)) && (o * ne + j) % h4n == lane) gs[o * ne + j] = g[o * NE + j];
+                    for (int u = 0; u < H4N; ++u)
+                        if (q * H4N + u < DD * NE) v = lane == u ? g[(q * H4N + u < DD * NE) ? q * H4N + u : 0] : v;
+                    const int c = q * H4N + lane;
+                    if (c < DD * NE) gs[c] = v;
+                }
+            } else {
+#pragma unroll
+                for (int o = 0; o < DD; ++o)
+#pragma unroll
+                    for (int j = 0; j < NE; ++j)
+                        if ((o < D && j < ne) && (o * ne + j) % h4n == lane) gs[o * ne + j] = g[o * NE + j];
+            }
         }
         float* __restrict__ p = a.P + m * a.ldp + h;
 #pragma unroll
@@ -132,12 +166,13 @@ __global__ __launch_bounds__(256) void bnmix_fwd_kernel(const BnMixK kk) {
 
 // ------------------------------------------------------------------------------------------ backward
 // workgroup = one 64-row tile, 64 * H/4 threads.  LDS: the tile's dY and dY * xhat, [64][n_cols + 4] floats each.
-template <int NE, int DD, bool EXACT>
-__global__ void bnmix_bwd_kernel(const BnMixK kk) {
+template <int NE, int DD, bool EXACT, int H4N>
+__global__ __launch_bounds__(BM_ROWS * H4N, NE <= 4 ? 4 : 2) void bnmix_bwd_kernel(const BnMixK kk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const swr_bnmix_args& a = kk.a;
     const int ne = EXACT ? NE : a.ne, D = EXACT ? DD : a.D;
-    const int h4n = kk.h4n, N = kk.n_cols, P = N + 4;
+    constexpr int h4n = H4N;
+    const int N = kk.n_cols, P = N + 4;
     float* t1 = lds;                     // dY
     float* t2 = lds + BM_ROWS * P;       // dY * xhat
     const int lane = threadIdx.x % h4n, r = threadIdx.x / h4n;
@@ -178,16 +213,30 @@ __global__ void bnmix_bwd_kernel(const BnMixK kk) {
                     dx[j].x = fmaf(gj, v.x, dx[j].x); dx[j].y = fmaf(gj, v.y, dx[j].y);
                     dx[j].z = fmaf(gj, v.z, dx[j].z); dx[j].w = fmaf(gj, v.w, dx[j].w);
                     float pd = (v.x * x[j].x + v.y * x[j].y) + (v.z * x[j].z + v.w * x[j].w);
-                    for (int off = 1; off < h4n; off <<= 1) pd += __shfl_xor(pd, off);
-                    dg[o * NE + j] = pd;
+                    dg[o * NE + j] = row_sum<H4N>(pd);
                 }
             }
+        }
+    }
+    // ---- the gate columns this lane will finish (q * H4N + lane): their pre-activations and statistics are fetched
+    // here, unconditionally and together, and land under the expert columns' section (they used to sit inside 20
+    // divergent single-lane branches, each exposing a full load latency)
+    constexpr int NQ = (DD * NE + H4N - 1) / H4N;
+    float zq[NQ], muq[NQ], rsq[NQ];
+    if constexpr (EXACT) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = gc + min(q * H4N + lane, DD * NE - 1);
+            zq[q] = z[c]; muq[q] = a.mean[c]; rsq[q] = a.rstd[c];
         }
     }
     // ---- expert columns: dY = relu'(.) dx; stage dY and dY * xhat, write dY
     float* row1 = t1 + r * P;
     float* row2 = t2 + r * P;
     float* __restrict__ dyrow = a.dY + mm * a.lddy;
+    // The statistics of expert j + 1 are requested BEFORE expert j's dY store: the compiler may not move a load of a.mean
+    // above a store to a.dY (they could alias), so in the plain loop every iteration began with an exposed load latency.
+    float4 mu = ldf4(a.mean + h), rs = ldf4(a.rstd + h);
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
         if (EXACT || j < ne) {
@@ -195,17 +244,48 @@ __global__ void bnmix_bwd_kernel(const BnMixK kk) {
             float4 d = make_float4(x[j].x > 0.f ? dx[j].x : 0.f, x[j].y > 0.f ? dx[j].y : 0.f, x[j].z > 0.f ? dx[j].z : 0.f,
                                    x[j].w > 0.f ? dx[j].w : 0.f);
             if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 mu = ldf4(a.mean + c), rs = ldf4(a.rstd + c);
+            const float4 mu_c = mu, rs_c = rs;
+            if (j + 1 < NE && (EXACT || j + 1 < ne)) {
+                mu = ldf4(a.mean + c + a.H);
+                rs = ldf4(a.rstd + c + a.H);
+            }
             *reinterpret_cast<float4*>(row1 + c) = d;
-            *reinterpret_cast<float4*>(row2 + c) = make_float4(d.x * ((ze[j].x - mu.x) * rs.x), d.y * ((ze[j].y - mu.y) * rs.y),
-                                                               d.z * ((ze[j].z - mu.z) * rs.z), d.w * ((ze[j].w - mu.w) * rs.w));
+            *reinterpret_cast<float4*>(row2 + c) =
+                make_float4(d.x * ((ze[j].x - mu_c.x) * rs_c.x), d.y * ((ze[j].y - mu_c.y) * rs_c.y),
+                            d.z * ((ze[j].z - mu_c.z) * rs_c.z), d.w * ((ze[j].w - mu_c.w) * rs_c.w));
             if (valid) *reinterpret_cast<float4*>(dyrow + c) = d;
         }
     }
     // ---- gate columns: softmax backward dZg[o][j] = g (dg - <dg_o, g_o>); lane (o*ne + j) % h4n keeps column o*ne + j
+    if constexpr (EXACT) {
+        float dgz[DD * NE];
+#pragma unroll
+        for (int o = 0; o < DD; ++o) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) dot = fmaf(dg[o * NE + j], g[o * NE + j], dot);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) dgz[o * NE + j] = g[o * NE + j] * (dg[o * NE + j] - dot);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float d = 0.f;
+#pragma unroll
+            for (int u = 0; u < H4N; ++u)
+                if (q * H4N + u < DD * NE) d = lane == u ? dgz[(q * H4N + u < DD * NE) ? q * H4N + u : 0] : d;
+            if (!valid) d = 0.f;
+            const int cq = q * H4N + lane;
+            if (cq < DD * NE) {
+                const int c = gc + cq;
+                row1[c] = d;
+                row2[c] = d * ((zq[q] - muq[q]) * rsq[q]);
+                if (valid) dyrow[c] = d;
+            }
+        }
+    } else
 #pragma unroll
     for (int o = 0; o < DD; ++o) {
-        if (EXACT || o < D) {
+        if (o < D) {
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < NE; ++j)
@@ -265,30 +345,41 @@ static int bnmix_common(const swr_bnmix_args* args, BnMixK& kk) {
 // exact (compile-time) expert / output counts for the common small configurations, predicated kernels otherwise
 #define BM_EXACT_LIST(X) X(2, 2) X(2, 3) X(3, 2) X(3, 3) X(4, 2) X(4, 3) X(4, 4) X(4, 5) X(4, 6) X(8, 5)
 
-static void bnmix_launch_fwd(const BnMixK& kk, dim3 grid, hipStream_t st) {
+template <int H4N>
+static void bnmix_launch_fwd_h(const BnMixK& kk, dim3 grid, hipStream_t st) {
     const int key = kk.a.ne * 16 + kk.a.D;
     switch (key) {
-#define X(NEV, DV) case NEV * 16 + DV: hipLaunchKernelGGL((bnmix_fwd_kernel<NEV, DV, true>), grid, dim3(256), 0, st, kk); return;
+#define X(NEV, DV) case NEV * 16 + DV: hipLaunchKernelGGL((bnmix_fwd_kernel<NEV, DV, true, H4N>), grid, dim3(256), 0, st, kk); return;
         BM_EXACT_LIST(X)
 #undef X
         default: break;
     }
     if (kk.a.ne <= 4)
-        hipLaunchKernelGGL((bnmix_fwd_kernel<4, BM_MAX_D, false>), grid, dim3(256), 0, st, kk);
+        hipLaunchKernelGGL((bnmix_fwd_kernel<4, BM_MAX_D, false, H4N>), grid, dim3(256), 0, st, kk);
     else
-        hipLaunchKernelGGL((bnmix_fwd_kernel<8, BM_MAX_D, false>), grid, dim3(256), 0, st, kk);
+        hipLaunchKernelGGL((bnmix_fwd_kernel<8, BM_MAX_D, false, H4N>), grid, dim3(256), 0, st, kk);
 }
 
-static const void* bnmix_bwd_fn(int ne, int D) {
+static void bnmix_launch_fwd(const BnMixK& kk, dim3 grid, hipStream_t st) {
+    if (kk.h4n == 8) bnmix_launch_fwd_h<8>(kk, grid, st);
+    else bnmix_launch_fwd_h<4>(kk, grid, st);
+}
+
+template <int H4N>
+static const void* bnmix_bwd_fn_h(int ne, int D) {
     const int key = ne * 16 + D;
     switch (key) {
-#define X(NEV, DV) case NEV * 16 + DV: return reinterpret_cast<const void*>(bnmix_bwd_kernel<NEV, DV, true>);
+#define X(NEV, DV) case NEV * 16 + DV: return reinterpret_cast<const void*>(bnmix_bwd_kernel<NEV, DV, true, H4N>);
         BM_EXACT_LIST(X)
 #undef X
         default: break;
     }
-    return ne <= 4 ? reinterpret_cast<const void*>(bnmix_bwd_kernel<4, BM_MAX_D, false>)
-                   : reinterpret_cast<const void*>(bnmix_bwd_kernel<8, BM_MAX_D, false>);
+    return ne <= 4 ? reinterpret_cast<const void*>(bnmix_bwd_kernel<4, BM_MAX_D, false, H4N>)
+                   : reinterpret_cast<const void*>(bnmix_bwd_kernel<8, BM_MAX_D, false, H4N>);
+}
+
+static const void* bnmix_bwd_fn(int ne, int D, int h4n) {
+    return h4n == 8 ? bnmix_bwd_fn_h<8>(ne, D) : bnmix_bwd_fn_h<4>(ne, D);
 }
 
 extern "C" int swr_bnmix_fwd(const swr_bnmix_args* args, void* stream) {
@@ -311,12 +402,12 @@ extern "C" int swr_bnmix_bwd(const swr_bnmix_args* args, void* stream) {
     const swr_bnmix_args& a = kk.a;
     SWR_REQUIRE(a.dP && a.lddp >= a.D * a.H && a.mean && a.rstd && a.dY && a.lddy >= kk.n_cols && a.bn_partials, SWR_ERR_ARG);
     SWR_REQUIRE(a.lddp % 4 == 0 && a.lddy % 4 == 0 && swr_aligned16(a.dP) && swr_aligned16(a.dY) && swr_aligned16(a.mean) &&
-                    swr_aligned16(a.rstd), SWR_ERR_ALIGN);
+                    swr_aligned16(a.rstd) && (a.G == nullptr || swr_aligned16(a.G)), SWR_ERR_ALIGN);
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(a.M, BM_ROWS));
     const unsigned threads = static_cast<unsigned>(BM_ROWS * kk.h4n);
     const size_t lds = 2 * static_cast<size_t>(BM_ROWS) * (kk.n_cols + 4) * sizeof(float);
     SWR_REQUIRE(lds <= 159 * 1024, SWR_ERR_UNSUPPORTED);
-    const void* fn = bnmix_bwd_fn(a.ne, a.D);
+    const void* fn = bnmix_bwd_fn(a.ne, a.D, kk.h4n);
     // more than 64 KB of dynamic LDS needs the attribute (idempotent, not a stream operation); the first call of a
     // configuration happens in a warm-up step, before any hipGraph capture
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)

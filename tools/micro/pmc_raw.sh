@@ -13,7 +13,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 for name, _d, c, v in rows:
     per[name.split("(")[0]][c].append(v)
 for k, cs in per.items():
-    if "rows3" in k or "segsum" in k or "tn3" in k:
+    if any(s in k for s in ("rows3", "segsum", "tn3", "bnmix", "tower", "act_bwd")):
         print(k[:48], {c: round(sum(v) / len(v)) for c, v in sorted(cs.items())})
 PY
 rm -rf $O/pmcr_$tag

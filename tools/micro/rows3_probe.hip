@@ -245,7 +245,19 @@ typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 #define ALOAD(dst, base, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(base) : "memory")
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <bool IL, int EPI>
+// ABL (ablation of the main loop, timing only): 1 = no A loads in the loop, 2 = no B DMA in the loop, 4 = no barriers,
+// 8 = no LDS reads (B fragments taken from registers)
+// PIPE: the B fragments are read with inline-asm ds_read_b128 one (group, tile) item ahead of the MFMAs that use them, with hand-counted
+// s_waitcnt lgkmcnt(3) (hipcc waits lgkmcnt(0) right after every read it emits: the LDS latency of every item is exposed)
+#define LDSREAD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ void lds_read3(u32x4 (&b)[3], uint32_t addr) {
+    LDSREAD(b[0], addr, OFF); LDSREAD(b[1], addr, OFF + 1024); LDSREAD(b[2], addr, OFF + 2048);
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4 (&b)[3]) {      // the fragments become usable only after the wait
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+}
+template <bool IL, int EPI, int ABL = 0, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void rows3_fwd_v3(const uint4* __restrict__ A3, const uint4* __restrict__ B3,
                                                        float* __restrict__ Z, int ldz, float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];      // [2][CHUNK_PAD_U4]
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void rows3_fwd_v3(const uint4* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    const uint32_t lds_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)lds)) + lane * 16;
     uint4 ar[4][3];
     // blocks of group g: 3 g + p (g < G3) or 3 G3 + g - G3; each 1 KB = 64 uint4: the immediate offset reaches +-4 KB
     auto a_group = [&](auto g_c, uint4 (&dst)[3]) {
@@ -293,7 +306,48 @@ __global__ __launch_bounds__(256, 2) void rows3_fwd_v3(const uint4* __restrict__
 
     auto chunk = [&](auto c_c) {
         constexpr int C = decltype(c_c)::value, BUF = C & 1;
-        if constexpr (C + 1 < NG / 2) dma_chunk(C + 1, BUF ^ 1);
+        if constexpr (C + 1 < NG / 2 && !(ABL & 2)) dma_chunk(C + 1, BUF ^ 1);
+        if constexpr (PIPE) {
+            u32x4 bq[2][3];
+            constexpr int BASE = BUF * CHUNK_PAD_U4 * 16;
+            auto rd = [&](auto j_c) {
+                constexpr int J = decltype(j_c)::value, OFF = BASE + ((J / NT) * NT + (J % NT)) * 3 * 1024;
+                lds_read3<OFF>(bq[J & 1], lds_lane);
+            };
+            auto item = [&](auto j_c) {
+                constexpr int J = decltype(j_c)::value, GQ = J / NT, TT = J % NT, G = 2 * C + GQ, SLOT = 2 * BUF + GQ;
+                constexpr bool exact = G >= G3;
+                if constexpr (J + 1 < 2 * NT) {
+                    rd(std::integral_constant<int, J + 1>{});
+                    wait_lgkm<3>(bq[J & 1]);
+                } else {
+                    wait_lgkm<0>(bq[J & 1]);
+                }
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, ar[SLOT][0]);
+                const bf16x8 am = __builtin_bit_cast(bf16x8, ar[SLOT][1]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, ar[SLOT][2]);
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[J & 1][0]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, bq[J & 1][1]);
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, bq[J & 1][2]);
+                f32x16 c_ = acc[TT];
+                if (!exact) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0, c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, c_, 0, 0, 0);
+                if (!exact) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1, c_, 0, 0, 0);
+                if (!exact) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0, c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1, c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0, c_, 0, 0, 0);
+                acc[TT] = c_;
+                if constexpr (TT == NT - 1) {
+                    __builtin_amdgcn_sched_barrier(0);   // the slot's MFMAs are issued before its registers are re-loaded
+                    if constexpr (!(ABL & 1)) a_group(std::integral_constant<int, 2 * C + 4 + GQ>{}, ar[SLOT]);
+                }
+            };
+            rd(std::integral_constant<int, 0>{});
+            item(std::integral_constant<int, 0>{}); item(std::integral_constant<int, 1>{}); item(std::integral_constant<int, 2>{});
+            item(std::integral_constant<int, 3>{}); item(std::integral_constant<int, 4>{}); item(std::integral_constant<int, 5>{});
+            item(std::integral_constant<int, 6>{}); item(std::integral_constant<int, 7>{}); item(std::integral_constant<int, 8>{});
+            item(std::integral_constant<int, 9>{});
+        } else
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq) {
             const int g = 2 * C + gq;
@@ -331,9 +385,10 @@ __global__ __launch_bounds__(256, 2) void rows3_fwd_v3(const uint4* __restrict__
             } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
+                bf16x8 b0 = (ABL & 8) ? am : __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
+                bf16x8 b1 = (ABL & 8) ? al : __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
+                bf16x8 b2 = (ABL & 8) ? ah : __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
+                if (ABL & 8) asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));      // opaque: the five tiles are not merged
                 f32x16 c_ = acc[t];
                 if (!exact) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0, c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, c_, 0, 0, 0);
@@ -345,12 +400,14 @@ __global__ __launch_bounds__(256, 2) void rows3_fwd_v3(const uint4* __restrict__
             }
             }
             __builtin_amdgcn_sched_barrier(0);       // the slot's MFMAs are issued before its registers are re-loaded
-            if (gq == 0) a_group(std::integral_constant<int, 2 * C + 4>{}, ar[2 * BUF]);
-            else a_group(std::integral_constant<int, 2 * C + 5>{}, ar[2 * BUF + 1]);
+            if constexpr (!(ABL & 1)) {
+                if (gq == 0) a_group(std::integral_constant<int, 2 * C + 4>{}, ar[2 * BUF]);
+                else a_group(std::integral_constant<int, 2 * C + 5>{}, ar[2 * BUF + 1]);
+            }
         }
         // everything but the A loads issued in THIS chunk has landed: the DMA of chunk C + 1 and the A blocks of chunk C + 1
-        wait_vm<n_loads(2 * C + 4) + n_loads(2 * C + 5)>();
-        __builtin_amdgcn_s_barrier();
+        wait_vm<(ABL & 1) ? 0 : n_loads(2 * C + 4) + n_loads(2 * C + 5)>();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
     chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
@@ -466,7 +523,15 @@ int main() {
     typedef void (*kfn)(const uint4*, const uint4*, float*, int, float*);
     struct { const char* name; kfn fn; bool check; } vs[] = {
         {"v3 chain  / direct stores", rows3_fwd_v3<false, 0>, true}, {"v3 chain  / LDS rows + 16-B stores", rows3_fwd_v3<false, 1>, true},
-        {"v3 chain  / no stores", rows3_fwd_v3<false, 2>, false}, {"v3 interleaved / LDS rows", rows3_fwd_v3<true, 1>, true}};
+        {"v3 chain  / no stores", rows3_fwd_v3<false, 2>, false}, {"v3 interleaved / LDS rows", rows3_fwd_v3<true, 1>, true},
+        {"v3 pipelined B reads / LDS rows", rows3_fwd_v3<false, 1, 0, true>, true},
+        {"v3 pipelined B reads / no stores", rows3_fwd_v3<false, 2, 0, true>, false},
+        {"  pipelined, no stores, no loads, no barriers", rows3_fwd_v3<false, 2, 7, true>, false},
+        {"  no stores, no A loads", rows3_fwd_v3<false, 2, 1>, false}, {"  no stores, no B DMA", rows3_fwd_v3<false, 2, 2>, false},
+        {"  no stores, no A loads, no B DMA", rows3_fwd_v3<false, 2, 3>, false},
+        {"  no stores, no loads, no barriers", rows3_fwd_v3<false, 2, 7>, false},
+        {"  no stores, MFMA only", rows3_fwd_v3<false, 2, 15>, false},
+        {"  no stores, loads but no barriers", rows3_fwd_v3<false, 2, 4>, false}};
     for (auto& v : vs) {
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         auto run = [&](int j) {
