@@ -22,6 +22,10 @@
 #define TW_THREADS 256
 #endif
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// shapes the matrix-pipe paths take: whole 16-wide column tiles, k fragments of whole 16-byte pieces
+#define TW_MFMA_OK(K, H) ((K) % 16 == 0 && (H) % 16 == 0 && TW_THREADS % 64 == 0)
+
 struct TowerK {
     swr_tower_args a;
     float* bn_partials;     // [tiles of 64 rows][G*H][2]   (sum dY, sum dY * xhat)
@@ -92,6 +96,46 @@ __global__ __launch_bounds__(TW_THREADS) void tower_linear_fwd_kernel(const Towe
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
     const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
     const bool valid = static_cast<int>(threadIdx.x) < rows;
+    if constexpr (TW_MFMA_OK(K, H)) {
+        // ---- the product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation).  The
+        // scalar path below stages X through a [256][K + 4] LDS tile (four workgroups per CU for the five a CU owes at the
+        // KuaiRand shape: a second, quarter-full round) and reads every weight through an LDS broadcast once per WAVE
+        // (H*K/4 ds_read_b128 per wave: 18 us of LDS pipe).  Here a wave keeps the tower's W1 in K/4 * H/16 registers and
+        // takes its A fragments straight from HBM: lane group kq holds k = KS*kq .. KS*kq + KS - 1 of row n (k is permuted
+        // the same way in both operands), so the four groups of a row read one contiguous 4*K-byte piece.  LDS holds only
+        // the Z1 tile (coalesced stores, statistics): every workgroup of the launch is resident at once.
+        constexpr int KS = K / 4, CT = H / 16, RT = 4;                     // k steps, column tiles, 16-row tiles per wave (64 rows)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int n = lane & 15, kq = lane >> 4;
+        float af[RT][KS];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int64_t m = min<int64_t>(m0 + wave * 64 + 16 * t + n, a.M - 1);
+            load_row<KS / 4>(a.X + m * a.ldx + static_cast<int64_t>(g) * K + KS * kq, af[t]);
+        }
+        float bf[CT][KS], bias[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)                       // (4-byte loads: a parameter view need not be 16-byte aligned)
+                bf[ct][ks] = a.W1[(static_cast<int64_t>(g) * H + 16 * ct + n) * K + KS * kq + ks];
+            bias[ct] = a.b1 ? a.b1[g * H + 16 * ct + n] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 acc = {bias[ct], bias[ct], bias[ct], bias[ct]};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], bf[ct][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                     // D[row 4 kq + r][column n]
+                    const int row = wave * 64 + 16 * t + 4 * kq + r;
+                    lz[row * PZ + 16 * ct + n] = row < rows ? acc[r] : 0.f;
+                }
+            }
+        }
+    } else {
     float* lw = lds + TW_THREADS * (PX > PZ ? PX : PZ);       // [H][K] weights of this tower (+ [H] biases)
     tile_load<K>(a.X + m0 * a.ldx + static_cast<int64_t>(g) * K, a.ldx, rows, lx);
     for (int i = threadIdx.x; i < H * K; i += TW_THREADS) lw[i] = a.W1[static_cast<int64_t>(g) * H * K + i];
@@ -108,6 +152,7 @@ __global__ __launch_bounds__(TW_THREADS) void tower_linear_fwd_kernel(const Towe
 #pragma unroll
         for (int k = 0; k < K; ++k) acc = fmaf(x[k], lw[j * K + k], acc);
         lz[threadIdx.x * PZ + j] = valid ? acc : 0.f;
+    }
     }
     __syncthreads();
     tile_store<H>(a.Z1 + m0 * a.ldz + g * H, a.ldz, rows, lz);
@@ -252,12 +297,85 @@ template <int K, int H>
 __global__ __launch_bounds__(TW_THREADS) void tower_bwd_apply_kernel(const TowerK kk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PX = K + 4, PZ = H + 4;
-    float* lz = lds;                                          // [TW_THREADS][PZ]: Z1 in, dZ1 out (in place)
-    float* lx = lds;                                          // [TW_THREADS][PX]: dX out, after dZ1 has left
     const swr_tower_args& a = kk.a;
     const int g = blockIdx.y;
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * TW_THREADS;
     const int rows = static_cast<int>(min<int64_t>(TW_THREADS, a.M - m0));
+    if constexpr (TW_MFMA_OK(H, K)) {
+        // ---- matrix-pipe path (see tower_linear_fwd_kernel).  dZ1 is computed directly in the A-fragment layout -- lane
+        // (n, kq) owns hidden units KS*kq .. KS*kq + KS - 1 of row n of each 16-row tile, with the same operations in the
+        // same order as the scalar path -- from Z1 read straight from HBM (the four lane groups of a row read one
+        // contiguous 4*H-byte piece) and stored the same way; dX_g = dZ1_g W1_g leaves through a wave-private 16-row
+        // staging tile (16-byte coalesced stores).  9 KB of LDS instead of 39: the launch is resident at once.
+        constexpr int KS = H / 4, CT = K / 16, RT = 4;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int n = lane & 15, kq = lane >> 4;
+        float sc[KS], sh[KS], w2[KS], cb[KS], mu[KS], ca[KS], cc[KS];
+        {
+            const int c0 = g * H + KS * kq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                     // (4-byte loads: parameter views need not be 16-byte aligned)
+                sc[ks] = a.scale[c0 + ks]; sh[ks] = a.shift[c0 + ks]; w2[ks] = a.w2[c0 + ks]; cb[ks] = a.cb[c0 + ks];
+                mu[ks] = a.mean[c0 + ks];  ca[ks] = a.ca[c0 + ks];    cc[ks] = a.cc[c0 + ks];
+            }
+        }
+        float bf[CT][KS];                                         // B[k = hidden KS*kq + s][column 16 ct + n] = W1[hidden][column]
+        if (a.dX) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    bf[ct][ks] = a.W1[(static_cast<int64_t>(g) * H + KS * kq + ks) * K + 16 * ct + n];
+        }
+        float dz[RT][KS];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int row = wave * 64 + 16 * t + n;
+            const bool ok = row < rows;
+            const int64_t m = min<int64_t>(m0 + row, a.M - 1);
+            load_row<KS / 4>(a.Z1 + m * a.ldz + g * H + KS * kq, dz[t]);
+            const float dv = ok ? tower_dv(a, m, g) : 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float zj = dz[t][ks];
+                const float pre = fmaf(zj, sc[ks], sh[ks]);
+                const float dy = pre > 0.f ? dv * w2[ks] : 0.f;
+                dz[t][ks] = fmaf(cb[ks], zj - mu[ks], dy * ca[ks]) + cc[ks];
+            }
+            if (ok) {
+                float* o = a.dZ1 + m * a.lddz + g * H + KS * kq;
+#pragma unroll
+                for (int q = 0; q < KS / 4; ++q)
+                    *reinterpret_cast<float4*>(o + 4 * q) = make_float4(dz[t][4 * q], dz[t][4 * q + 1], dz[t][4 * q + 2], dz[t][4 * q + 3]);
+            }
+        }
+        if (!a.dX) return;
+        float* stage = lds + wave * (16 * PX);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[t][ks], bf[ct][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[(4 * kq + r) * PX + 16 * ct + n] = acc[r];
+            }
+            __builtin_amdgcn_wave_barrier();                      // (same wave: the LDS queue is in order; this only pins hipcc)
+            constexpr int Q = K / 4;
+#pragma unroll
+            for (int u = 0; u < 16 * Q / 64; ++u) {
+                const int idx = lane + 64 * u, r = idx / Q, c = idx - r * Q;
+                const int row = wave * 64 + 16 * t + r;
+                const float4 v = *reinterpret_cast<const float4*>(stage + r * PX + 4 * c);
+                if (row < rows) *reinterpret_cast<float4*>(a.dX + (m0 + row) * a.lddx + static_cast<int64_t>(g) * K + 4 * c) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    float* lz = lds;                                          // [TW_THREADS][PZ]: Z1 in, dZ1 out (in place)
+    float* lx = lds;                                          // [TW_THREADS][PX]: dX out, after dZ1 has left
     const bool valid = static_cast<int>(threadIdx.x) < rows;
     float* lw = lds + TW_THREADS * (PX > PZ ? PX : PZ);       // [H][K] weights, then 7 x [H] per-column coefficients
     float* lc = lw + H * K;
@@ -271,10 +389,10 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_apply_kernel(const Tower
     }
     const float dv = valid ? tower_dv(a, m0 + threadIdx.x, g) : 0.f;
     __syncthreads();
+    float* zrow = lz + threadIdx.x * PZ;
     float dx[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) dx[k] = 0.f;
-    float* zrow = lz + threadIdx.x * PZ;
 #pragma unroll 2
     for (int j = 0; j < H; ++j) {
         const float zj = valid ? zrow[j] : 0.f;
@@ -340,7 +458,9 @@ extern "C" int swr_tower_supported(int K, int H) { return tower_shape_ok(K, H) ?
 
 template <int K, int H>
 static void launch_linear_fwd(const TowerK& kk, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((tower_linear_fwd_kernel<K, H>), grid, dim3(TW_THREADS), (TW_THREADS * ((K > H ? K : H) + 4) + H * K + H) * sizeof(float), st, kk);
+    const size_t lds = TW_MFMA_OK(K, H) ? TW_THREADS * (H + 4) * sizeof(float)
+                                        : (TW_THREADS * ((K > H ? K : H) + 4) + H * K + H) * sizeof(float);
+    hipLaunchKernelGGL((tower_linear_fwd_kernel<K, H>), grid, dim3(TW_THREADS), lds, st, kk);
 }
 template <int H>
 static void launch_head_fwd(const TowerK& kk, dim3 grid, hipStream_t st) {
@@ -352,7 +472,9 @@ static void launch_bwd_stats(const TowerK& kk, dim3 grid, hipStream_t st) {
 }
 template <int K, int H>
 static void launch_bwd_apply(const TowerK& kk, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((tower_bwd_apply_kernel<K, H>), grid, dim3(TW_THREADS), (TW_THREADS * ((K > H ? K : H) + 4) + H * K + 7 * H) * sizeof(float), st, kk);
+    const size_t lds = TW_MFMA_OK(H, K) ? (TW_THREADS / 64) * 16 * (K + 4) * sizeof(float)
+                                        : (TW_THREADS * ((K > H ? K : H) + 4) + H * K + 7 * H) * sizeof(float);
+    hipLaunchKernelGGL((tower_bwd_apply_kernel<K, H>), grid, dim3(TW_THREADS), lds, st, kk);
 }
 
 static int tower_common(const swr_tower_args* args) {

@@ -7,7 +7,7 @@ DataParallel sharding)."""
 import numpy as np
 import pytest
 
-from _golden import Case, assert_probs_close, case_names, make_oracle, state_atol
+from _golden import Case, assert_probs_close, case_names, make_oracle, assert_state_close
 from oracle.optim import Adam
 
 
@@ -47,8 +47,7 @@ def test_train_step_grads_and_state(name):
                 if k.endswith("num_batches_tracked"):
                     assert int(m.state[k]) == int(v), k
                 else:
-                    np.testing.assert_allclose(m.state[k], v, rtol=1e-4, atol=state_atol(c, k, s + 1),
-                                               err_msg=f"step{s + 1}:{k}")
+                    assert_state_close(m.state[k], v, c, k, s + 1)
     np.testing.assert_allclose(losses, c.z["losses"], rtol=2e-5)
     x, _ = c.batch(0)
     assert_probs_close(m.predict(x), c.z["eval3_probs"], tol=1e-4)
@@ -105,4 +104,4 @@ def test_torch_port_matches_the_oracle():
         if k.endswith("num_batches_tracked"):
             assert int(got) == int(v)
         else:
-            np.testing.assert_allclose(got, v, rtol=1e-4, atol=state_atol(c, k, 1), err_msg=k)
+            assert_state_close(got, v, c, k, 1)

@@ -12,7 +12,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from _golden import Case, state_atol
+from _golden import Case, assert_state_close
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -121,7 +121,7 @@ def test_two_ranks_full_hip_step(name, world, limit, allreduce):
         if k.endswith("num_batches_tracked"):
             assert int(got[k]) == int(v)
         else:
-            np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=state_atol(c, k, 1), err_msg=k)
+            assert_state_close(got[k], v, c, k, 1)
 
 
 @pytest.mark.gpu
@@ -151,7 +151,7 @@ def test_ctrtrainer_gpus_argument_runs_data_parallel():
         if k.endswith("num_batches_tracked"):
             assert int(got[k]) == int(v)
         else:
-            np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=state_atol(c, k, 1), err_msg=k)
+            assert_state_close(got[k], v, c, k, 1)
     a = run_workers("trainer-gpu", "mmoe_dp2", 2, extra=("4",))
     b = run_workers("trainer-gpu", "mmoe_dp2", 2, extra=("4",), env_extra={"DP_EAGER_REFERENCE": "1"})
     ga, gb = np.load(os.path.join(a, "state1.npz")), np.load(os.path.join(b, "state1.npz"))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import Case, assert_probs_close, build_product_model, case_names, state_atol, to_device
+from _golden import Case, assert_probs_close, build_product_model, case_names, assert_state_close, to_device
 
 pytestmark = pytest.mark.gpu
 SINGLE = [n for n in case_names() if "_dp" not in n]
@@ -71,8 +71,7 @@ def test_train_three_steps(name):
                 if k.endswith("num_batches_tracked"):
                     assert int(got[k]) == int(v), k
                 else:
-                    np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=state_atol(c, k, s + 1),
-                                               err_msg=f"step{s + 1}:{k}")
+                    assert_state_close(got[k], v, c, k, s + 1)
     H.check_errors()
     np.testing.assert_allclose(losses, c.z["losses"], rtol=5e-5)
     model.eval()
