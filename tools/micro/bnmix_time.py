@@ -61,5 +61,5 @@ for name, fn, mb in (("bnmix_fwd", lib.swr_bnmix_fwd, (N + D * Hh + D * ne) * 4 
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
-    print(f"{name}: {us:.1f} us per launch, {mb:.0f} MB algorithmic -> {mb / us / 1e3 * 1e3:.0f} GB/s")
+    print(f"{name}: {us:.1f} us per launch, {mb:.0f} MB algorithmic -> {mb / us:.2f} TB/s")
 print("checksum", float(dY[0].double().abs().sum()), float(part.double().abs().sum()), float(P[0].double().abs().sum()))
