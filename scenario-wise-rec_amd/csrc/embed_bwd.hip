@@ -40,12 +40,16 @@
                        // table does not serialise its atomics on one address (16 -> 4 stripes: -8 us of zero-fill and finalise per step at config 2)
 #endif
 
+#ifndef DIRECT_THREADS
 #define DIRECT_THREADS 512
+#endif
 #define DIRECT_CAP_ELEMS 4096     // (hi, lo) int64 accumulator pairs per workgroup = 64 KB of LDS, 2 workgroups per CU
 #define DIRECT_MAX_PARTS 8        // a table larger than the cap is cut into row ranges, one workgroup column each
 #define DIRECT_MAX_MEMBERS 72
 #define DIRECT_MAX_GROUPS 48
+#ifndef DIRECT_TARGET
 #define DIRECT_TARGET 32768       // (sample, column) elements per workgroup
+#endif
 
 struct DirectMember {
     int64_t acc_off;      // dense accumulator offset of (row_lo, column 0) of the member's table
