@@ -531,8 +531,9 @@ typedef struct {
  * inv_bc2_sqrt) to hist[s % hist_cap] -- a ring; the lazy row updates below replay them.  The caller must flush every
  * lazily updated table (swr_adam_flush) before any of its rows lags hist_cap - 1 steps. */
 int swr_adam_advance(swr_adam_hyper* hyper_dev, float* hist, int64_t hist_cap, void* stream);
-/* dense update of a flat fp32 arena */
-int swr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n,
+/* dense update of a flat fp32 arena; clear_grad != 0: g is zeroed behind the update (the optimizer consumed it: the next
+ * step's zero_grad -- optimizer.zero_grad(), ctr_trainer.py:71 -- then has nothing to fill) */
+int swr_adam_dense(float* p, float* g, float* m, float* v, int64_t n, int clear_grad,
                    const swr_adam_hyper* hyper_dev, void* stream);
 /* large tables with row-sparse gradients (mode 1 of swr_embed_bwd): touched rows take the summed
  * gradient, every other row takes g = weight_decay * p -- together exactly the dense update the
@@ -543,7 +544,7 @@ int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int dim,
                   uint32_t* bitmap /* sweep mode, nullable */, int32_t* last /* lazy mode, nullable */,
                   const swr_adam_hyper* hyper_dev, void* stream);
 /* swr_adam_dense + swr_adam_rows (lazy mode) in ONE launch: the common step of one parameter arena + one large table */
-int swr_adam_dense_rows(float* dense_p, const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n,
+int swr_adam_dense_rows(float* dense_p, float* dense_g, float* dense_m, float* dense_v, int64_t dense_n, int clear_grad,
                         float* p, float* m, float* v, int64_t vocab, int dim,
                         const int32_t* urow, const float* ugrad, int64_t n_entries, int32_t* last,
                         const swr_adam_hyper* hyper_dev, void* stream);

@@ -43,24 +43,28 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p -= h.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(AD_THREADS) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
+// clear_grad: the gradient is consumed -- zero it behind the update, so that the next step's zero_grad has nothing to fill
+// (its launch sat on a side branch the backward pass had to wait for)
+__global__ __launch_bounds__(AD_THREADS) void adam_dense_kernel(float* __restrict__ p, float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                                const swr_adam_hyper* __restrict__ hp) {
+                                                                int clear_grad, const swr_adam_hyper* __restrict__ hp) {
     const swr_adam_hyper h = *hp;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * AD_THREADS;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x; i < n; i += stride) {
         float pi = p[i], mi = m[i], vi = v[i];
         adam_elem(pi, g[i], mi, vi, h);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        if (clear_grad) g[i] = 0.f;
     }
 }
 
-extern "C" int swr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const swr_adam_hyper* hyper,
+extern "C" int swr_adam_dense(float* p, float* g, float* m, float* v, int64_t n, int clear_grad, const swr_adam_hyper* hyper,
                               void* stream) {
     SWR_REQUIRE(p && g && m && v && hyper && n >= 0, SWR_ERR_ARG);
     if (n == 0) return SWR_OK;
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(n, AD_THREADS) < 4096 ? swr_ceil_div(n, AD_THREADS) : 4096);
-    hipLaunchKernelGGL(adam_dense_kernel, dim3(grid), dim3(AD_THREADS), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, hyper);
+    hipLaunchKernelGGL(adam_dense_kernel, dim3(grid), dim3(AD_THREADS), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
+                       clear_grad, hyper);
     return swr_launch_status();
 }
 
@@ -100,9 +104,9 @@ extern "C" int swr_adam_rows(float* p, float* m, float* v, int64_t vocab, int di
 // the two launches above as ONE (the common step: one contiguous parameter arena + one large lazily updated table):
 // workgroups [0, dense_blocks) stream the arena, the rest take the row entries -- at config 2 each launch is pure
 // latency (~5 us), so one fewer is what this saves
-__global__ __launch_bounds__(AD_THREADS) void adam_dense_rows_kernel(float* __restrict__ dp, const float* __restrict__ dg,
+__global__ __launch_bounds__(AD_THREADS) void adam_dense_rows_kernel(float* __restrict__ dp, float* __restrict__ dg,
                                                                      float* __restrict__ dm, float* __restrict__ dv, int64_t dn,
-                                                                     int dense_blocks, float* __restrict__ p, float* __restrict__ m,
+                                                                     int clear_grad, int dense_blocks, float* __restrict__ p, float* __restrict__ m,
                                                                      float* __restrict__ v, int64_t vocab, int dim,
                                                                      const int32_t* __restrict__ urow, const float* __restrict__ ugrad,
                                                                      int64_t n_entries, int32_t* __restrict__ last,
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(AD_THREADS) void adam_dense_rows_kernel(float* __re
             float pi = dp[i], mi = dm[i], vi = dv[i];
             adam_elem(pi, dg[i], mi, vi, h);
             dp[i] = pi; dm[i] = mi; dv[i] = vi;
+            if (clear_grad) dg[i] = 0.f;
         }
         return;
     }
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(AD_THREADS) void adam_dense_rows_kernel(float* __re
     if (e == 0) last[row] = static_cast<int32_t>(h.step);
 }
 
-extern "C" int swr_adam_dense_rows(float* dp, const float* dg, float* dm, float* dv, int64_t dn, float* p, float* m, float* v,
+extern "C" int swr_adam_dense_rows(float* dp, float* dg, float* dm, float* dv, int64_t dn, int clear_grad, float* p, float* m, float* v,
                                    int64_t vocab, int dim, const int32_t* urow, const float* ugrad, int64_t n_entries,
                                    int32_t* last, const swr_adam_hyper* hyper, void* stream) {
     SWR_REQUIRE(dp && dg && dm && dv && dn > 0 && p && m && v && urow && ugrad && last && hyper && vocab > 0 && dim > 0 &&
@@ -138,7 +143,7 @@ extern "C" int swr_adam_dense_rows(float* dp, const float* dg, float* dm, float*
     const int dense_blocks = static_cast<int>(swr_ceil_div(dn, AD_THREADS) < 4096 ? swr_ceil_div(dn, AD_THREADS) : 4096);
     const int64_t row_blocks = swr_ceil_div(n_entries * dim, AD_THREADS);
     hipLaunchKernelGGL(adam_dense_rows_kernel, dim3(static_cast<unsigned>(dense_blocks + row_blocks)), dim3(AD_THREADS), 0,
-                       static_cast<hipStream_t>(stream), dp, dg, dm, dv, dn, dense_blocks, p, m, v, vocab, dim, urow, ugrad,
+                       static_cast<hipStream_t>(stream), dp, dg, dm, dv, dn, clear_grad, dense_blocks, p, m, v, vocab, dim, urow, ugrad,
                        n_entries, last, hyper);
     return swr_launch_status();
 }
@@ -243,6 +248,59 @@ __global__ __launch_bounds__(AD_THREADS) void adam_catchup_kernel(float* __restr
     if (e == 0) last[row] = now;             // nobody reads `last` in this launch
 }
 
+// phases 1 + 2 as ONE launch when dim is a power of two <= 64 (a row's dim lanes then sit inside one wavefront): the lane of
+// column 0 elects the row's replayer with a compare-and-swap on `last[row]` itself (f -> now; exactly one of the duplicate
+// lookups of a row that is behind sees its own f come back), and hands (row, f) to the other lanes by shuffle.  Which
+// duplicate wins does not matter: the replay reads only the row's own (p, m, v) and the step scalars.  Nobody reads
+// p / m / v in this launch, so marking the row current before it is replayed is safe; a second entry of the SAME table in
+// one launch (a table shared by two features) simply loses the election.  One ~5 us launch less in front of every lookup.
+__device__ __forceinline__ void adam_catchup_elect(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   int32_t* __restrict__ last, int64_t vocab, int dim, const void* __restrict__ idx,
+                                                   int idx_dtype, uint32_t hash_seed, int64_t i, int e,
+                                                   const float* __restrict__ hist, const swr_adam_hyper& h) {
+    const int now = static_cast<int>(h.step);
+    int f = now;
+    uint32_t row = 0u;
+    if (e == 0) {
+        int64_t id = swr_load_index(idx, idx_dtype, i);
+        if (hash_seed != 0u) {
+            uint64_t z = static_cast<uint64_t>(id) ^ hash_seed;
+            z += 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            id = static_cast<int64_t>((z ^ (z >> 31)) % static_cast<uint64_t>(vocab));
+        }
+        if (id >= 0 && id < vocab) {            // out-of-range ids: the gather flags them; nothing to replay
+            row = static_cast<uint32_t>(id);
+            f = __hip_atomic_load(last + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f < now && atomicCAS(last + id, f, now) != f) f = now;      // another lookup of the row replays it
+        }
+    }
+    const int src = static_cast<int>(__lane_id()) - e;
+    f = __shfl(f, src);
+    row = static_cast<uint32_t>(__shfl(static_cast<int>(row), src));
+    if (f >= now) return;
+    const int64_t o = static_cast<int64_t>(row) * dim + e;
+    float pi = p[o], mi = m[o], vi = v[o];
+    adam_replay(pi, mi, vi, f, now, hist, h);
+    p[o] = pi; m[o] = mi; v[o] = vi;
+}
+
+__global__ __launch_bounds__(AD_THREADS) void adam_catchup_fused_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                                        float* __restrict__ v, int32_t* __restrict__ last,
+                                                                        int64_t vocab, int dim, const void* __restrict__ idx,
+                                                                        int idx_dtype, uint32_t hash_seed, int64_t n,
+                                                                        const float* __restrict__ hist,
+                                                                        const swr_adam_hyper* __restrict__ hp) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x;
+    const int64_t i = g / dim;
+    if (i >= n) return;                           // (whole lane groups: n * dim is a multiple of dim)
+    const swr_adam_hyper h = *hp;
+    adam_catchup_elect(p, m, v, last, vocab, dim, idx, idx_dtype, hash_seed, i, static_cast<int>(g - i * dim), hist, h);
+}
+
+static inline bool adam_dim_in_wave(int dim) { return dim > 0 && dim <= 64 && (dim & (dim - 1)) == 0; }
+
 extern "C" int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last, int32_t* claim, int64_t vocab, int dim,
                                      const void* idx, int idx_dtype, uint32_t hash_seed, int64_t n, const float* hist,
                                      const swr_adam_hyper* hyper, void* workspace, size_t workspace_bytes, void* stream) {
@@ -251,6 +309,11 @@ extern "C" int swr_adam_catchup_rows(float* p, float* m, float* v, int32_t* last
     SWR_REQUIRE(workspace_bytes >= static_cast<size_t>(n) * 8, SWR_ERR_WORKSPACE);
     if (n == 0) return SWR_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (adam_dim_in_wave(dim)) {
+        hipLaunchKernelGGL(adam_catchup_fused_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n * dim, AD_THREADS))), dim3(AD_THREADS),
+                           0, st, p, m, v, last, vocab, dim, idx, idx_dtype, hash_seed, n, hist, hyper);
+        return swr_launch_status();
+    }
     int32_t* from = static_cast<int32_t*>(workspace);
     uint32_t* rows = reinterpret_cast<uint32_t*>(from + n);
     hipLaunchKernelGGL(adam_claim_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, AD_THREADS))), dim3(AD_THREADS), 0, st, idx,
@@ -361,6 +424,21 @@ __global__ __launch_bounds__(AD_THREADS) void adam_catchup_multi_kernel(const Ad
     if (e == 0) T.last[row] = now;
 }
 
+// claim + catch-up of every table in one launch (see adam_catchup_fused_kernel); each table's work items start at a
+// multiple of 64 so that no row's lanes straddle a wavefront
+__global__ __launch_bounds__(AD_THREADS) void adam_catchup_fused_multi_kernel(const AdamMultiK k) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x;
+    if (g >= k.first[k.n_tables]) return;
+    const int t = adam_multi_table(k, g);
+    const swr_adam_table& T = k.tab[t];
+    const int64_t idx = g - k.first[t];
+    const int64_t i = idx / T.dim;
+    if (i >= T.n) return;                         // alignment padding behind the table's last row
+    const swr_adam_hyper h = *k.hp;
+    adam_catchup_elect(T.p, T.m, T.v, T.last, T.vocab, T.dim, T.idx, T.idx_dtype, T.hash_seed, i,
+                       static_cast<int>(idx - i * T.dim), k.hist, h);
+}
+
 __global__ __launch_bounds__(AD_THREADS) void adam_rows_multi_kernel(const AdamMultiK k) {
     const int64_t g = static_cast<int64_t>(blockIdx.x) * AD_THREADS + threadIdx.x;
     if (g >= k.first[k.n_tables]) return;
@@ -408,6 +486,19 @@ extern "C" int swr_adam_catchup_multi(const swr_adam_table* tables, int n_tables
     int rc = adam_multi_fill(k, tables, n_tables, false, false, hist, hyper);
     if (rc != SWR_OK) return rc;
     if (k.first[n_tables] == 0) return SWR_OK;
+    bool in_wave = true;
+    for (int t = 0; t < n_tables; ++t) in_wave = in_wave && adam_dim_in_wave(tables[t].dim);
+    if (in_wave) {
+        int64_t pos = 0;
+        for (int t = 0; t < n_tables; ++t) {
+            k.first[t] = pos;
+            pos += (tables[t].n * tables[t].dim + 63) / 64 * 64;
+        }
+        k.first[n_tables] = pos;
+        hipLaunchKernelGGL(adam_catchup_fused_multi_kernel, dim3(static_cast<unsigned>(swr_ceil_div(pos, AD_THREADS))),
+                           dim3(AD_THREADS), 0, st, k);
+        return swr_launch_status();
+    }
     hipLaunchKernelGGL(adam_claim_multi_kernel, dim3(static_cast<unsigned>(swr_ceil_div(k.first[n_tables], AD_THREADS))),
                        dim3(AD_THREADS), 0, st, k);
     rc = adam_multi_fill(k, tables, n_tables, true, false, hist, hyper);

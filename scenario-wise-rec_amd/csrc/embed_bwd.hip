@@ -472,6 +472,36 @@ __device__ __forceinline__ void to_fixed_n(const float (&x)[N], long long (&hi)[
     }
 }
 
+// The direct sums' form: when every value of the wave is zero or 2^-37 <= |x| < 2^-13 (gradients of a mean loss over a large
+// batch are), the whole product sm << (e - 90) -- below 2^47 -- goes into the LOW limb and the high limb is not touched: one
+// LDS atomic per element instead of two.  A workgroup adds at most 32 768 of them per accumulator (< 2^62), and its flush
+// carries bits 40 and up into the high limb, so the totals that reach memory are the pairs the two-limb form produces.
+// Returns true when the wave took the one-limb form (wave-uniform).
+template <int N>
+__device__ __forceinline__ bool to_fixed_wide_n(const float (&x)[N], long long (&hi)[N], long long (&lo)[N], uint32_t& bad) {
+    bool small = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t e = (__float_as_uint(x[i]) >> 23) & 0xFFu;
+        small = small && (e == 0u || (e - 90u) < 24u);
+    }
+    if (__all(small)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t u = __float_as_uint(x[i]);
+            const uint32_t e = (u >> 23) & 0xFFu;
+            const int m = e ? static_cast<int>((u & 0x7FFFFFu) | 0x800000u) : 0;
+            const int s = static_cast<int>(u) >> 31;
+            const int sm = (m ^ s) - s;
+            lo[i] = static_cast<long long>(sm) << ((e - 90u) & 63u);
+            hi[i] = 0;
+        }
+        return true;
+    }
+    to_fixed_n<N>(x, hi, lo, bad);
+    return false;
+}
+
 __device__ __forceinline__ float from_fixed(long long hi, long long lo) {
     return static_cast<float>(static_cast<double>(hi) * (1.0 / 1048576.0) +
                               static_cast<double>(lo) * (1.0 / 1152921504606846976.0));
@@ -504,6 +534,9 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
     const int spl = DIRECT_THREADS / W;                       // sample lanes
     if (tid < spl * W) {
         const int c = (tid % W) * V, sl = tid / W;
+        // a lane's V = 4 elements are taken in an order rotated by its sample lane: rows start at multiples of 128 bytes
+        // (dim 16), so with every lane on element v of its quad the 16 lanes of an LDS group hit 4 bank pairs 4 deep
+        const int rot = V == 4 ? (sl & 3) : 0;
         int mi = G.member0, cc = c;
         while (cc >= dm.mem[mi].dim) { cc -= dm.mem[mi].dim; ++mi; }
         const int dim = dm.mem[mi].dim, row_lo = dm.mem[mi].row_lo, rows = dm.mem[mi].rows;
@@ -532,11 +565,21 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
                 if (s0 + static_cast<int64_t>(u) * spl < b1 && r < static_cast<uint32_t>(rows)) {
                     const int a = base + static_cast<int>(r) * dim;
                     long long h[V], l[V];
-                    to_fixed_n<V>(x[u], h, l, bad);
+                    float xr[V];
+                    if (V == 4) {
+                        const bool r1 = rot & 1, r2 = rot & 2;
+                        const float y0 = r1 ? x[u][1 % V] : x[u][0], y1 = r1 ? x[u][2 % V] : x[u][1 % V],
+                                    y2 = r1 ? x[u][3 % V] : x[u][2 % V], y3 = r1 ? x[u][0] : x[u][3 % V];
+                        xr[0] = r2 ? y2 : y0; xr[1 % V] = r2 ? y3 : y1; xr[2 % V] = r2 ? y0 : y2; xr[3 % V] = r2 ? y1 : y3;
+                    } else {
+                        xr[0] = x[u][0];
+                    }
+                    const bool wide = to_fixed_wide_n<V>(xr, h, l, bad);
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        atomicAdd(&lacc[a + v], static_cast<unsigned long long>(h[v]));
-                        atomicAdd(&lacc[elems + a + v], static_cast<unsigned long long>(l[v]));
+                        const int av = a + ((v + rot) & (V - 1));
+                        if (!wide) atomicAdd(&lacc[av], static_cast<unsigned long long>(h[v]));
+                        atomicAdd(&lacc[elems + av], static_cast<unsigned long long>(l[v]));
                     }
                 }
             }
@@ -550,11 +593,11 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
         const DirectMember& M = dm.mem[G.member0 + q];
         const int n = M.rows * M.dim;
         for (int j = tid; j < n; j += DIRECT_THREADS) {
-            const unsigned long long h = lacc[M.lds_off + j], l = lacc[elems + M.lds_off + j];
-            if ((h | l) != 0ull) {
-                atomicAdd(acc_hi + stripe + M.acc_off + j, h);
-                atomicAdd(acc_lo + stripe + M.acc_off + j, l);
-            }
+            long long h = static_cast<long long>(lacc[M.lds_off + j]), l = static_cast<long long>(lacc[elems + M.lds_off + j]);
+            h += l >> 40;                                        // carry of the one-limb form (floor, like the two-limb split)
+            l &= (1ll << 40) - 1;
+            if (h != 0) atomicAdd(acc_hi + stripe + M.acc_off + j, static_cast<unsigned long long>(h));
+            if (l != 0) atomicAdd(acc_lo + stripe + M.acc_off + j, static_cast<unsigned long long>(l));
         }
     }
 }

@@ -233,9 +233,9 @@ _SIGS = {
     "swr_colsum_workspace_bytes": (_Z, [_L, _I]),
     "swr_colsum": (C.c_int, [_P, _L, _L, _I, _P, _I, _P, _Z, _P]),
     "swr_adam_advance": (C.c_int, [_P, _P, _L, _P]),
-    "swr_adam_dense": (C.c_int, [_P, _P, _P, _P, _L, _P, _P]),
+    "swr_adam_dense": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P]),
     "swr_adam_rows": (C.c_int, [_P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _P]),
-    "swr_adam_dense_rows": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P]),
+    "swr_adam_dense_rows": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P]),
     "swr_adam_catchup_rows": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _I, C.c_uint32, _L, _P, _P, _P, _Z, _P]),
     "swr_adam_flush": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "swr_adam_sweep_untouched": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),

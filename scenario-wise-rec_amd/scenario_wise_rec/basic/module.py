@@ -146,7 +146,13 @@ class SwrModule(nn.Module):
         if a is None:
             return super().zero_grad(set_to_none)
         g = a["g"]
-        if g.is_cuda and g.data_ptr() % 16 == 0:
+        # nothing to fill when every parameter that took a gradient since the last call had it consumed AND zeroed by the
+        # optimizer (optim.FusedAdam.clear_grads): the arena was all zeros before that backward pass and is again
+        dirty = any(getattr(p, "_swr_touched", True) and not getattr(p, "_swr_grad_clean", False)
+                    for p, _off, _n in a["spans"] if p.requires_grad)
+        if not dirty:
+            pass
+        elif g.is_cuda and g.data_ptr() % 16 == 0:
             from .. import _hip as H
             H.check(H.lib.swr_zero(H.ptr(g), g.numel() * 4, H.stream()), "swr_zero")
         else:
@@ -155,6 +161,7 @@ class SwrModule(nn.Module):
             if p.requires_grad:
                 if p.grad is None or p.grad.data_ptr() != a["g"].data_ptr() + 4 * off:
                     p.grad = a["g"][off:off + n].view(p.shape)
+                p._swr_grad_clean = False
                 if hasattr(p, "_swr_hooked"):
                     p._swr_touched = False
         for p in a["big"]:
@@ -165,3 +172,4 @@ class SwrModule(nn.Module):
 
 def _mark_touched(p):
     p._swr_touched = True
+    p._swr_grad_clean = False

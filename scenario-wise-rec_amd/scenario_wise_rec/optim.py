@@ -107,6 +107,10 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.lazy_rows = lazy_rows
+        # True: the dense update zeroes each gradient it consumed (SwrModule.zero_grad then skips its fill).  For loops that
+        # call zero_grad -> backward -> step and never read `.grad` after the step (CTRTrainer sets it); the default keeps
+        # torch's behaviour: gradients stay readable until the next zero_grad
+        self.clear_grads = False
         if hist_cap < 4 or hist_cap & (hist_cap - 1):
             raise ValueError("hist_cap must be a power of two >= 4")
         self.hist_cap = int(hist_cap)
@@ -248,6 +252,7 @@ class FusedAdam(torch.optim.Optimizer):
                     self._since_flush += 1
             # contiguous runs: parameter, gradient and state addresses all advance together
             items = []
+            clear_g = 1 if self.clear_grads else 0
             for p in dense:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise H.SwrError("FusedAdam needs contiguous fp32 parameters")
@@ -256,6 +261,8 @@ class FusedAdam(torch.optim.Optimizer):
                     g = g.float().contiguous()
                 m, v, key = self._state_for(p)
                 items.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), key, g))
+                if clear_g and g is p.grad:
+                    p._swr_grad_clean = True          # zeroed behind the update (SwrModule.zero_grad skips its fill)
             items.sort(key=lambda t: t[0])
             # parameters of this optimizer that are NOT updated this step (no gradient / untouched / frozen): a run must
             # not sweep over them (torch skips them entirely: no decay, no state)
@@ -281,14 +288,14 @@ class FusedAdam(torch.optim.Optimizer):
                 p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep = runs[0]
                 p, (urow, ugrad) = sparse[0]
                 st = self._lazy_state(p, hist, hyper)
-                H.check(lib.swr_adam_dense_rows(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr), n,
+                H.check(lib.swr_adam_dense_rows(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr), n, clear_g,
                                                 H.ptr(p), H.ptr(st.m), H.ptr(st.v), p.shape[0], p.shape[1], H.ptr(urow),
                                                 H.ptr(ugrad), urow.numel(), H.ptr(st.last), H.ptr(hyper), stream),
                         "swr_adam_dense_rows")
                 continue
             for p_ptr, g_ptr, m_ptr, v_ptr, n, _key, _keep in runs:
                 H.check(lib.swr_adam_dense(C.c_void_p(p_ptr), C.c_void_p(g_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
-                                           n, H.ptr(hyper), stream), "swr_adam_dense")
+                                           n, clear_g, H.ptr(hyper), stream), "swr_adam_dense")
             if self.lazy_rows and len(sparse) > 1:
                 # several large tables: one row-update launch for all of them (swr_adam_rows_multi)
                 for c0 in range(0, len(sparse), H.ADAM_MAX_TABLES):

@@ -61,6 +61,10 @@ class CTRTrainer(object):
             # behaviour, nn.Embedding sparse=False); row-sparse gradients are a FusedAdam-only representation
             self.model.set_dense_table_limit(1 << 62)
         self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
+        if isinstance(self.optimizer, FusedAdam):
+            # this loop is zero_grad -> backward -> step (`ctr_trainer.py:71-73`) and reads no gradient after the step: the
+            # update zeroes what it consumed and zero_grad has nothing left to launch (set False to inspect `.grad` after a step)
+            self.optimizer.clear_grads = os.environ.get("SWR_CLEAR_GRADS", "1") != "0"
         self.scheduler = None
         if scheduler_fn is not None:
             self.scheduler = scheduler_fn(self.optimizer, **scheduler_params)

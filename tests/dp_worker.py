@@ -145,6 +145,8 @@ def main():
                         device="cuda:0")
         step = DataParallelStep(tr, world)
         model.train()
+        if mode == "full-gpu":
+            tr.optimizer.clear_grads = False       # the exchanged gradients are dumped AFTER the step
         if mode == "graph-gpu":
             # two captured graphs + eager collectives; the captured step must land where the eager one does.
             # capture() runs 2 eager warm-up steps, so compare after 3 steps in total on the same batch.

@@ -49,7 +49,8 @@ def test_lazy_rows_equal_dense_sweep_bitwise(name):
         assert np.array_equal(lazy[k], dense[k]), f"{k}: max diff {np.abs(lazy[k].astype(np.float64) - dense[k]).max()}"
 
 
-def test_shared_lazy_table_is_caught_up_once_per_row():
+@pytest.mark.parametrize("dim", [16, 12], ids=["dim16-elected-in-one-launch", "dim12-claim-then-replay"])
+def test_shared_lazy_table_is_caught_up_once_per_row(dim):
     """Two large (row-sparse, lazily updated) tables, one of them looked up through TWO id columns (`shared_with`) that hold
     the same id at the same batch position: the batched catch-up (optim.catchup_many) must replay a row's pending
     decay-only steps once -- lazy == per-step sweep, bitwise, over steps that leave rows untouched for a while."""
@@ -63,8 +64,10 @@ def test_shared_lazy_table_is_caught_up_once_per_row():
         SwrModule.dense_table_limit_bytes = 1024
         try:
             torch.manual_seed(11)
-            feats = [SparseFeature("a", 3000, 16), SparseFeature("b", 2000, 16), SparseFeature("a2", 3000, 16, shared_with="a"),
-                     SparseFeature("small", 7, 16), DenseFeature("d0")]
+            # (dim 16: a row's lanes sit in one wavefront and elect its replayer by compare-and-swap inside ONE launch,
+            # csrc/adam.hip adam_catchup_elect; dim 12: the claim launch + the replay launch)
+            feats = [SparseFeature("a", 3000, dim), SparseFeature("b", 2000, dim), SparseFeature("a2", 3000, dim, shared_with="a"),
+                     SparseFeature("small", 7, dim), DenseFeature("d0")]
             model = MMOE(feats, domain_num=3, n_expert=2, expert_params={"dims": [16]}, tower_params={"dims": [8]})
             with torch.no_grad():
                 for n, p in model.named_parameters():

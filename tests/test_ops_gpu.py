@@ -57,7 +57,8 @@ def test_gather_out_of_range_index_raises():
                                                 (512, 12, [40], 1 << 30), (300, 64, [11, 13], 1 << 30),
                                                 (2000, 16, [1000, 3000, 70000], 1 << 30),  # row-range parts; sorted dense
                                                 (600, 6, [40, 3000], 1 << 30)])            # columns not 16-byte aligned
-def test_embedding_backward(B, dim, vocabs, limit):
+@pytest.mark.parametrize("scale", [1e-3, 5e-6])     # 5e-6: every |g| < 2^-13, the direct sums take their one-limb form
+def test_embedding_backward(B, dim, vocabs, limit, scale):
     """K3 against np.add.at in fp64.  The fixed-point accumulation is exact to 2^-60, so the only error
     is the final fp32 rounding: rtol 2e-7 of the largest entry."""
     from scenario_wise_rec.basic.features import SparseFeature
@@ -71,7 +72,7 @@ def test_embedding_backward(B, dim, vocabs, limit):
     x = {f.name: rng.integers(0, f.vocab_size, size=B) for f in feats}
     x["s0"][: B // 2] = 1                                                          # a long run of one row
     out = layer({k: _dev(v) for k, v in x.items()}, feats, squeeze_dim=True)
-    g = rng.standard_normal(out.shape).astype(np.float32) * 1e-3
+    g = rng.standard_normal(out.shape).astype(np.float32) * np.float32(scale)
     out.backward(_dev(g))
     torch.cuda.synchronize()
     for i, f in enumerate(feats[:-1]):
@@ -131,6 +132,33 @@ def test_embedding_backward_wide_dynamic_range(limit, monkeypatch):
         else:
             got = w.grad.cpu().numpy()
         # exact integer sums: the result is the fp32 rounding of the true sum (+ B * 2^-60 of truncation)
+        np.testing.assert_allclose(got, want, rtol=1.2e-7, atol=B * 2.0 ** -60)
+
+
+@pytest.mark.parametrize("B", [4096, 40000])
+def test_embedding_backward_one_limb_form_is_exact(B):
+    """Direct sums, gradients around the 2^-13 switch of the one-limb LDS form (csrc/embed_bwd.hip to_fixed_wide_n): waves
+    whose values are all below it add one limb, the others two, into the same accumulators; negative sums carry into the
+    high limb at the flush.  Exact integer sums: the result is the fp32 rounding of the fp64 sum."""
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(B)
+    dim = 16
+    feats = [SparseFeature("a", 7, dim), SparseFeature("b", 300, dim), SparseFeature("c", 1472, dim)]
+    layer = EmbeddingLayer(feats).to("cuda")
+    x = {f.name: rng.integers(0, f.vocab_size, size=B) for f in feats}
+    g = (rng.standard_normal((B, 3 * dim)) * 2e-5).astype(np.float32)
+    g[B // 2:] *= np.float32(16.0)                     # second half: some values above 2^-13 in most waves
+    g[:, 5] = -np.abs(g[:, 5])                          # one all-negative column (carry of a negative low limb)
+    g[::3, 7] = 0.0
+    layer(({k: _dev(v) for k, v in x.items()}), feats, squeeze_dim=True).backward(_dev(g))
+    torch.cuda.synchronize()
+    from scenario_wise_rec import _hip as H
+    H.check_errors()
+    for i, f in enumerate(feats):
+        want = np.zeros((f.vocab_size, dim), np.float64)
+        np.add.at(want, x[f.name], g[:, i * dim:(i + 1) * dim].astype(np.float64))
+        got = layer.embed_dict[f.name].weight.grad.cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=1.2e-7, atol=B * 2.0 ** -60)
 
 

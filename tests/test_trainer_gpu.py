@@ -215,3 +215,45 @@ def test_adam_skips_an_untouched_parameter_between_two_touched_ones():
     torch.optim.Adam(ref, lr=0.1, weight_decay=0.5).step()
     torch.testing.assert_close(flat[0:8], ref[0].data, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(flat[10:18], ref[1].data, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,limit", [("mmoe", None), ("mmoe", 2048), ("ppnet", None)])
+def test_optimizer_cleared_gradients_replace_the_zero_grad_fill(name, limit, monkeypatch):
+    """FusedAdam.clear_grads (CTRTrainer's default): the dense update zeroes each gradient it consumed and
+    SwrModule.zero_grad launches no fill -- same trajectory, bit for bit, as the fill; a backward pass that no optimizer
+    step consumed is still wiped by the next zero_grad (`ctr_trainer.py:71-73`)."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.trainers import CTRTrainer
+    _limit(monkeypatch, limit)
+    c = Case(name)
+    res = {}
+    for clear in (False, True):
+        model = build_product_model(c)
+        tr = CTRTrainer(model, "clear", optimizer_params={"lr": LR, "weight_decay": WD}, device="cuda")
+        tr.optimizer.clear_grads = clear
+        model.train()
+        fills = []
+        real = H.lib.swr_zero
+        monkeypatch.setattr(H.lib, "swr_zero", lambda *a: (fills.append(1), real(*a))[1])
+        for s in range(3):
+            x, y = c.batch(s)
+            tr.train_step(to_device(x), torch.from_numpy(y).cuda())
+        n_fills = len(fills)
+        arena = model.arena()["g"]
+        if clear:
+            assert not torch.count_nonzero(arena)                      # everything written was consumed and zeroed
+            assert n_fills == 0, "zero_grad still filled the arena"
+        else:
+            assert torch.count_nonzero(arena) and n_fills == 2      # (the first zero_grad finds the fresh arena untouched)
+        # a backward pass without an optimizer step leaves gradients behind: the next zero_grad must fill
+        x, y = c.batch(0)
+        tr.forward_backward(to_device(x), torch.from_numpy(y).cuda())
+        assert torch.count_nonzero(arena)
+        model.zero_grad()
+        assert not torch.count_nonzero(arena) and len(fills) > n_fills
+        monkeypatch.setattr(H.lib, "swr_zero", real)
+        torch.cuda.synchronize()
+        H.check_errors()
+        res[clear] = _state(model)
+    for k, v in res[False].items():
+        assert np.array_equal(v, res[True][k]), k

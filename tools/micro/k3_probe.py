@@ -20,7 +20,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 sets = []
 for j in range(4):
     keys = torch.stack([torch.randint(0, v, (B,), device="cuda", generator=g, dtype=torch.int32) for v in vocabs]).contiguous()
-    dE = torch.randn(B, ld, device="cuda", generator=g) * 1e-3
+    # K3_SCALE: magnitude of the gradients (the step's dE at batch 65 536 has a median of 4.5e-6 and a maximum of 1e-4)
+    dE = torch.randn(B, ld, device="cuda", generator=g) * float(os.environ.get("K3_SCALE", "5e-6"))
     sets.append((keys, dE))
 grads = [torch.zeros(v, dim, device="cuda") for v in vocabs]
 slots = (H.EmbedGradSlot * len(vocabs))()
@@ -66,7 +67,7 @@ def bench(label):
           f"sums + finalise {t_late:.1f}", flush=True)
 
 
-for rows in ("64", "128", "256", "512", "1024", "4096"):
+for rows in (("64", "128", "256", "512", "1024", "4096") if os.environ.get("K3_PROBE_MFMA") else ()):
     os.environ["SWR_K3_MFMA"] = "1"
     os.environ["SWR_K3_MFMA_MAX_ROWS"] = rows
     for wgs in ("256", "768"):
