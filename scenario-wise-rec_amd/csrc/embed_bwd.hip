@@ -43,6 +43,7 @@
 #ifndef DIRECT_THREADS
 #define DIRECT_THREADS 512
 #endif
+#define DIRECT_RESIDENT 512       // workgroups of the direct sums the chip holds at once (2 per CU by LDS)
 #define DIRECT_CAP_ELEMS 4096     // (hi, lo) int64 accumulator pairs per workgroup = 64 KB of LDS, 2 workgroups per CU
 #define DIRECT_MAX_PARTS 8        // a table larger than the cap is cut into row ranges, one workgroup column each
 #define DIRECT_MAX_MEMBERS 72
@@ -52,12 +53,12 @@
 #endif
 
 struct DirectMember {
-    int64_t acc_off;      // dense accumulator offset of (row_lo, column 0) of the member's table
+    int64_t acc_off;      // slab element of (row_lo, column 0) in the member's slab of sample chunk 0 (see `pad`)
     int32_t col;          // first column of the lookup in dE
     int32_t row_lo, rows; // row range accumulated by this member
     int32_t lds_off;      // first LDS accumulator element
     int16_t dim, slot;
-    int32_t pad;
+    int32_t pad;          // slab stride: elements (vocab x dim) from one sample chunk's slab of this lookup to the next
 };
 struct DirectGroup {
     int32_t col0, width;  // contiguous column span of dE
@@ -99,9 +100,9 @@ struct SegMeta {
     int64_t rows_per_split;   // multiple of 32 * SEG_WAVES
     int64_t B;
 };
-struct SegFin {               // per table: where the finalise launch finds the partial tables (n == 0: not a segsum table)
-    int64_t off[MAX_SLOTS];
-    int32_t n[MAX_SLOTS];     // lookups of the table x batch splits
+struct SegFin {               // per table: where the finalise launch finds the partial tables (n == 0: neither kind)
+    int64_t off[MAX_SLOTS];   // n > 0: float offset of the MFMA segment sums' partial tables; n < 0: first slab element of the
+    int32_t n[MAX_SLOTS];     // direct sums' -n slabs (one per lookup of the table x sample chunk), `stride` elements apart
     int32_t stride[MAX_SLOTS];   // rows_pad * dim
 };
 static inline int seg_class(int dim) { return dim <= 16 ? 0 : (dim <= 32 ? 1 : 2); }
@@ -141,6 +142,8 @@ struct HostPlan {
     SegFin sf;
     int64_t part_elems;      // floats of segsum partial tables
     size_t off_part;
+    int64_t slab_elems;      // (hi, lo) pairs of the direct sums' slabs
+    size_t off_slab;
     int64_t dense_acc_elems;
     int64_t sparse_acc_elems;
     size_t off_k0, off_k1, off_v0, off_v1, off_hist, off_acc_hi, off_acc_lo, total;
@@ -216,6 +219,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     for (int c = 0; c < 3; ++c) { p.sg[c].n_jobs = 0; p.sg[c].n_splits = 0; p.sg[c].rows_per_split = 0; p.sg[c].B = B; }
     for (int t = 0; t < MAX_SLOTS; ++t) { p.sf.off[t] = 0; p.sf.n[t] = 0; p.sf.stride[t] = 0; }
     p.part_elems = 0;
+    p.slab_elems = 0;
     if (seg_enabled() && B >= 2048) {        // (the kernel's 32-bit element offsets: B * ld < 2^31 is checked at launch)
         int n_jobs_all = 0, count_cls[3] = {0, 0, 0};
         for (int t = 0; t < n_tables; ++t) {
@@ -311,7 +315,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         if (tm.mode != 1) {
             SWR_REQUIRE(m.sparse_start < 0, SWR_ERR_ARG);        // sparse tables carry the largest ids
             tm.acc_off = acc;
-            acc += tm.vocab * tm.dim;
+            if (!direct[t]) acc += tm.vocab * tm.dim;      // (the direct sums keep their accumulators in slabs)
         } else {
             if (m.sparse_start < 0) m.sparse_start = pos;
             tm.acc_off = 0;
@@ -368,14 +372,59 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
             if (open < 0) open = new_group(slots[s].in_col);
             add_member(open, s, 0, static_cast<int>(tm.vocab));
         }
+        // workgroups: DIRECT_TARGET (sample, column) elements each -- unless a launch of slightly more than the chip's 512
+        // resident workgroups (64 KB of LDS each, 256 CUs) results: its second round costs a full workgroup time for a few
+        // stragglers (config 2: 576 workgroups at 32 768 elements, 504 at 38 400: 38.7 -> 34.2 us), so the target grows by
+        // up to half until the launch fits one round
+        auto count_blocks = [&](int64_t target) {
+            int64_t nb = 0;
+            for (int gi = 0; gi < dm.n_groups; ++gi)
+                nb += swr_ceil_div(B, std::min<int64_t>(B, std::max<int64_t>(64, target / dm.grp[gi].width)));
+            return nb;
+        };
+        int64_t target = DIRECT_TARGET;
+        if (count_blocks(target) > DIRECT_RESIDENT)
+            for (int64_t t2 = target + target / 16; t2 <= target + target / 2; t2 += target / 16)
+                if (count_blocks(t2) <= DIRECT_RESIDENT) { target = t2; break; }
         int blocks = 0;
         for (int gi = 0; gi < dm.n_groups; ++gi) {
             DirectGroup& g = dm.grp[gi];
-            g.chunk = static_cast<int32_t>(std::min<int64_t>(B, std::max<int64_t>(64, DIRECT_TARGET / g.width)));
+            g.chunk = static_cast<int32_t>(std::min<int64_t>(B, std::max<int64_t>(64, target / g.width)));
             g.block0 = blocks;
             blocks += static_cast<int>(swr_ceil_div(B, g.chunk));
         }
         dm.n_blocks = blocks;
+        // slabs: every workgroup STORES its accumulators (all of them) into the slab of (lookup, sample chunk) -- plain 16-byte
+        // stores instead of two memory-side atomics per element into shared stripes (4 M atomics per step at config 2: they,
+        // not the LDS atomics or the reads, set the kernel's time); the finalise launch adds a table's slabs
+        int64_t slot_first[MAX_SLOTS], n_slabs[MAX_SLOTS];
+        for (int s = 0; s < MAX_SLOTS; ++s) { slot_first[s] = -1; n_slabs[s] = 0; }
+        for (int gi = 0; gi < dm.n_groups; ++gi) {
+            const DirectGroup& g = dm.grp[gi];
+            const int64_t chunks = swr_ceil_div(B, g.chunk);
+            for (int q = 0; q < g.n_members; ++q) {
+                const int s = dm.mem[g.member0 + q].slot, t = slots[s].table_id;
+                if (slot_first[s] < 0) { slot_first[s] = n_slabs[t]; n_slabs[t] += chunks; }   // (row-range parts share the slabs)
+            }
+        }
+        int64_t slab = 0;
+        for (int t = 0; t < n_tables; ++t) {
+            if (!direct[t] || n_slabs[t] == 0) continue;
+            const int64_t te = m.tab[t].vocab * m.tab[t].dim;
+            SWR_REQUIRE(n_slabs[t] < (1ll << 30), SWR_ERR_ARG);
+            p.sf.off[t] = slab;
+            p.sf.n[t] = -static_cast<int32_t>(n_slabs[t]);
+            p.sf.stride[t] = static_cast<int32_t>(te);
+            slab += n_slabs[t] * te;
+        }
+        p.slab_elems = slab;
+        for (int q = 0; q < dm.n_members; ++q) {
+            DirectMember& mb = dm.mem[q];
+            const int t = slots[mb.slot].table_id;
+            const int64_t te = m.tab[t].vocab * m.tab[t].dim;
+            mb.acc_off = p.sf.off[t] + slot_first[mb.slot] * te + static_cast<int64_t>(mb.row_lo) * mb.dim;
+            mb.pad = static_cast<int32_t>(te);
+        }
     }
     p.sm.seg_off[n_tables] = pos;
     p.sm.tile_off[n_tables] = tiles;
@@ -401,6 +450,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     p.off_acc_hi = off; off += ab;
     p.off_acc_lo = off; off += ab;
     p.off_part = off; off += align_up(static_cast<size_t>(p.part_elems) * 4);
+    p.off_slab = off; off += align_up(static_cast<size_t>(p.slab_elems) * 16);
     p.total = off;
     return SWR_OK;
 }
@@ -516,8 +566,7 @@ __device__ __forceinline__ float from_fixed(long long hi, long long lo) {
 template <int V>
 __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta dm, const uint32_t* __restrict__ keys,
                                                                 const float* __restrict__ dE, int64_t ld,
-                                                                unsigned long long* acc_hi, unsigned long long* acc_lo,
-                                                                int64_t dense_acc_elems, uint32_t* err) {
+                                                                longlong2* __restrict__ slab, uint32_t* err) {
     extern __shared__ unsigned long long lacc[];              // [elems] hi limbs, then [elems] lo limbs
     int gi = 0;
     while (gi + 1 < dm.n_groups && dm.grp[gi + 1].block0 <= static_cast<int>(blockIdx.x)) ++gi;
@@ -543,7 +592,10 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
         const int base = dm.mem[mi].lds_off + cc;
         const uint32_t* __restrict__ kp = keys + static_cast<int64_t>(dm.mem[mi].slot) * dm.B;
         const float* __restrict__ xp = dE + G.col0 + c;
-        constexpr int U = 4;                                  // row loads in flight per thread
+#ifndef DIRECT_U
+#define DIRECT_U 4
+#endif
+        constexpr int U = DIRECT_U;                           // row loads in flight per thread
         uint32_t bad = 0u;
         for (int64_t s0 = b0 + sl; s0 < b1; s0 += static_cast<int64_t>(spl) * U) {
             float x[U][V];
@@ -587,17 +639,17 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
         if (bad && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
     }
     __syncthreads();
-    // flush the touched accumulators into stripe (chunk % ACC_STRIPES) of the dense accumulators
-    const int64_t stripe = static_cast<int64_t>(chunk_id % ACC_STRIPES) * dense_acc_elems;
+    // every accumulator (touched or not) goes to this workgroup's part of the slab of (lookup, sample chunk): one coalesced
+    // 16-byte store per element, no zero-fill needed in front, nothing shared with another workgroup
     for (int q = 0; q < G.n_members; ++q) {
         const DirectMember& M = dm.mem[G.member0 + q];
         const int n = M.rows * M.dim;
+        longlong2* __restrict__ dst = slab + M.acc_off + static_cast<int64_t>(chunk_id) * M.pad;
         for (int j = tid; j < n; j += DIRECT_THREADS) {
             long long h = static_cast<long long>(lacc[M.lds_off + j]), l = static_cast<long long>(lacc[elems + M.lds_off + j]);
             h += l >> 40;                                        // carry of the one-limb form (floor, like the two-limb split)
             l &= (1ll << 40) - 1;
-            if (h != 0) atomicAdd(acc_hi + stripe + M.acc_off + j, static_cast<unsigned long long>(h));
-            if (l != 0) atomicAdd(acc_lo + stripe + M.acc_off + j, static_cast<unsigned long long>(l));
+            dst[j] = make_longlong2(h, l);
         }
     }
 }
@@ -1002,7 +1054,8 @@ __global__ __launch_bounds__(RB_THREADS) void finalize_kernel(const BwdMeta m, c
                                                               const long long* __restrict__ acc_hi,
                                                               const long long* __restrict__ acc_lo, int64_t dense_acc_elems,
                                                               int gx, int dense_blocks, const SegFin sf,
-                                                              const float* __restrict__ part) {
+                                                              const float* __restrict__ part,
+                                                              const longlong2* __restrict__ slab) {
     if (static_cast<int>(blockIdx.x) < dense_blocks) {
         const int ti = blockIdx.x / gx;
         const TableMeta& t = m.tab[ti];
@@ -1023,6 +1076,30 @@ __global__ __launch_bounds__(RB_THREADS) void finalize_kernel(const BwdMeta m, c
                     g += v0; g += v1; g += v2; g += v3;
                 }
                 for (; q < np; ++q) g += p0[q * stride + j];
+                t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;
+            }
+            return;
+        }
+        if (sf.n[ti] < 0) {
+            // direct sums: the table's slabs (one per lookup x sample chunk), integer sums of (hi, lo) pairs
+            const longlong2* __restrict__ s0 = slab + sf.off[ti];
+            const int64_t stride = sf.stride[ti];
+            const int ns = -sf.n[ti];
+            for (int64_t j = static_cast<int64_t>(blockIdx.x % gx) * RB_THREADS + threadIdx.x; j < n;
+                 j += static_cast<int64_t>(gx) * RB_THREADS) {
+                long long hi = 0, lo = 0;
+                int q = 0;
+                for (; q + 4 <= ns; q += 4) {
+                    const longlong2 v0 = s0[q * stride + j], v1 = s0[(q + 1) * stride + j], v2 = s0[(q + 2) * stride + j],
+                                    v3 = s0[(q + 3) * stride + j];
+                    hi += (v0.x + v1.x) + (v2.x + v3.x);
+                    lo += (v0.y + v1.y) + (v2.y + v3.y);
+                }
+                for (; q < ns; ++q) {
+                    const longlong2 v = s0[q * stride + j];
+                    hi += v.x; lo += v.y;
+                }
+                const float g = from_fixed(hi, lo);
                 t.grad_dense[j] = t.mode == 2 ? t.grad_dense[j] + g : g;
             }
             return;
@@ -1121,10 +1198,10 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         const size_t lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long);
         if (vec4)
             hipLaunchKernelGGL(direct_kernel<4>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
-                               p.dm, keys, dE, ld, acc_hi, acc_lo, p.dense_acc_elems, err_flag);
+                               p.dm, keys, dE, ld, reinterpret_cast<longlong2*>(ws + p.off_slab), err_flag);
         else
             hipLaunchKernelGGL(direct_kernel<1>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
-                               p.dm, keys, dE, ld, acc_hi, acc_lo, p.dense_acc_elems, err_flag);
+                               p.dm, keys, dE, ld, reinterpret_cast<longlong2*>(ws + p.off_slab), err_flag);
     }
     if ((phases & 2) && n > 0) {
         int lpe = 1;
@@ -1145,7 +1222,7 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
 #undef LAUNCH_REDUCE
     }
     int gx = 0, dense_blocks = 0;
-    if ((phases & 4) && p.dense_acc_elems > 0) {
+    if ((phases & 4) && (p.dense_acc_elems > 0 || p.slab_elems > 0)) {
         int64_t biggest = 1;
         for (int t = 0; t < m.n_tables; ++t)
             if (m.tab[t].mode != 1 && m.tab[t].vocab * m.tab[t].dim > biggest) biggest = m.tab[t].vocab * m.tab[t].dim;
@@ -1157,7 +1234,8 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
     if (dense_blocks + sparse_blocks > 0)
         hipLaunchKernelGGL(finalize_kernel, dim3(static_cast<unsigned>(dense_blocks + sparse_blocks)), dim3(RB_THREADS), 0, st,
                            m, ck, reinterpret_cast<const long long*>(acc_hi), reinterpret_cast<const long long*>(acc_lo),
-                           p.dense_acc_elems, gx > 0 ? gx : 1, dense_blocks, p.sf, reinterpret_cast<const float*>(ws + p.off_part));
+                           p.dense_acc_elems, gx > 0 ? gx : 1, dense_blocks, p.sf, reinterpret_cast<const float*>(ws + p.off_part),
+                           reinterpret_cast<const longlong2*>(ws + p.off_slab));
     return swr_launch_status();
 }
 

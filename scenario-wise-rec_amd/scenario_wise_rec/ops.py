@@ -594,8 +594,13 @@ class EmbedGather(Function):
             # hidden behind the rest of the forward and backward pass; the backward joins before it reduces
             live, _uses, table_id = _grad_slot_layout(plan, weights, ctx.n_k3_slots)
             proto = (H.EmbedGradSlot * max(1, len(live)))()
+            pos = 0
             for s, (wpos, idx, vocab, dim, col, seed) in enumerate(live):
                 mode = 1 if weights[wpos].numel() * 4 > plan.dense_limit_bytes else 0
+                if plan.oh:
+                    # the backward will see the consuming layer's COMPACT dX (OneHotInfo.compact: the K3 slots packed in
+                    # order); the workspace layout depends on which lookups are adjacent (direct-sum groups -> slab count)
+                    col, pos = pos, pos + dim
                 proto[s] = H.EmbedGradSlot(vocab, dim, col, table_id[wpos], mode, None, None, None)
             nbytes = lib.swr_embed_bwd_workspace_bytes(proto, len(live), B) if live else 0
             if not live:
