@@ -168,6 +168,7 @@ class SwrModule(nn.Module):
             p.grad = None
             p._swr_sparse_grad = None
             p._swr_touched = False
+        return dirty           # (ops.add_side_job: False = no launch, nothing for the backward pass to wait for)
 
 
 def _mark_touched(p):

@@ -199,16 +199,21 @@ def _skew(point):
         H.check(lib.swr_spin_us(us, H.stream()), "swr_spin_us")
 
 
-def add_side_job(fn):
+def add_side_job(fn, backward_needs=True):
     """Run `fn()` on the side stream inside the next forward-time fork (EmbedGather.forward); `run_side_jobs()` runs
-    whatever is still pending on the current stream."""
-    _side["jobs"].append(fn)
+    whatever is still pending on the current stream.  `backward_needs=False`: nothing in the backward pass reads what the
+    job writes (the optimizer's step counter); a job that returns False launched nothing (a zero_grad with nothing to fill)."""
+    _side["jobs"].append((fn, backward_needs))
 
 
 def run_side_jobs():
+    """-> True when a job launched something the backward pass has to wait for."""
     jobs, _side["jobs"] = _side["jobs"], []
-    for fn in jobs:
-        fn()
+    needed = False
+    for fn, backward_needs in jobs:
+        launched = fn()
+        needed = needed or (backward_needs and launched is not False)
+    return needed
 
 
 def _fork_extras():
@@ -217,15 +222,22 @@ def _fork_extras():
     the critical path of the backward pass.  An event marks their end: the backward pass needs THEM from its first
     kernel on (zero_grad), the sort that follows on the same stream only when the embedding backward runs."""
     _side["epoch"] += 1
-    run_side_jobs()
+    needed = run_side_jobs()
     for ent in _side["wt"].values():
+        needed = True
         if ent.get("sel") is not None:
             torch.index_select(ent["src"].t(), 0, ent["sel"], out=ent["buf"])
         else:
             ent["buf"].copy_(ent["src"].t())
         ent["epoch"] = _side["epoch"]
-    _side["extras_ev"] = torch.cuda.Event()
-    _side["extras_ev"].record(torch.cuda.current_stream())
+    if needed:
+        _side["extras_ev"] = torch.cuda.Event()
+        _side["extras_ev"].record(torch.cuda.current_stream())
+    else:
+        # nothing the backward pass reads was launched here (the optimizer cleared the gradients it consumed, no W^T copies):
+        # its first kernel takes no edge from this branch -- in a replayed graph such an edge parks that kernel in the branch's
+        # queue, behind the sort
+        _side["extras_ev"] = "none"
 
 
 def join_side_extras():
@@ -238,7 +250,8 @@ def join_side_extras():
         join_side_streams()
         return
     _side["extras_ev"] = None
-    torch.cuda.current_stream().wait_event(ev)
+    if ev != "none":
+        torch.cuda.current_stream().wait_event(ev)
 
 
 def _transposed_weight(W):

@@ -146,7 +146,7 @@ class CTRTrainer(object):
 
     def _local_step(self, x_dict, y):
         if hasattr(self.optimizer, "advance_early"):
-            ops.add_side_job(self.optimizer.advance_early)      # the step-counter launch leaves the critical path too
+            ops.add_side_job(self.optimizer.advance_early, backward_needs=False)      # the step-counter launch leaves the critical path too
         loss = self.forward_backward(x_dict, y)
         self.optimizer.step()
         return loss
