@@ -168,7 +168,6 @@ SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"      # "0": everythi
 # 0.506 ms at config 2; a fork / join pair costs ~10-20 us of edges, so smaller products stay on the main stream (forking
 # every product LOSES 0.02 ms at configs 1, 3, 4) and chip-filling ones only slow what they overlap
 SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = 2e9, 2e10
-SORT_STREAM = os.environ.get("SWR_SORT_STREAM", "0") != "0"      # the sort on a branch of its own (measured: 0.487 vs 0.463 ms, see _side_stream)
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
@@ -281,12 +280,8 @@ def _selected_wt(W, sel):
     return Wt
 
 
-def _side_stream(dev, sort=False):
-    """The side stream of a device; `sort=True`: a second one that carries only the large tables' sort.  (In a replayed
-    hipGraph the runtime continues a node with two parents in the queue of its side-branch parent: with the sort behind the
-    one-shot jobs on ONE branch, the first kernel of the backward pass -- which waits for zero_grad -- sat behind the whole
-    sort chain, 29 us of idle critical path at config 2.)"""
-    key = (torch.device(dev).index or 0) + (1000 if sort and SORT_STREAM else 0)
+def _side_stream(dev):
+    key = torch.device(dev).index or 0
     if key not in _side["streams"]:
         _side["streams"][key] = torch.cuda.Stream(device=dev)
     return _side["streams"][key]
@@ -391,8 +386,6 @@ def _defer_side(dev, fn):
     captured graph the main stream's kernel then comes first in capture order.  (Measured at config 2: this form 0.700
     ms, fork at once 0.709, edge and launches both later 0.711, event-record nodes stall the branch until the join.)"""
     _side_stream(dev).wait_stream(torch.cuda.current_stream(dev))
-    if SORT_STREAM:
-        _side_stream(dev, sort=True).wait_stream(torch.cuda.current_stream(dev))
     _side["deferred"].append((dev, fn, "nowait"))
 
 
@@ -625,11 +618,12 @@ class EmbedGather(Function):
                     # the one-shot jobs first (zero_grad, the optimizer's step counter, W^T copies): the main stream joins
                     # this branch right before the backward pass, and the dozen latency-bound sort launches are what it
                     # would otherwise wait for LAST (measured: 30 us of join stall at config 2 with the jobs behind the sort)
+                    # (the sort on a branch of its own -- so that nothing that joins the one-shot jobs queues behind it -- was
+                    # measured: 0.487 vs 0.463 ms per step, the runtime then starts it in the middle of the backward pass)
                     _fork_extras()
-                    with torch.cuda.stream(_side_stream(dev, sort=True)):
-                        box["ws"] = torch.empty(box["nbytes"], dtype=torch.uint8, device=dev)
-                        H.check(lib.swr_embed_bwd_sort(proto, n, H.ptr(keys), B, H.ptr(box["ws"]), box["nbytes"], H.stream()),
-                                "swr_embed_bwd_sort")
+                    box["ws"] = torch.empty(box["nbytes"], dtype=torch.uint8, device=dev)
+                    H.check(lib.swr_embed_bwd_sort(proto, n, H.ptr(keys), B, H.ptr(box["ws"]), box["nbytes"], H.stream()),
+                            "swr_embed_bwd_sort")
                 _defer_side(dev, sort_now)
                 ctx.presorted = box
         return out[:, :plan.width] if plan.width != plan.ld else out
