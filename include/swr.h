@@ -623,6 +623,10 @@ typedef struct {
 } swr_star_layer_args;
 int swr_star_layer_fwd(const swr_star_layer_args* args, void* stream);
 int swr_star_layer_bwd(const swr_star_layer_args* args, void* stream);
+/* the same for n_layers layers (host array): their launches merged, four layers per launch -- every effective weight of the
+ * FCN stack before its first product, every parameter gradient after its last (star.py:99-110 over all layers) */
+int swr_star_layers_fwd(const swr_star_layer_args* layers_host, int n_layers, void* stream);
+int swr_star_layers_bwd(const swr_star_layer_args* layers_host, int n_layers, void* stream);
 
 /* ------------------------------------------------------------ routed inference ----
  * MMoE head in eval mode, routed: every row mixes the experts with its OWN domain's gate

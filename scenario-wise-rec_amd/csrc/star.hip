@@ -24,11 +24,10 @@ __device__ __forceinline__ void star_store(float* p, float v, int accumulate) {
 
 // workgroups [0, w_blocks): effective weights, thread = (i, o) with i fastest (coalesced writes of W_eff[o][i]);
 // the rest: effective biases
-__global__ __launch_bounds__(STAR_THREADS) void star_layer_fwd_kernel(const StarK k, int w_blocks) {
-    const swr_star_layer_args& a = k.a;
+__device__ __forceinline__ void star_layer_fwd_body(const swr_star_layer_args& a, int block, int w_blocks) {
     const int I = a.in_dim, O = a.out_dim;
-    if (static_cast<int>(blockIdx.x) < w_blocks) {
-        const int64_t e = static_cast<int64_t>(blockIdx.x) * STAR_THREADS + threadIdx.x;
+    if (block < w_blocks) {
+        const int64_t e = static_cast<int64_t>(block) * STAR_THREADS + threadIdx.x;
         if (e >= static_cast<int64_t>(I) * O) return;
         const int o = static_cast<int>(e / I), i = static_cast<int>(e - static_cast<int64_t>(o) * I);
         const float ws = a.Ws[static_cast<int64_t>(i) * O + o];
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(STAR_THREADS) void star_layer_fwd_kernel(const Star
     // one thread per output would be one serial chain); slices are added in order
     __shared__ float red[16][17];
     const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int o = (static_cast<int>(blockIdx.x) - w_blocks) * 16 + ol;
+    const int o = (block - w_blocks) * 16 + ol;
     for (int d = 0; d < a.D; ++d) {
         float s = 0.f;
         if (a.first && o < O)
@@ -63,12 +62,15 @@ __global__ __launch_bounds__(STAR_THREADS) void star_layer_fwd_kernel(const Star
 
 // workgroups [0, w_blocks): weight gradients, thread = (i, o) with o fastest (coalesced reads / writes of the [in, out]
 // parameters); then b_blocks of bias gradients (thread = o); then (first layer) the affine's gradients (thread = i)
-__global__ __launch_bounds__(STAR_THREADS) void star_layer_bwd_kernel(const StarK k, int w_blocks, int b_blocks) {
-    const swr_star_layer_args& a = k.a;
+__global__ __launch_bounds__(STAR_THREADS) void star_layer_fwd_kernel(const StarK k, int w_blocks) {
+    star_layer_fwd_body(k.a, static_cast<int>(blockIdx.x), w_blocks);
+}
+
+__device__ __forceinline__ void star_layer_bwd_body(const swr_star_layer_args& a, int block, int w_blocks, int b_blocks) {
     const int I = a.in_dim, O = a.out_dim;
     const int acc = a.accumulate;
-    if (static_cast<int>(blockIdx.x) < w_blocks) {
-        const int64_t e = static_cast<int64_t>(blockIdx.x) * STAR_THREADS + threadIdx.x;
+    if (block < w_blocks) {
+        const int64_t e = static_cast<int64_t>(block) * STAR_THREADS + threadIdx.x;
         if (e >= static_cast<int64_t>(I) * O) return;
         const int i = static_cast<int>(e / O), o = static_cast<int>(e - static_cast<int64_t>(i) * O);
         const float ws = a.Ws[e];
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(STAR_THREADS) void star_layer_bwd_kernel(const Star
         star_store(a.dWs ? a.dWs + e : nullptr, sum_s, acc);
         return;
     }
-    const int bb = static_cast<int>(blockIdx.x) - w_blocks;
+    const int bb = block - w_blocks;
     if (bb < b_blocks) {
         const int o = bb * STAR_THREADS + threadIdx.x;
         if (o >= O) return;
@@ -134,6 +136,33 @@ __global__ __launch_bounds__(STAR_THREADS) void star_layer_bwd_kernel(const Star
     }
 }
 
+__global__ __launch_bounds__(STAR_THREADS) void star_layer_bwd_kernel(const StarK k, int w_blocks, int b_blocks) {
+    star_layer_bwd_body(k.a, static_cast<int>(blockIdx.x), w_blocks, b_blocks);
+}
+
+// several layers per launch (the tensors are parameter-sized: one launch per layer each way is 14 latency-bound launches
+// per step at config 3): the layers' workgroups back to back, descriptors by value (4 x 856 bytes of the 4 KB kernarg segment)
+#define STAR_MULTI 4
+struct StarMultiK {
+    swr_star_layer_args a[STAR_MULTI];
+    int first[STAR_MULTI + 1];          // first workgroup of each layer
+    int w_blocks[STAR_MULTI], b_blocks[STAR_MULTI];
+    int n;
+};
+__device__ __forceinline__ int star_multi_layer(const StarMultiK& k, int block) {
+    int l = 0;
+    while (l + 1 < k.n && block >= k.first[l + 1]) ++l;
+    return l;
+}
+__global__ __launch_bounds__(STAR_THREADS) void star_layers_fwd_kernel(const StarMultiK k) {
+    const int l = star_multi_layer(k, static_cast<int>(blockIdx.x));
+    star_layer_fwd_body(k.a[l], static_cast<int>(blockIdx.x) - k.first[l], k.w_blocks[l]);
+}
+__global__ __launch_bounds__(STAR_THREADS) void star_layers_bwd_kernel(const StarMultiK k) {
+    const int l = star_multi_layer(k, static_cast<int>(blockIdx.x));
+    star_layer_bwd_body(k.a[l], static_cast<int>(blockIdx.x) - k.first[l], k.w_blocks[l], k.b_blocks[l]);
+}
+
 static int star_check(const swr_star_layer_args* args, bool bwd) {
     SWR_REQUIRE(args != nullptr, SWR_ERR_ARG);
     const swr_star_layer_args& a = *args;
@@ -170,4 +199,38 @@ extern "C" int swr_star_layer_bwd(const swr_star_layer_args* args, void* stream)
     hipLaunchKernelGGL(star_layer_bwd_kernel, dim3(w_blocks + b_blocks + a_blocks), dim3(STAR_THREADS), 0,
                        static_cast<hipStream_t>(stream), k, w_blocks, b_blocks);
     return swr_launch_status();
+}
+
+static int star_layers(const swr_star_layer_args* layers, int n_layers, bool bwd, void* stream) {
+    SWR_REQUIRE(layers != nullptr && n_layers > 0, SWR_ERR_ARG);
+    for (int l0 = 0; l0 < n_layers; l0 += STAR_MULTI) {
+        StarMultiK k;
+        k.n = n_layers - l0 < STAR_MULTI ? n_layers - l0 : STAR_MULTI;
+        int pos = 0;
+        for (int l = 0; l < k.n; ++l) {
+            const int rc = star_check(layers + l0 + l, bwd);
+            if (rc != SWR_OK) return rc;
+            k.a[l] = layers[l0 + l];
+            const swr_star_layer_args& a = k.a[l];
+            k.w_blocks[l] = static_cast<int>(swr_ceil_div(static_cast<int64_t>(a.in_dim) * a.out_dim, STAR_THREADS));
+            k.b_blocks[l] = bwd ? static_cast<int>(swr_ceil_div(a.out_dim, STAR_THREADS)) : static_cast<int>(swr_ceil_div(a.out_dim, 16));
+            const int a_blocks = (bwd && a.first) ? static_cast<int>(swr_ceil_div(a.in_dim, 16)) : 0;
+            k.first[l] = pos;
+            pos += k.w_blocks[l] + k.b_blocks[l] + a_blocks;
+        }
+        k.first[k.n] = pos;
+        if (bwd)
+            hipLaunchKernelGGL(star_layers_bwd_kernel, dim3(pos), dim3(STAR_THREADS), 0, static_cast<hipStream_t>(stream), k);
+        else
+            hipLaunchKernelGGL(star_layers_fwd_kernel, dim3(pos), dim3(STAR_THREADS), 0, static_cast<hipStream_t>(stream), k);
+    }
+    return swr_launch_status();
+}
+
+extern "C" int swr_star_layers_fwd(const swr_star_layer_args* layers, int n_layers, void* stream) {
+    return star_layers(layers, n_layers, false, stream);
+}
+
+extern "C" int swr_star_layers_bwd(const swr_star_layer_args* layers, int n_layers, void* stream) {
+    return star_layers(layers, n_layers, true, stream);
 }

@@ -249,6 +249,8 @@ _SIGS = {
     "swr_block_select_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _L, _P, _L, _P]),
     "swr_star_layer_fwd": (C.c_int, [_P, _P]),
     "swr_star_layer_bwd": (C.c_int, [_P, _P]),
+    "swr_star_layers_fwd": (C.c_int, [_P, _I, _P]),
+    "swr_star_layers_bwd": (C.c_int, [_P, _I, _P]),
     "swr_eval_metrics_workspace_bytes": (_Z, [_L, _I]),
     "swr_eval_metrics": (C.c_int, [_P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _Z, _P]),
     "swr_dp_finish": (C.c_int, [_P, _L, _L, _P, _P, _L, _P, _I, _I, _F, _P]),

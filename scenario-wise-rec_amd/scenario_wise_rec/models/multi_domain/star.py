@@ -85,6 +85,15 @@ class Star(SwrModule):
                   [b.running_var for b in bns], [b.num_batches_tracked for b in bns]]
         return g
 
+    def _layer_params(self, l):
+        """What ops.star_layer_weights takes for layer l (the first layer also carries the partitioned norm's affines)."""
+        D, first = self.num_domains, l == 0
+        params = [self.share_parm_w[l], self.share_parm_b[l]] + ([self.dn_share_gamma, self.dn_share_bias] if first else [])
+        params += [self.domain_specific_w[d][l] for d in range(D)] + [self.domain_specific_b[d][l] for d in range(D)]
+        if first:
+            params += list(self.domain_specific_dn_gamma) + list(self.domain_specific_dn_bias)
+        return params
+
     def _routed_eval(self, h, domain_id, aux_out):
         """Inference: the partitioned norm's statistics are whole-batch (computed above); everything after it is per row,
         so a row runs the FCN stack of its own domain only -- 1/D of the dense evaluation's products."""
@@ -115,15 +124,14 @@ class Star(SwrModule):
         h = ops.batch_standardize(emb, self.eps)
         if not self.training and D <= 8 and ops.routed_eval_ok(h):
             return self._routed_eval(h, domain_id, aux_out)
+        fused = D <= 8 and os.environ.get("SWR_STAR_FUSED", "1") != "0"
+        if fused:
+            # effective weights of EVERY layer for all domains before the first product, every parameter gradient after the
+            # last one: two launches each way for the whole stack (csrc/star.hip, ops.StarStackWeights)
+            effs = ops.star_stack_weights(D, [self._layer_params(l) for l in range(self.layer_num)])
         for l in range(self.layer_num):
-            if D <= 8 and os.environ.get("SWR_STAR_FUSED", "1") != "0":
-                # effective weights of the layer for all domains: one launch each way (csrc/star.hip)
-                first = l == 0
-                params = [self.share_parm_w[l], self.share_parm_b[l]] + ([self.dn_share_gamma, self.dn_share_bias] if first else [])
-                params += [self.domain_specific_w[d][l] for d in range(D)] + [self.domain_specific_b[d][l] for d in range(D)]
-                if first:
-                    params += list(self.domain_specific_dn_gamma) + list(self.domain_specific_dn_bias)
-                eff = ops.star_layer_weights(first, D, *params)
+            if fused:
+                eff = effs[l]
                 bns = [self.domain_specific_bn[d][l] for d in range(D)]
                 h = ops.linear_bn_act(h, list(eff[:D]), list(eff[D:]), bn=_bn_dict(bns), acts="relu",
                                       groups=(1 if l == 0 else D), training=self.training)

@@ -1932,6 +1932,65 @@ def eval_metrics(prob, label, domain, n_domains):
 
 
 # =========================================================================== STAR factorised weights
+def _star_fwd_args(first, D, ps):
+    """swr_star_layer_args of one layer's forward + the stacked outputs it writes."""
+    I, O = ps[0].shape
+    dev = ps[0].device
+    off = 4 if first else 2
+    a = H.StarLayerArgs()
+    a.D, a.in_dim, a.out_dim, a.first = D, I, O, int(first)
+    a.Ws, a.bs = ps[0].data_ptr(), ps[1].data_ptr()
+    if first:
+        a.gamma_s, a.beta_s = ps[2].data_ptr(), ps[3].data_ptr()
+    Wst = torch.empty((D * O, I), dtype=torch.float32, device=dev)
+    bst = torch.empty(D * O, dtype=torch.float32, device=dev)
+    for d in range(D):
+        a.Wd[d], a.bd[d] = ps[off + d].data_ptr(), ps[off + D + d].data_ptr()
+        if first:
+            a.gamma_d[d], a.beta_d[d] = ps[off + 2 * D + d].data_ptr(), ps[off + 3 * D + d].data_ptr()
+        a.W_eff[d] = Wst.data_ptr() + 4 * d * O * I
+        a.b_eff[d] = bst.data_ptr() + 4 * d * O
+    return a, tuple(Wst[d * O:(d + 1) * O] for d in range(D)) + tuple(bst[d * O:(d + 1) * O] for d in range(D))
+
+
+def _star_bwd_args(first, D, params, ps, needs, grads):
+    """swr_star_layer_args of one layer's backward; -> (args, gradient tensors, written straight into the arena?, keep-alive)."""
+    I, O = params[0].shape
+    off = 4 if first else 2
+    # straight into the gradient arena when every parameter's .grad lives there (zero_grad zeroed it), else fresh tensors
+    direct = [_grad_alias([p]) if needs[j] else None for j, p in enumerate(params)]
+    all_direct = all(g is not None or not needs[j] for j, g in enumerate(direct))
+    if all_direct:
+        out = direct
+    else:
+        out = [torch.empty_like(p, memory_format=torch.contiguous_format) if needs[j] else None for j, p in enumerate(params)]
+    a = H.StarLayerArgs()
+    a.D, a.in_dim, a.out_dim, a.first, a.accumulate = D, I, O, int(first), int(all_direct)
+    a.Ws, a.bs = ps[0].data_ptr(), ps[1].data_ptr()
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    a.dWs, a.dbs = ptr(out[0]), ptr(out[1])
+    if first:
+        a.gamma_s, a.beta_s = ps[2].data_ptr(), ps[3].data_ptr()
+        a.dgamma_s, a.dbeta_s = ptr(out[2]), ptr(out[3])
+    keep = []
+    for d in range(D):
+        a.Wd[d], a.bd[d] = ps[off + d].data_ptr(), ps[off + D + d].data_ptr()
+        a.dWd[d], a.dbd[d] = ptr(out[off + d]), ptr(out[off + D + d])
+        if first:
+            a.gamma_d[d], a.beta_d[d] = ps[off + 2 * D + d].data_ptr(), ps[off + 3 * D + d].data_ptr()
+            a.dgamma_d[d], a.dbeta_d[d] = ptr(out[off + 2 * D + d]), ptr(out[off + 3 * D + d])
+        gW, gb = grads[d], grads[D + d]
+        if gW is not None:
+            gW = H.f32c(gW)
+            keep.append(gW)
+            a.dW_eff[d] = gW.data_ptr()
+        if gb is not None:
+            gb = H.f32c(gb)
+            keep.append(gb)
+            a.db_eff[d] = gb.data_ptr()
+    return a, out, all_direct, keep
+
+
 class StarLayerWeights(Function):
     """Effective weights / biases of one STAR layer for all domains (reference `star.py:99-107`; the first layer also
     folds in the partitioned norm's domain affine, `star.py:91-100`): one launch each way (csrc/star.hip) instead of
@@ -1944,77 +2003,82 @@ class StarLayerWeights(Function):
     @staticmethod
     def forward(ctx, first, D, *params):
         H.require_device(*params)
-        Ws = params[0]
-        I, O = Ws.shape
-        dev = Ws.device
-        off = 4 if first else 2
-        a = H.StarLayerArgs()
-        a.D, a.in_dim, a.out_dim, a.first = D, I, O, int(first)
         ps = [H.f32c(p.detach()) for p in params]
-        a.Ws, a.bs = ps[0].data_ptr(), ps[1].data_ptr()
-        if first:
-            a.gamma_s, a.beta_s = ps[2].data_ptr(), ps[3].data_ptr()
-        Wst = torch.empty((D * O, I), dtype=torch.float32, device=dev)
-        bst = torch.empty(D * O, dtype=torch.float32, device=dev)
-        for d in range(D):
-            a.Wd[d], a.bd[d] = ps[off + d].data_ptr(), ps[off + D + d].data_ptr()
-            if first:
-                a.gamma_d[d], a.beta_d[d] = ps[off + 2 * D + d].data_ptr(), ps[off + 3 * D + d].data_ptr()
-            a.W_eff[d] = Wst.data_ptr() + 4 * d * O * I
-            a.b_eff[d] = bst.data_ptr() + 4 * d * O
+        a, outs = _star_fwd_args(first, D, ps)
         H.check(lib.swr_star_layer_fwd(C.byref(a), H.stream()), "swr_star_layer_fwd")
         ctx.first, ctx.D, ctx.params, ctx.keep = first, D, params, ps
-        return tuple(Wst[d * O:(d + 1) * O] for d in range(D)) + tuple(bst[d * O:(d + 1) * O] for d in range(D))
+        return outs
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
         first, D, params, ps = ctx.first, ctx.D, ctx.params, ctx.keep
-        I, O = params[0].shape
-        dev = params[0].device
-        off = 4 if first else 2
         n = len(params)
-        # straight into the gradient arena when every parameter's .grad lives there (zero_grad zeroed it), else fresh tensors
-        direct = [_grad_alias([p]) if ctx.needs_input_grad[2 + j] else None for j, p in enumerate(params)]
-        all_direct = all(g is not None or not ctx.needs_input_grad[2 + j] for j, g in enumerate(direct))
-        if all_direct:
-            out = direct
-        else:
-            out = [torch.empty_like(p, memory_format=torch.contiguous_format) if ctx.needs_input_grad[2 + j] else None
-                   for j, p in enumerate(params)]
-        a = H.StarLayerArgs()
-        a.D, a.in_dim, a.out_dim, a.first, a.accumulate = D, I, O, int(first), int(all_direct)
-        a.Ws, a.bs = ps[0].data_ptr(), ps[1].data_ptr()
-        ptr = lambda t: t.data_ptr() if t is not None else None
-        a.dWs, a.dbs = ptr(out[0]), ptr(out[1])
-        if first:
-            a.gamma_s, a.beta_s = ps[2].data_ptr(), ps[3].data_ptr()
-            a.dgamma_s, a.dbeta_s = ptr(out[2]), ptr(out[3])
-        keep = []
-        for d in range(D):
-            a.Wd[d], a.bd[d] = ps[off + d].data_ptr(), ps[off + D + d].data_ptr()
-            a.dWd[d], a.dbd[d] = ptr(out[off + d]), ptr(out[off + D + d])
-            if first:
-                a.gamma_d[d], a.beta_d[d] = ps[off + 2 * D + d].data_ptr(), ps[off + 3 * D + d].data_ptr()
-                a.dgamma_d[d], a.dbeta_d[d] = ptr(out[off + 2 * D + d]), ptr(out[off + 3 * D + d])
-            gW, gb = grads[d], grads[D + d]
-            if gW is not None:
-                gW = H.f32c(gW)
-                keep.append(gW)
-                a.dW_eff[d] = gW.data_ptr()
-            if gb is not None:
-                gb = H.f32c(gb)
-                keep.append(gb)
-                a.db_eff[d] = gb.data_ptr()
+        needs = ctx.needs_input_grad[2:]
+        a, out, all_direct, _keep = _star_bwd_args(first, D, params, ps, needs, grads)
         H.check(lib.swr_star_layer_bwd(C.byref(a), H.stream()), "swr_star_layer_bwd")
         if all_direct:
-            _mark_touched([p for j, p in enumerate(params) if ctx.needs_input_grad[2 + j]])
+            _mark_touched([p for j, p in enumerate(params) if needs[j]])
             return (None, None) + (None,) * n
         return (None, None) + tuple(out)
 
 
+class StarStackWeights(Function):
+    """StarLayerWeights for EVERY layer of the FCN stack in one call each way: all effective weights before the first
+    product (`swr_star_layers_fwd`), all parameter gradients after the last weight-gradient product (`swr_star_layers_bwd`;
+    autograd runs this backward once every layer's dW_eff exists).  Parameter-sized tensors: 14 latency-bound launches per
+    step at config 3 become 4.  counts[l] = number of parameters of layer l (the first layer is layer 0); returns the
+    layers' outputs (2 D tensors each) one after another."""
+
+    @staticmethod
+    def forward(ctx, D, counts, *params):
+        H.require_device(*params)
+        ps = [H.f32c(p.detach()) for p in params]
+        args = (H.StarLayerArgs * len(counts))()
+        outs, pos = (), 0
+        for l, n in enumerate(counts):
+            a, o = _star_fwd_args(l == 0, D, ps[pos:pos + n])
+            args[l] = a
+            outs += o
+            pos += n
+        H.check(lib.swr_star_layers_fwd(args, len(counts), H.stream()), "swr_star_layers_fwd")
+        ctx.D, ctx.counts, ctx.params, ctx.keep = D, counts, params, ps
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        D, counts, params, ps = ctx.D, ctx.counts, ctx.params, ctx.keep
+        args = (H.StarLayerArgs * len(counts))()
+        result, touched, keep, pos = [], [], [], 0
+        for l, n in enumerate(counts):
+            needs = ctx.needs_input_grad[2 + pos:2 + pos + n]
+            a, out, all_direct, k = _star_bwd_args(l == 0, D, params[pos:pos + n], ps[pos:pos + n], needs,
+                                                   grads[2 * D * l:2 * D * (l + 1)])
+            args[l] = a
+            keep.append(k)
+            if all_direct:
+                touched += [p for j, p in enumerate(params[pos:pos + n]) if needs[j]]
+                result += [None] * n
+            else:
+                result += list(out)
+            pos += n
+        H.check(lib.swr_star_layers_bwd(args, len(counts), H.stream()), "swr_star_layers_bwd")
+        _mark_touched(touched)
+        return (None, None) + tuple(result)
+
+
 def star_layer_weights(first, D, *params):
     return StarLayerWeights.apply(bool(first), int(D), *params)
+
+
+def star_stack_weights(D, layer_params):
+    """layer_params[l] = the parameter list star_layer_weights takes for layer l (layer 0 = the first layer) ->
+    [outputs of layer 0, outputs of layer 1, ...], each 2 D tensors (D weights [out, in], D biases)."""
+    counts = tuple(len(ps) for ps in layer_params)
+    flat = [p for ps in layer_params for p in ps]
+    outs = StarStackWeights.apply(int(D), counts, *flat)
+    return [outs[2 * D * l:2 * D * (l + 1)] for l in range(len(counts))]
 
 
 # =========================================================================== routed inference (SURVEY.md 8 row f2)
