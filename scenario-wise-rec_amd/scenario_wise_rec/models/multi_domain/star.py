@@ -101,13 +101,9 @@ class Star(SwrModule):
         route = ops.DomainRouting(domain_id, D)
         hs = route.rows(h)
         xs = [route.segment(hs, d) for d in range(D)]
+        effs = ops.star_stack_weights(D, [self._layer_params(l) for l in range(self.layer_num)])
         for l in range(self.layer_num):
-            first = l == 0
-            params = [self.share_parm_w[l], self.share_parm_b[l]] + ([self.dn_share_gamma, self.dn_share_bias] if first else [])
-            params += [self.domain_specific_w[d][l] for d in range(D)] + [self.domain_specific_b[d][l] for d in range(D)]
-            if first:
-                params += list(self.domain_specific_dn_gamma) + list(self.domain_specific_dn_bias)
-            eff = ops.star_layer_weights(first, D, *params)
+            eff = effs[l]
             for d in range(D):
                 if route.count(d):
                     xs[d] = ops.linear_bn_act(xs[d], [eff[d]], [eff[D + d]], bn=_bn_dict([self.domain_specific_bn[d][l]]),

@@ -761,6 +761,36 @@ def test_star_layer_weights_against_torch(D, I, O, first):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("dims", [[37, 20, 12, 6], [64, 32, 16, 8, 8, 4, 4], [5, 1]])
+def test_star_stack_weights_is_bitwise_the_layer_by_layer_form(dims):
+    """ops.star_stack_weights (swr_star_layers_fwd / bwd: four layers per launch, every layer of the stack in one call each
+    way) against one ops.star_layer_weights call per layer: same kernels bodies, so values and gradients bit for bit --
+    incl. a 7-layer stack, which takes two launches each way."""
+    from scenario_wise_rec import ops
+    D = 3
+    g = torch.Generator(device="cuda").manual_seed(len(dims))
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).requires_grad_(True)
+    layers = []
+    for l in range(len(dims) - 1):
+        I, O = dims[l], dims[l + 1]
+        first = l == 0
+        layers.append([mk(I, O), mk(O)] + ([mk(I), mk(I)] if first else []) + [mk(I, O) for _ in range(D)] +
+                      [mk(O) for _ in range(D)] + ([mk(I) for _ in range(2 * D)] if first else []))
+    flat = [p for ps in layers for p in ps]
+    stacked = ops.star_stack_weights(D, layers)
+    single = [ops.star_layer_weights(l == 0, D, *ps) for l, ps in enumerate(layers)]
+    outs_a = [t for eff in stacked for t in eff]
+    outs_b = [t for eff in single for t in eff]
+    assert len(outs_a) == len(outs_b) == 2 * D * len(layers)
+    cot = [torch.randn(t.shape, device="cuda", generator=g) for t in outs_a]
+    ga = torch.autograd.grad(outs_a, flat, cot)
+    gb = torch.autograd.grad(outs_b, flat, cot)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
+
+
 def test_device_data_loader_serves_the_same_batches():
     """DeviceDataLoader (row f3): without shuffle the batches are the DataLoader(TorchDataset) batches bit for bit (ragged
     last batch, drop_last); with shuffle every epoch is a permutation of the rows applied consistently to all columns."""
