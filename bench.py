@@ -593,7 +593,7 @@ def k3_roofline(cfg, dev, iters, B, config=2):
     return {"kernel": "direct_kernel + finalize_kernel (K3 sums of the %d mid-size tables)" % len(mids), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "traffic": pmc_traffic("void direct_kernel<", config),
-            "note": "bound by 64-bit LDS atomics on random rows, not by HBM (DESIGN.md): the fraction is what it is"}
+            "note": "a workgroup is a chain of five load -> convert -> LDS-atomic trips and a 64 KB slab store (latency-bound, DESIGN.md section 4); the slabs add 2 x 25 MB to the algorithmic bytes"}
 
 
 def gather_roofline(cfg, model, x, dev, iters, B, config=2):
