@@ -43,6 +43,7 @@
 #ifndef DIRECT_THREADS
 #define DIRECT_THREADS 512
 #endif
+#define DIRECT_LIST_MAX 3072      // samples per workgroup up to which a single-lookup workgroup lists its samples in LDS (12 KB)
 #define DIRECT_RESIDENT 512       // workgroups of the direct sums the chip holds at once (2 per CU by LDS)
 #define DIRECT_CAP_ELEMS 4096     // (hi, lo) int64 accumulator pairs per workgroup = 64 KB of LDS, 2 workgroups per CU
 #define DIRECT_MAX_PARTS 8        // a table larger than the cap is cut into row ranges, one workgroup column each
@@ -576,15 +577,76 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
     const int64_t b1 = min(b0 + G.chunk, dm.B);
     const int elems = G.elems;
     const int tid = threadIdx.x;
-    for (int j = tid; j < 2 * elems; j += DIRECT_THREADS) lacc[j] = 0ull;
+    for (int j = tid; j < 2 * elems + 1; j += DIRECT_THREADS) lacc[j] = 0ull;    // (+ the sample list's counter word)
     __syncthreads();
 
     const int W = G.width / V;                                // threads per sample row
     const int spl = DIRECT_THREADS / W;                       // sample lanes
-    if (tid < spl * W) {
+#ifndef DIRECT_U
+#define DIRECT_U 4
+#endif
+    constexpr int U = DIRECT_U;                               // row loads in flight per thread
+    uint32_t bad = 0u;
+    // one quad (V = 4) / one element of a gradient row -> the LDS accumulators at `a`; a lane's four elements are taken in an
+    // order rotated by its sample lane: rows start at multiples of 128 bytes (dim 16), so with every lane on element v of its
+    // quad the 16 lanes of an LDS group hit 4 bank pairs 4 deep
+    auto add_quad = [&](const float (&xq)[V], int a, int rot) {
+        long long h[V], l[V];
+        float xr[V];
+        if (V == 4) {
+            const bool r1 = rot & 1, r2 = rot & 2;
+            const float y0 = r1 ? xq[1 % V] : xq[0], y1 = r1 ? xq[2 % V] : xq[1 % V], y2 = r1 ? xq[3 % V] : xq[2 % V],
+                        y3 = r1 ? xq[0] : xq[3 % V];
+            xr[0] = r2 ? y2 : y0; xr[1 % V] = r2 ? y3 : y1; xr[2 % V] = r2 ? y0 : y2; xr[3 % V] = r2 ? y1 : y3;
+        } else {
+            xr[0] = xq[0];
+        }
+        const bool wide = to_fixed_wide_n<V>(xr, h, l, bad);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int av = a + ((v + rot) & (V - 1));
+            if (!wide) atomicAdd(&lacc[av], static_cast<unsigned long long>(h[v]));
+            atomicAdd(&lacc[elems + av], static_cast<unsigned long long>(l[v]));
+        }
+    };
+    if (V == 4 && G.n_members == 1 && G.chunk <= DIRECT_LIST_MAX) {
+        // ---- one lookup per workgroup (every mid-size table, every row range of a cut table): the chunk's keys are read in
+        // ONE round of independent loads and the samples whose row falls in this workgroup's range are listed in LDS
+        // ((sample << 16) | row; list order is arbitrary, integer sums do not care).  The walk over the list then has one
+        // memory latency per round (the gradient row) instead of two (key, then row), and a row range of a table cut 6 ways
+        // walks a sixth of the chunk instead of idling through all of it.
+        const DirectMember& M = dm.mem[G.member0];
+        uint32_t* list = reinterpret_cast<uint32_t*>(lacc + 2 * elems);      // [0] = count (zeroed above), entries from [1]
+        const uint32_t* __restrict__ kp = keys + static_cast<int64_t>(M.slot) * dm.B + b0;
+        const int ns = static_cast<int>(b1 - b0);
+        for (int s = tid; s < ns; s += DIRECT_THREADS) {
+            const uint32_t r = kp[s] - static_cast<uint32_t>(M.row_lo);
+            if (r < static_cast<uint32_t>(M.rows)) list[1 + atomicAdd(&list[0], 1u)] = (static_cast<uint32_t>(s) << 16) | r;
+        }
+        __syncthreads();
+        const int n_mine = static_cast<int>(list[0]);
+        if (tid < spl * W) {
+            const int c = (tid % W) * V, sl = tid / W;
+            const int rot = sl & 3;
+            const int dim = M.dim, base = M.lds_off + c;
+            const float* __restrict__ xp = dE + G.col0 + c + b0 * ld;
+            for (int e0 = sl; e0 < n_mine; e0 += spl * U) {
+                float x[U][V];
+                uint32_t ent[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) ent[u] = list[1 + min(e0 + u * spl, n_mine - 1)];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(xp + static_cast<int64_t>(ent[u] >> 16) * ld);
+                    x[u][0] = v.x; x[u][1 % V] = v.y; x[u][2 % V] = v.z; x[u][3 % V] = v.w;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (e0 + u * spl < n_mine) add_quad(x[u], base + static_cast<int>(ent[u] & 0xFFFFu) * dim, rot);
+            }
+        }
+    } else if (tid < spl * W) {
         const int c = (tid % W) * V, sl = tid / W;
-        // a lane's V = 4 elements are taken in an order rotated by its sample lane: rows start at multiples of 128 bytes
-        // (dim 16), so with every lane on element v of its quad the 16 lanes of an LDS group hit 4 bank pairs 4 deep
         const int rot = V == 4 ? (sl & 3) : 0;
         int mi = G.member0, cc = c;
         while (cc >= dm.mem[mi].dim) { cc -= dm.mem[mi].dim; ++mi; }
@@ -592,18 +654,11 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
         const int base = dm.mem[mi].lds_off + cc;
         const uint32_t* __restrict__ kp = keys + static_cast<int64_t>(dm.mem[mi].slot) * dm.B;
         const float* __restrict__ xp = dE + G.col0 + c;
-#ifndef DIRECT_U
-#define DIRECT_U 4
-#endif
-        constexpr int U = DIRECT_U;                           // row loads in flight per thread
-        uint32_t bad = 0u;
         for (int64_t s0 = b0 + sl; s0 < b1; s0 += static_cast<int64_t>(spl) * U) {
             float x[U][V];
             uint32_t k[U];
             bool mine[U];
-            // keys first: a table cut into row ranges is walked by one workgroup column per range, and only the samples whose
-            // row falls in THIS range fetch their gradient row (unconditional loads read every gradient column once per range:
-            // 18 instead of 8 column blocks at config 2; 36.9 -> 34.3 us with the finalise launch, 0.4549 -> 0.4496 ms/step)
+            // keys first: only the samples whose row falls in THIS workgroup's range fetch their gradient row
 #pragma unroll
             for (int u = 0; u < U; ++u) k[u] = kp[min(s0 + static_cast<int64_t>(u) * spl, b1 - 1)];
 #pragma unroll
@@ -619,32 +674,11 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t r = k[u] - static_cast<uint32_t>(row_lo);
-                if (mine[u]) {
-                    const int a = base + static_cast<int>(r) * dim;
-                    long long h[V], l[V];
-                    float xr[V];
-                    if (V == 4) {
-                        const bool r1 = rot & 1, r2 = rot & 2;
-                        const float y0 = r1 ? x[u][1 % V] : x[u][0], y1 = r1 ? x[u][2 % V] : x[u][1 % V],
-                                    y2 = r1 ? x[u][3 % V] : x[u][2 % V], y3 = r1 ? x[u][0] : x[u][3 % V];
-                        xr[0] = r2 ? y2 : y0; xr[1 % V] = r2 ? y3 : y1; xr[2 % V] = r2 ? y0 : y2; xr[3 % V] = r2 ? y1 : y3;
-                    } else {
-                        xr[0] = x[u][0];
-                    }
-                    const bool wide = to_fixed_wide_n<V>(xr, h, l, bad);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const int av = a + ((v + rot) & (V - 1));
-                        if (!wide) atomicAdd(&lacc[av], static_cast<unsigned long long>(h[v]));
-                        atomicAdd(&lacc[elems + av], static_cast<unsigned long long>(l[v]));
-                    }
-                }
-            }
+            for (int u = 0; u < U; ++u)
+                if (mine[u]) add_quad(x[u], base + static_cast<int>(k[u] - static_cast<uint32_t>(row_lo)) * dim, rot);
         }
-        if (bad && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
     }
+    if (bad && err) atomicOr(err, SWR_FLAG_GRAD_RANGE);
     __syncthreads();
     // every accumulator (touched or not) goes to this workgroup's part of the slab of (lookup, sample chunk): one coalesced
     // 16-byte store per element, no zero-fill needed in front, nothing shared with another workgroup
@@ -1202,7 +1236,8 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         bool vec4 = (ld % 4 == 0) && swr_aligned16(dE);
         for (int g = 0; g < p.dm.n_groups; ++g) max_elems = std::max(max_elems, p.dm.grp[g].elems);
         for (int q = 0; q < p.dm.n_members; ++q) vec4 = vec4 && p.dm.mem[q].dim % 4 == 0 && p.dm.mem[q].col % 4 == 0;
-        const size_t lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long);
+        const size_t lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long) + 8 +
+                           (vec4 ? sizeof(uint32_t) * (DIRECT_LIST_MAX + 2) : 0);
         if (vec4)
             hipLaunchKernelGGL(direct_kernel<4>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
                                p.dm, keys, dE, ld, reinterpret_cast<longlong2*>(ws + p.off_slab), err_flag);
