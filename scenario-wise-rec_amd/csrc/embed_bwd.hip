@@ -47,6 +47,10 @@
 #define DIRECT_RESIDENT 512       // workgroups of the direct sums the chip holds at once (2 per CU by LDS)
 #define DIRECT_CAP_ELEMS 4096     // (hi, lo) int64 accumulator pairs per workgroup = 64 KB of LDS, 2 workgroups per CU
 #define DIRECT_MAX_PARTS 8        // a table larger than the cap is cut into row ranges, one workgroup column each
+#define DIRECT_MAX_PARTS_SMALL 16 // ... up to 16 ranges while the table's slabs stay below DIRECT_SMALL_SLAB_BYTES: a small batch
+#define DIRECT_SMALL_SLAB_BYTES (4ll << 20)   // over a 6 040-row table (config 1) then needs no sort at all -- no side branch, no
+                                  // fork / join edges: 0.255 -> 0.238 ms per step; at batch 32 768 the two 1 000 x 64 tables of
+                                  // configs 5 / 6 would write 56 MB of slabs each and stay on the sorted path
 #define DIRECT_MAX_MEMBERS 72
 #define DIRECT_MAX_GROUPS 48
 #ifndef DIRECT_TARGET
@@ -279,10 +283,14 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         for (int t = 0; t < n_tables; ++t) {
             if (!seen[t] || segsum[t] || m.tab[t].mode == 1 || m.tab[t].dim > DIRECT_THREADS) continue;
             const int64_t elems = m.tab[t].vocab * m.tab[t].dim;
-            if (elems > static_cast<int64_t>(DIRECT_CAP_ELEMS) * DIRECT_MAX_PARTS || m.tab[t].dim > DIRECT_CAP_ELEMS) continue;
+            if (elems > static_cast<int64_t>(DIRECT_CAP_ELEMS) * DIRECT_MAX_PARTS_SMALL || m.tab[t].dim > DIRECT_CAP_ELEMS) continue;
             int uses = 0;
             for (int s = 0; s < n_slots; ++s) uses += slots[s].table_id == t;
             const int parts = static_cast<int>(swr_ceil_div(elems, DIRECT_CAP_ELEMS));
+            if (parts > DIRECT_MAX_PARTS) {
+                const int64_t chunks = swr_ceil_div(B, std::max<int64_t>(64, DIRECT_TARGET / m.tab[t].dim));
+                if (chunks * uses * elems * 16 > DIRECT_SMALL_SLAB_BYTES) continue;
+            }
             if (need_members + uses * parts > DIRECT_MAX_MEMBERS || need_groups + uses * parts > DIRECT_MAX_GROUPS) continue;
             need_members += uses * parts;
             need_groups += uses * parts;
