@@ -141,6 +141,15 @@ class SwrModule(nn.Module):
                 raise RuntimeError("set_dense_table_limit after the optimizer created lazy-row state for a table")
         return self.build_arena()
 
+    def arena_dirty(self):
+        """True when a parameter of the gradient arena took a gradient that no optimizer step consumed and zeroed
+        (optim.FusedAdam.clear_grads); None without an arena."""
+        a = self.arena()
+        if a is None:
+            return None
+        return any(getattr(p, "_swr_touched", True) and not getattr(p, "_swr_grad_clean", False)
+                   for p, _off, _n in a["spans"] if p.requires_grad)
+
     def zero_grad(self, set_to_none=True):
         a = self.arena()
         if a is None:
@@ -148,8 +157,7 @@ class SwrModule(nn.Module):
         g = a["g"]
         # nothing to fill when every parameter that took a gradient since the last call had it consumed AND zeroed by the
         # optimizer (optim.FusedAdam.clear_grads): the arena was all zeros before that backward pass and is again
-        dirty = any(getattr(p, "_swr_touched", True) and not getattr(p, "_swr_grad_clean", False)
-                    for p, _off, _n in a["spans"] if p.requires_grad)
+        dirty = self.arena_dirty()
         if not dirty:
             pass
         elif g.is_cuda and g.data_ptr() % 16 == 0:

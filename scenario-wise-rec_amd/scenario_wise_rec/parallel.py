@@ -366,6 +366,9 @@ class DataParallelStep(object):
         cur = torch.cuda.current_stream()
         if hasattr(self.trainer.optimizer, "note_replays"):
             self.trainer.optimizer.note_replays(1)
+        model = self.trainer.model
+        if getattr(self.trainer.optimizer, "clear_grads", False) and hasattr(model, "arena_dirty") and model.arena_dirty():
+            model.zero_grad()              # (the captured step holds no fill: trainers/graph.py GraphedStep.replay)
         g1.replay()
         rows = bool(xb["offs"])
         if rows:

@@ -63,6 +63,10 @@ class GraphedStep(object):
         if hasattr(opt, "hist_cap") and 2 * opt._since_flush >= opt.hist_cap:
             opt.materialize()              # (a history-ring flush must not end up INSIDE the captured step)
         snap = opt.host_counts() if hasattr(opt, "host_counts") else None
+        # with FusedAdam.clear_grads the captured step holds NO zero_grad fill (the update zeroes what it consumed): gradients
+        # that an eager backward pass leaves behind between two replays would be added to -- replay() wipes them first
+        model = getattr(trainer, "model", None)
+        self._guard = model if (getattr(opt, "clear_grads", False) and hasattr(model, "arena_dirty")) else None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             loss = fn(self.x, self.y)
@@ -80,5 +84,7 @@ class GraphedStep(object):
         opt = getattr(self.trainer, "optimizer", None)
         if hasattr(opt, "note_replays"):
             opt.note_replays(1)            # host step count, scheduler lr, history-ring flush (optim.FusedAdam)
+        if self._guard is not None and self._guard.arena_dirty():
+            self._guard.zero_grad()        # (what the step's own zero_grad does when the loop is launched eagerly)
         self.graph.replay()
         return self.loss                   # the STATIC buffer: the next replay overwrites it (keep a `.clone()`, not this)

@@ -43,3 +43,40 @@ def test_graph_replay_matches_eager(name, limit):
     b = _run(c, 6, use_graph=True, limit=limit)
     for k in a:
         assert np.array_equal(a[k], b[k]), f"{k}: max diff {np.abs(a[k].astype(np.float64) - b[k]).max()}"
+
+
+@pytest.mark.parametrize("name", ["mmoe", "star"])
+def test_replay_after_a_backward_pass_nobody_consumed(name):
+    """With FusedAdam.clear_grads the captured step holds no zero_grad fill.  An eager forward + backward WITHOUT an
+    optimizer step between two replays leaves gradients in the arena; the next step's zero_grad must wipe them
+    (`ctr_trainer.py:71`) -- GraphedStep.replay does, so the replayed loop ends where the eager one does, bit for bit."""
+    from scenario_wise_rec.trainers import CTRTrainer
+    from scenario_wise_rec.trainers.graph import GraphedStep
+    c = Case(name)
+    res = {}
+    for use_graph in (False, True):
+        model = build_product_model(c)
+        tr = CTRTrainer(model, "g", optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device="cuda")
+        assert tr.optimizer.clear_grads
+        model.train()
+        x, y = c.batch(0)
+        xd, yd = to_device(x), torch.from_numpy(y).cuda()
+        x1, y1 = c.batch(1)
+        x1d, y1d = to_device(x1), torch.from_numpy(y1).cuda()
+        if use_graph:
+            g = GraphedStep(tr, xd, yd, warmup=2)
+            g.replay()
+            tr.forward_backward(x1d, y1d)           # gradients nobody consumes
+            assert model.arena_dirty()
+            g.replay()
+            g.replay()
+        else:
+            for _ in range(3):
+                tr.train_step(xd, yd)
+            tr.forward_backward(x1d, y1d)
+            tr.train_step(xd, yd)
+            tr.train_step(xd, yd)
+        torch.cuda.synchronize()
+        res[use_graph] = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    for k in res[False]:
+        assert np.array_equal(res[False][k], res[True][k]), k
