@@ -1,9 +1,10 @@
 // K3: backward of the embedding lookup for ALL features of a batch at once
 // (replaces F_s x aten::embedding_dense_backward).
 //
-//   0. direct     : lookups of SMALL dense-gradient tables (<= DIRECT_MAX_PARTS x 64 KB of accumulators) skip the
-//                   sort: a workgroup owns a span of adjacent lookup columns and a chunk of samples, adds the
-//                   fixed-point gradients into LDS accumulators (ds_add_u64) and flushes the non-zero ones
+//   0. direct     : lookups of SMALL dense-gradient tables (<= DIRECT_MAX_PARTS x 64 KB of accumulators; 16 row ranges while
+//                   the slabs stay small) skip the sort: a workgroup owns a span of adjacent lookup columns and a chunk of
+//                   samples, adds the fixed-point gradients into LDS accumulators (ds_add_u64) and STORES them into the
+//                   slab of its (lookup, chunk); the finalise launch adds a table's slabs
 //   0'. segsum    : MID-SIZE dense-gradient tables (17 .. 4096 rows, dim a multiple of 8 up to 64) at batches >= 2048 are
 //                   summed on the matrix pipes: dEmb_t = OneHot_t^T dE_t, the one-hot fragment built in registers from
 //                   the keys (0 / 1 are exact in bf16), dE split into three bf16 terms (exact), fp32 accumulation by
@@ -36,7 +37,7 @@
 #define CHUNK_MAX 32     // sorted entries per reduce walker; 8 / 16 when there are few entries
 #define RB_THREADS 256
 #ifndef ACC_STRIPES
-#define ACC_STRIPES 4    // copies of the dense accumulators: chunk c adds into stripe c % ACC_STRIPES, so a hot row of a small
+#define ACC_STRIPES 4    // copies of the dense accumulators of SORTED dense tables: walker w adds into stripe w % ACC_STRIPES, so a hot row of a
                        // table does not serialise its atomics on one address (16 -> 4 stripes: -8 us of zero-fill and finalise per step at config 2)
 #endif
 
