@@ -374,6 +374,19 @@ def main():
         other = {"scaling": "weak" if args.scaling == "strong" else "strong", "global_batch": world * B2, "per_gpu_batch": B2,
                  "ms_per_step": dt2 / args.steps * 1e3, "value": world * B2 * args.steps / dt2, "unit": "samples/s"}
 
+    # ---- what the process group really was: every rank's device as the runtime names it, gathered over the group itself
+    # (N > 1: the driver can see from the line that RCCL connected N ranks on N different GPUs)
+    ranks_info = None
+    if dist is not None:
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": prop.name,
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", "")),
+                "visible_devices": torch.cuda.device_count()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered,
+                      "distinct_devices": len({(g["pci_bus_id"], g["uuid"], g["device_index"]) for g in gathered})}
+
     if rank != 0:
         return
 
@@ -396,7 +409,7 @@ def main():
                    "step": "fwd+BCE+bwd+Adam(all params; dense-Adam semantics on every table row, applied lazily but exactly)", "parallelism": f"dp{world}",
                    "ids": "uniform" if args.uniform_ids else "zipf1.05(large tables)+uniform", "hipgraph": graph is not None,
                    "batches_rotated": n_rot, "ms_per_step_single_batch_replayed": single_ms,
-                   "final_loss": final_loss, "scaling": args.scaling, "other_scaling": other,
+                   "final_loss": final_loss, "scaling": args.scaling, "other_scaling": other, "process_group": ranks_info,
                    "precision_mode": ("bf16 perf mode (SWR_GEMM=bf16): ONE bf16 MFMA product per k-group, operands rounded to bf16 -- "
                                       "NOT the parity path (max logit error ~1e-3..1e-2 at these widths, tests/test_perf_mode_gpu.py); "
                                       "reported beside the fp32-accurate line, never instead of it") if bf16_mode else

@@ -1245,8 +1245,24 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         bool vec4 = (ld % 4 == 0) && swr_aligned16(dE);
         for (int g = 0; g < p.dm.n_groups; ++g) max_elems = std::max(max_elems, p.dm.grp[g].elems);
         for (int q = 0; q < p.dm.n_members; ++q) vec4 = vec4 && p.dm.mem[q].dim % 4 == 0 && p.dm.mem[q].col % 4 == 0;
+        // the sample list (12 KB) is spent only when some workgroup takes the list branch (direct_kernel: V == 4, one lookup
+        // per workgroup, chunk <= DIRECT_LIST_MAX)
+        bool lists = false;
+        for (int g = 0; g < p.dm.n_groups; ++g)
+            lists = lists || (p.dm.grp[g].n_members == 1 && p.dm.grp[g].chunk <= DIRECT_LIST_MAX);
         const size_t lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long) + 8 +
-                           (vec4 ? sizeof(uint32_t) * (DIRECT_LIST_MAX + 2) : 0);
+                           ((vec4 && lists) ? sizeof(uint32_t) * (DIRECT_LIST_MAX + 2) : 0);
+        SWR_REQUIRE(lds <= 160 * 1024, SWR_ERR_UNSUPPORTED);
+        if (lds > 64 * 1024) {
+            // above 64 KB of dynamic LDS the attribute is needed (idempotent, not a stream operation; the first call of a
+            // shape happens in a warm-up step, never inside a hipGraph capture -- as bnmix.hip, gemm.hip)
+            static bool raised[2] = {false, false};
+            if (!raised[vec4 ? 1 : 0]) {
+                const void* fn = vec4 ? reinterpret_cast<const void*>(direct_kernel<4>) : reinterpret_cast<const void*>(direct_kernel<1>);
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;
+                raised[vec4 ? 1 : 0] = true;
+            }
+        }
         if (vec4)
             hipLaunchKernelGGL(direct_kernel<4>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,
                                p.dm, keys, dE, ld, reinterpret_cast<longlong2*>(ws + p.off_slab), err_flag);

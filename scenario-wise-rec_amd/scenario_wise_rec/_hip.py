@@ -27,7 +27,15 @@ def _load():
     return C.CDLL(_LIB_PATH)
 
 
+# the ABI number of include/swr.h these bindings were written against (SWR_ABI_VERSION): argument lists changed between
+# numbers, so a stale or variant libswr.so with another number would take shifted arguments -- refuse it
+ABI_VERSION = 4
+
 lib = _load()
+lib.swr_abi_version.restype = C.c_int
+if lib.swr_abi_version() != ABI_VERSION:
+    raise ImportError(f"{_LIB_PATH} has ABI {lib.swr_abi_version()}, these bindings need {ABI_VERSION}: rebuild it with "
+                      "`python scenario-wise-rec_amd/build_native.py --force`")
 
 # ----------------------------------------------------------------------------- enums
 I8, I16, I32, I64, U8, F16, BF16, F32, F64, BOOL = range(1, 11)

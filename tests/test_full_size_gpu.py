@@ -7,6 +7,11 @@ reduced vocabularies and batches, here at the sizes bench.py runs.
   reference step (oracle/torch_port.py, pinned on the golden vectors by tests/test_oracle_golden.py): loss sequence,
   train-mode logits of a fresh batch within 1e-4, every dense parameter, the rows of the large table that were looked
   up, and a sample of rows that never were (they must have decayed exactly like the reference's dense Adam decays them).
+* `test_cfg3_full` / `test_cfg4_full`: STAR at its per-GPU shard (batch 16 384, all 23 Ali-CCP tables at their full sizes:
+  238 635 / 467 298 / 263 942 ... rows) and PLE (batch 8 192, the 748 000-row x 32 user table): one step against the fp64
+  oracle holding the FULL tables (probabilities, loss, every gradient incl. the row lists of the large tables, the state
+  after Adam for every row -- rows nobody looked up carry the oracle's dense decay), then captured + lazy rows == eager +
+  dense sweep bitwise over rotating batches.
 * `test_cfg5_full_tables` / `test_cfg6_full_tables`: the two 50 M-row x 64 tables of BASELINE config 5 (12.8 GB each) at
   full size with hashed 40-bit ids.  The fp64 oracle cannot hold such a table, so it runs on the COMPACTED row set: the
   rows any step looks up, gathered from the device table before training, with ids remapped -- exact for the looked-up
@@ -23,7 +28,7 @@ import bench
 from _golden import assert_probs_close, logit, perturb_product
 from oracle.nn import Dense, Sparse
 from oracle.optim import Adam
-from test_baseline_shapes_gpu import mix64, oracle_for
+from test_baseline_shapes_gpu import mix64, oracle_for, run_config
 
 pytestmark = pytest.mark.gpu
 LR, WD = 1e-3, 1e-5
@@ -259,3 +264,58 @@ def test_cfg6_full_tables():
 def test_cfg5_full_tables():
     """HamurSmall over the same tables (the oracle's per-sample adapter products keep the batch small)."""
     _full_table_case(5, 512, {"s0": 0x2545F491, "s1": 0x9E3779B1})
+
+
+def _captured_lazy_equals_eager_sweep(n, n_steps=4):
+    """Config n at its full size: two eager warm-up steps + capture + replays over rotating batches with lazily updated rows
+    == the same steps launched eagerly with a dense Adam sweep over every table, BITWISE (state and loss sequence)."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.trainers import CTRTrainer
+    from scenario_wise_rec.trainers.graph import GraphedStep
+    cfg = copy.deepcopy(bench.CONFIGS[n])
+    cfg.pop("on_device_init", None)
+    B = cfg["batch"]
+    batches = [bench.synth_batch(cfg, B, seed=7100 + 10 * n + j) for j in range(n_steps - 1)]
+    dev = [({k: torch.from_numpy(v).cuda() for k, v in x.items()}, torch.from_numpy(y).cuda()) for x, y in batches]
+    order = [0, 0] + list(range(1, n_steps - 1))                     # batch 0 twice (the warm-up steps), then the others
+
+    def run(lazy, graphed):
+        model, _feats = bench.build_model(cfg, seed=17)
+        perturb_product(model, 43)
+        tr = CTRTrainer(model, f"cfg{n}-full", optimizer_params={"lr": LR, "weight_decay": WD, "lazy_rows": lazy}, device="cuda")
+        tr.use_graph = False
+        model.train()
+        losses = []
+        if graphed:
+            g = GraphedStep(tr, dev[0][0], dev[0][1], warmup=2)
+            for j in order[2:]:
+                g.load(*dev[j])
+                losses.append(float(g.replay().clone()))
+        else:
+            for j in order:
+                losses.append(float(tr.train_step(*dev[j]).detach()))
+            losses = losses[2:]
+        torch.cuda.synchronize()
+        H.check_errors()
+        return {k: v.cpu().numpy() for k, v in model.state_dict().items()}, losses
+    got, losses = run(True, True)
+    ref, ref_losses = run(False, False)
+    assert losses == ref_losses
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), f"{k}: captured + lazy differs from eager + sweep (max {np.abs(got[k].astype(np.float64) - ref[k]).max():.3e})"
+
+
+def test_cfg3_full():
+    """Ali-CCP 3-domain STAR at the per-GPU shard of BASELINE config 3 (batch 131 072 / 8), full vocabularies."""
+    cfg = copy.deepcopy(bench.CONFIGS[3])
+    assert cfg["batch"] == 16384 and max(cfg["vocabs"]) == 467298
+    run_config(cfg, seed=1)
+    _captured_lazy_equals_eager_sweep(3)
+
+
+def test_cfg4_full():
+    """Mind 4-domain PLE at the per-GPU shard of BASELINE config 4 (batch 65 536 / 8), the 748 000-row user table."""
+    cfg = copy.deepcopy(bench.CONFIGS[4])
+    assert cfg["batch"] == 8192 and max(cfg["vocabs"]) == 748000
+    run_config(cfg, seed=2)
+    _captured_lazy_equals_eager_sweep(4)
