@@ -101,7 +101,7 @@ int swr_embed_gather_fwd(const swr_sparse_slot* sparse_host, int n_sparse,
  * counterpart -- it restructures the backward of `embedding -> Linear`, basic/layers.py:64-105 + 253): columns
  * [oh_col, oh_col + oh_width) of `out`, slot s with oh_off[s] >= 0 owns columns oh_col + oh_off[s] + v, v < vocab_s, and
  * out[b, oh_col + oh_off[s] + v] = (row_s(b) == v) ? 1 : 0; unowned columns of the block and the alignment columns
- * [pad_col, oh_col) are zeros.  With the block in place, the weight-gradient product of the layer that consumes the
+ * [pad_col, oh_col) (fewer than 16) are zeros.  With the block in place, the weight-gradient product of the layer that consumes the
  * concat, dZ^T [out | one-hot] (swr_gemm_tn with a second destination), also yields S[v, :] = sum of dZ over the samples
  * whose row is v -- and the gradient of a small table is S W_t (swr_onehot_table_grads): its columns of dX are
  * never computed and it skips K3.  oh_width, oh_col multiples of 4, oh_width <= 256, n_sparse <= 64. */
@@ -158,6 +158,62 @@ int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, 
 int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const float* dbp /* nullable */, int N, int K, int Kp, int ohw,
                              const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables_host,
                              int n_tables, float* dW, int64_t lddw, float* db /* nullable */, int accumulate, void* stream);
+
+/* ---- fused lookup + first layer ("fl"; training; no reference counterpart: `embedding -> Linear`,
+ * basic/layers.py:64-105 + 253-258, with the lookup as the A-operand producer of the layer's products).  The [B, K0]
+ * concat is never written.  The layer's k axis is the COMPACT layout of the folded first layer above, in 8-column pieces:
+ *     [ pieces of the tables that keep an embedding (K3 tables) | dense-feature pieces | zero pieces ]  = 16 * n_real_groups
+ *     [ one-hot columns of the small tables ]                                                            = oh_width (<= 128)
+ * and three launches replace  lookup + fold + product:
+ *   swr_fl_prep : parameters only.  Wf = [W_big | W_d | 0 | P] split into three bf16 terms and laid out in MFMA fragment
+ *                 order (B3 image), bf16-term shadows of the tables of kind SWR_FL_PLANES, and Wt_sel (rows `sel` of W^T,
+ *                 the operand of the backward's dX product);
+ *   swr_fl_keys : ids only.  Row keys of slots [0, n_keys) ([n_keys][B] uint32: K3 and the weight-gradient product read
+ *                 them), the one-hot block as a 128-bit mask per sample (bit c = one-hot column c), the byte offset of every
+ *                 (32-row tile, group, lane)'s 48-byte piece (three 16-byte bf16 terms h | m | l of 8 columns), and the
+ *                 pieces of kind SWR_FL_ROWS / SWR_FL_DENSE gathered from fp32 and split;
+ *   swr_fl_fwd  : Z[B, N] = A' Wf^T + bias, per-32-row-tile (mean, M2) of every column -- fp32 results from six bf16
+ *                 MFMA products per real group and three per one-hot group (same arithmetic as swr_gemm_nt on the written
+ *                 concat); a lane's A fragment is three 16-byte loads through its offset, or 8 mask bits.
+ * Everything the launches exchange lives in ONE caller-owned workspace (swr_fl_workspace_bytes; sections:
+ * swr_fl_layout).  n_real_groups in [1, 16], oh_width a multiple of 16 (<= 128), N <= 160, dims multiples of 8. */
+enum { SWR_FL_ZERO = 0, SWR_FL_PLANES = 1, SWR_FL_ROWS = 2, SWR_FL_DENSE = 3 };
+typedef struct {
+    int32_t kind;          /* SWR_FL_*: zero padding / small table read through its bf16-term shadow / fp32 table rows
+                              (large, row-sparse tables) / dense-feature columns */
+    int32_t slot;          /* PLANES, ROWS: lookup slot; DENSE: first dense feature of the piece */
+    int32_t off;           /* PLANES, ROWS: first column inside the table row (multiple of 8) */
+    int32_t n_valid;       /* DENSE: features in the piece (<= 8; the rest are zero columns); others: 8 */
+    int32_t w_col;         /* first column of W behind the piece (n_valid consecutive columns) */
+    int32_t pad;
+} swr_fl_piece;
+typedef struct {
+    const swr_sparse_slot* sparse_host; int32_t n_sparse;   /* as swr_embed_gather_fwd; out_col = the slot's column in W */
+    const swr_dense_slot* dense_host; int32_t n_dense;
+    int32_t n_keys;                 /* slots [0, n_keys) get their row keys written (the slots that keep an embedding) */
+    int32_t n_real_groups;          /* 16-column groups in front of the one-hot block */
+    swr_fl_piece piece[32];         /* [2 * n_real_groups] */
+    int32_t oh_width;               /* one-hot columns (multiple of 16) */
+    const int32_t* oh_off_host;     /* [n_sparse]: first one-hot column of the slot, -1 = none */
+    int64_t B;
+    int32_t N;                      /* output columns of the layer (swr_fl_layout / swr_fl_keys accept 0 = not known yet) */
+    int32_t pad;
+} swr_fl_plan;
+typedef struct {                    /* byte offsets of the workspace sections (keys: what swr_embed_bwd* take) */
+    int64_t zero, planes, a3f, b3, keys, mask, mask_t, voff, densef, total;
+    int32_t nd4;                    /* row pitch of densef (fp32 dense features, [B][nd4]) */
+    int32_t n_fpieces;              /* pieces of kind ROWS / DENSE */
+} swr_fl_offsets;
+int swr_fl_layout(const swr_fl_plan* plan_host, swr_fl_offsets* out_host);
+size_t swr_fl_workspace_bytes(const swr_fl_plan* plan_host);
+int swr_fl_prep(const swr_fl_plan* plan_host, const float* W, int64_t ldw, int K,
+                const int32_t* oh_table /* [oh_width] (device): table of one-hot column o, -1 = padding */,
+                const swr_onehot_table* tables_host /* .grad = the table's weights */, int n_tables,
+                const int64_t* sel /* nullable */, int n_sel, float* Wt_sel, int64_t ldt,
+                void* workspace, void* stream);
+int swr_fl_keys(const swr_fl_plan* plan_host, void* workspace, uint32_t* err_flag, void* stream);
+int swr_fl_fwd(const swr_fl_plan* plan_host, const void* workspace, const float* bias /* nullable */,
+               float* Z, int64_t ldz, float* stat_partials /* nullable, [ceil(B/32)][N][2] */, void* stream);
 
 /* ------------------------------------------------------------------ K3 ----
  * Backward of the lookup: replaces aten::embedding_dense_backward (32 calls

@@ -191,7 +191,7 @@ extern "C" int swr_embed_gather_fwd_onehot(const swr_sparse_slot* sparse, int n_
     SWR_REQUIRE(B >= 0 && n_sparse >= 0 && n_dense >= 0 && out != nullptr && ld_out > 0, SWR_ERR_ARG);
     if (oh_width > 0) {
         SWR_REQUIRE(oh_off && n_sparse <= MAX_SPARSE && n_sparse > 0 && oh_width <= OH_MAX && oh_width % 4 == 0 && oh_col % 4 == 0 &&
-                        pad_col >= 0 && pad_col <= oh_col && oh_col - pad_col < 4 && oh_col + oh_width <= ld_out && ld_out % 4 == 0 &&
+                        pad_col >= 0 && pad_col <= oh_col && oh_col - pad_col < 16 && oh_col + oh_width <= ld_out && ld_out % 4 == 0 &&
                         swr_aligned16(out), SWR_ERR_ARG);
         for (int s = 0; s < n_sparse; ++s)
             SWR_REQUIRE(oh_off[s] < 0 || (sparse[s].hash_seed == 0 && sparse[s].vocab <= 0xFFFF &&

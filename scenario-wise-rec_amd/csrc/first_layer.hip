@@ -1,0 +1,712 @@
+// Fused lookup + first layer ("fl", include/swr.h): the lookup is the A-operand producer of the first layer's products.
+//
+// Reference: EmbeddingLayer.forward -> Linear of the stacked expert / gate (or shared-bottom) layer, basic/layers.py:64-105,
+// 253-258, mmoe.py:37-40.  The [B, K0] concat (and the compact [B, Kp + ohw] block A' of the folded first layer) is never
+// written: a lane of the product kernel fetches the 48 bytes it needs of its sample's table row through the row key.
+//
+//   fl_prep_kernel : parameters -> (a) B3, the folded weights Wf = [W_big | W_d | 0 | P] split into three bf16 terms
+//                    (x = h + m + l) in MFMA fragment order, one linear chunk per two 16-column groups: a chunk is one
+//                    LDS-DMA copy and every fragment read a conflict-free ds_read_b128 at lane * 16;
+//                    (b) the bf16-term shadow of every small table, piece-major: [row][dim / 8][h | m | l] x 16 bytes, so the
+//                    three terms of a lane's 8 columns are 48 consecutive bytes; (c) rows `sel` of W^T for the dX product.
+//   fl_keys_kernel : ids -> row keys [n_keys][B], one-hot mask (128 bits per sample, and transposed [4][B] for the
+//                    weight-gradient product), the byte offset of every (tile, group, lane)'s piece, and the pieces that
+//                    come from fp32 sources (row-sparse tables, dense features) gathered + split (A3f).
+//   fl_fwd_kernel  : a wave owns 32 samples and all N <= 160 columns (NT tiles of 32): per real group three 16-byte loads
+//                    per lane (ring of 4 groups in flight, inline-asm loads, one counted s_waitcnt per chunk), one-hot
+//                    groups expanded from 8 mask bits; weights streamed through a double-buffered LDS chunk by LDS-DMA;
+//                    6 (real) / 3 (one-hot) v_mfma_f32_32x32x16_bf16 per (group, tile); epilogue = gemm.hip's.
+// HBM traffic at config 2 (B = 65 536): keys launch ~17 MB of ids in, ~25 MB out; forward ~45 MB in (mostly L2 hits on
+// the shadows) + 38.8 MB of Z out -- against 72 MB written + 72 MB re-read for A' before.
+#include <algorithm>
+#include <cstring>
+
+#include "rows_epilogue.h"
+#include "split3.h"
+
+#define FL_MAX_GROUPS 16
+#define FL_MAX_OH_GROUPS 8
+#define FL_MAX_SPARSE 64
+#define FL_MAX_DENSE 32
+#define FL_MAX_TABLES 32
+#define FL_MAX_OHT 64
+#define FL_NT_MAX 5
+#define FL_THREADS 256
+#define FL_PIECE_BYTES 48
+
+// splitmix64 finaliser: the optional hash stage of the lookup (embed_fwd.hip)
+__device__ __forceinline__ uint64_t fl_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct FlDevPiece {           // what the keys launch needs of a piece
+    int16_t kind, slot, off, n_valid;
+    int16_t fp;               // index among the pieces of kind ROWS / DENSE
+    int16_t pad;
+    uint32_t base;            // PLANES: byte offset of the piece's column block in row 0 of the table's shadow
+    uint32_t rowbytes;        // PLANES: bytes per shadow row
+};
+struct FlPrepPiece {
+    int16_t kind, n_valid;
+    int32_t w_col;
+};
+struct FlTable {              // a table of kind PLANES (unique by weight pointer)
+    const float* w;
+    int32_t vocab, dim;
+    uint32_t planes_off;      // byte offset of its shadow in the workspace
+    int32_t first_item;       // first (row, piece) item of the table in the prep launch
+};
+
+static inline int fl_pitch_blocks(int nt) { return (6 * nt + 3) / 4 * 4; }     // 1-KB blocks per B3 chunk (4 waves x whole pieces)
+static inline int64_t fl_align(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct FlHost {
+    swr_fl_offsets o;
+    int NR, NOg, ncr, nco, NT, n_tiles;
+    FlDevPiece piece[2 * FL_MAX_GROUPS];
+    FlTable tbl[FL_MAX_TABLES];
+    int n_tbl;
+    int items_planes;
+    int8_t fpiece[2 * FL_MAX_GROUPS];
+};
+
+static int fl_build(const swr_fl_plan* p, FlHost& h) {
+    SWR_REQUIRE(p != nullptr, SWR_ERR_ARG);
+    SWR_REQUIRE(p->n_sparse >= 1 && p->n_sparse <= FL_MAX_SPARSE && p->sparse_host && p->n_dense >= 0 && p->n_dense <= FL_MAX_DENSE &&
+                    (p->n_dense == 0 || p->dense_host), SWR_ERR_ARG);
+    SWR_REQUIRE(p->n_real_groups >= 1 && p->n_real_groups <= FL_MAX_GROUPS && p->oh_width >= 0 && p->oh_width % 16 == 0 &&
+                    p->oh_width <= 16 * FL_MAX_OH_GROUPS && p->N >= 0 && p->N <= 32 * FL_NT_MAX && p->B >= 0 &&
+                    p->n_keys >= 0 && p->n_keys <= p->n_sparse && (p->oh_width == 0 || p->oh_off_host), SWR_ERR_ARG);
+    SWR_REQUIRE(p->B < (1ll << 31), SWR_ERR_UNSUPPORTED);
+    h.NR = p->n_real_groups;
+    h.NOg = p->oh_width / 16;
+    h.ncr = (h.NR + 1) / 2;
+    h.nco = (h.NOg + 1) / 2;
+    h.NT = p->N > 0 ? (p->N + 31) / 32 : FL_NT_MAX;        // (N = 0: not known yet -- the layout does not depend on it)
+    h.n_tiles = static_cast<int>((p->B + 31) / 32);
+    h.n_tbl = 0;
+    h.items_planes = 0;
+    int nfp = 0;
+    int64_t planes = 0;
+    for (int q = 0; q < 2 * h.NR; ++q) {
+        const swr_fl_piece& pc = p->piece[q];
+        FlDevPiece& d = h.piece[q];
+        std::memset(&d, 0, sizeof(d));
+        d.kind = static_cast<int16_t>(pc.kind);
+        d.fp = -1;
+        if (pc.kind == SWR_FL_ZERO) continue;
+        SWR_REQUIRE(pc.w_col >= 0, SWR_ERR_ARG);
+        if (pc.kind == SWR_FL_PLANES || pc.kind == SWR_FL_ROWS) {
+            SWR_REQUIRE(pc.slot >= 0 && pc.slot < p->n_sparse, SWR_ERR_ARG);
+            const swr_sparse_slot& sl = p->sparse_host[pc.slot];
+            SWR_REQUIRE(sl.weight && sl.idx && sl.vocab > 0 && sl.dim > 0 && sl.dim % 8 == 0 && pc.off >= 0 && pc.off % 8 == 0 &&
+                            pc.off + 8 <= sl.dim && swr_aligned16(sl.weight) && swr_is_index_dtype(sl.idx_dtype), SWR_ERR_ARG);
+            SWR_REQUIRE(sl.vocab <= 0xFFFFFFFFll, SWR_ERR_UNSUPPORTED);
+            d.slot = static_cast<int16_t>(pc.slot);
+            d.off = static_cast<int16_t>(pc.off);
+            d.n_valid = 8;
+            if (pc.kind == SWR_FL_PLANES) {
+                int t = 0;
+                while (t < h.n_tbl && h.tbl[t].w != sl.weight) ++t;
+                if (t == h.n_tbl) {
+                    SWR_REQUIRE(h.n_tbl < FL_MAX_TABLES, SWR_ERR_UNSUPPORTED);
+                    FlTable& T = h.tbl[h.n_tbl++];
+                    T.w = sl.weight;
+                    T.vocab = static_cast<int32_t>(sl.vocab);
+                    T.dim = sl.dim;
+                    T.planes_off = static_cast<uint32_t>(planes);      // relative to the planes section (fixed up below)
+                    T.first_item = h.items_planes;
+                    const int64_t bytes = sl.vocab * (sl.dim / 8) * FL_PIECE_BYTES;
+                    SWR_REQUIRE(sl.vocab < (1 << 24) && planes + bytes < (1ll << 30), SWR_ERR_UNSUPPORTED);
+                    planes += fl_align(bytes);
+                    h.items_planes += static_cast<int>(sl.vocab) * (sl.dim / 8);
+                }
+                SWR_REQUIRE(h.tbl[t].dim == sl.dim && h.tbl[t].vocab == sl.vocab, SWR_ERR_ARG);
+                d.base = h.tbl[t].planes_off + static_cast<uint32_t>(pc.off / 8) * FL_PIECE_BYTES;
+                d.rowbytes = static_cast<uint32_t>(sl.dim / 8) * FL_PIECE_BYTES;
+            } else {
+                h.fpiece[nfp] = static_cast<int8_t>(q);
+                d.fp = static_cast<int16_t>(nfp++);
+            }
+        } else if (pc.kind == SWR_FL_DENSE) {
+            SWR_REQUIRE(pc.slot >= 0 && pc.n_valid >= 1 && pc.n_valid <= 8 && pc.slot + pc.n_valid <= p->n_dense, SWR_ERR_ARG);
+            for (int e = 0; e < pc.n_valid; ++e)
+                SWR_REQUIRE(p->dense_host[pc.slot + e].values && swr_is_value_dtype(p->dense_host[pc.slot + e].dtype), SWR_ERR_DTYPE);
+            d.slot = static_cast<int16_t>(pc.slot);
+            d.n_valid = static_cast<int16_t>(pc.n_valid);
+            h.fpiece[nfp] = static_cast<int8_t>(q);
+            d.fp = static_cast<int16_t>(nfp++);
+        } else {
+            return SWR_ERR_ARG;
+        }
+    }
+    for (int s = 0; s < p->n_sparse; ++s) {
+        const swr_sparse_slot& sl = p->sparse_host[s];
+        SWR_REQUIRE(sl.idx && sl.vocab > 0 && sl.vocab <= 0xFFFFFFFFll && swr_is_index_dtype(sl.idx_dtype), SWR_ERR_ARG);
+        if (p->oh_width > 0 && p->oh_off_host[s] >= 0)
+            SWR_REQUIRE(sl.hash_seed == 0 && p->oh_off_host[s] + sl.vocab <= p->oh_width, SWR_ERR_ARG);
+    }
+    swr_fl_offsets& o = h.o;
+    o.n_fpieces = nfp;
+    o.nd4 = (p->n_dense + 3) / 4 * 4;
+    int64_t at = 0;
+    o.zero = at; at += 256;
+    o.planes = at; at += planes;
+    o.a3f = at; at += fl_align(static_cast<int64_t>(h.n_tiles) * nfp * 32 * FL_PIECE_BYTES);
+    SWR_REQUIRE(at < (1ll << 32), SWR_ERR_UNSUPPORTED);                 // everything a lane's 32-bit piece offset can reach
+    o.b3 = at; at += fl_align(static_cast<int64_t>(h.ncr + h.nco) * fl_pitch_blocks(FL_NT_MAX) * 1024);     // (sized for the widest layer)
+    o.keys = at; at += fl_align(static_cast<int64_t>(p->n_keys) * p->B * 4);
+    o.mask = at; at += fl_align(p->B * 16);
+    o.mask_t = at; at += fl_align(p->B * 16);
+    o.voff = at; at += fl_align(static_cast<int64_t>(h.n_tiles) * h.NR * 64 * 4);
+    o.densef = at; at += fl_align(p->B * o.nd4 * 4);
+    o.total = at;
+    for (int t = 0; t < h.n_tbl; ++t) h.tbl[t].planes_off += static_cast<uint32_t>(o.planes);
+    for (int q = 0; q < 2 * h.NR; ++q)
+        if (h.piece[q].kind == SWR_FL_PLANES) h.piece[q].base += static_cast<uint32_t>(o.planes);
+    return SWR_OK;
+}
+
+extern "C" int swr_fl_layout(const swr_fl_plan* plan, swr_fl_offsets* out) {
+    SWR_REQUIRE(out != nullptr, SWR_ERR_ARG);
+    FlHost h;
+    const int rc = fl_build(plan, h);
+    if (rc != SWR_OK) return rc;
+    *out = h.o;
+    return SWR_OK;
+}
+
+extern "C" size_t swr_fl_workspace_bytes(const swr_fl_plan* plan) {
+    FlHost h;
+    if (fl_build(plan, h) != SWR_OK) return 0;
+    return static_cast<size_t>(h.o.total);
+}
+
+// ------------------------------------------------------------------------------------------------ prep
+struct FlPrepK {
+    FlPrepPiece piece[2 * FL_MAX_GROUPS];
+    swr_onehot_table tab[FL_MAX_OHT];           // .grad = the table's weights
+    FlTable tbl[FL_MAX_TABLES];
+    int n_tbl, items_planes;
+    int NR, NOg, ncr, nco, NT, N, pitch_blocks;
+    const float* W; int64_t ldw;
+    const int32_t* oh_table;
+    const int64_t* sel; int n_sel; float* Wt; int64_t ldt;
+    char* ws; int64_t off_b3, off_zero;
+    int blocks_a, blocks_b;
+};
+
+__device__ __forceinline__ void fl_split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    SPLIT3_PAIR(v[0], v[1], h, m, l, 0);
+    SPLIT3_PAIR(v[2], v[3], h, m, l, 2);
+    SPLIT3_PAIR(v[4], v[5], h, m, l, 4);
+    SPLIT3_PAIR(v[6], v[7], h, m, l, 6);
+}
+
+__global__ __launch_bounds__(FL_THREADS) void fl_prep_kernel(const FlPrepK k) {
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk < k.blocks_a) {
+        // ---- B3: thread = (chunk group, column tile, lane) -> 8 folded weights -> three 16-byte terms
+        if (blk == 0 && tid < 16) reinterpret_cast<uint4*>(k.ws + k.off_zero)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        const int idx = blk * FL_THREADS + tid;
+        const int n_cg = 2 * (k.ncr + k.nco);
+        if (idx >= n_cg * k.NT * 64) return;
+        const int lane = idx & 63, t = (idx >> 6) % k.NT, cg = idx / (64 * k.NT);
+        const int j = lane & 31, s = lane >> 5, n = 32 * t + j;
+        const int chunk = cg >> 1, gq = cg & 1;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (n < k.N) {
+            const float* __restrict__ wrow = k.W + static_cast<int64_t>(n) * k.ldw;
+            if (chunk < k.ncr) {
+                const int g = 2 * chunk + gq;
+                if (g < k.NR) {
+                    const FlPrepPiece pc = k.piece[2 * g + s];
+                    if (pc.kind != SWR_FL_ZERO) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < pc.n_valid) v[e] = wrow[pc.w_col + e];
+                    }
+                }
+            } else {
+                const int q = 2 * (chunk - k.ncr) + gq;
+                if (q < k.NOg) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int o = 16 * q + 8 * s + e;
+                        const int tb = k.oh_table[o];
+                        if (tb >= 0) {
+                            // P[n, o] = sum_e emb_t[v, e] W[n, col_t + e]: the arithmetic of fold_fwd_kernel (embed_fwd.hip)
+                            const swr_onehot_table& T = k.tab[tb];
+                            const float* __restrict__ em = T.grad + static_cast<int64_t>(o - T.oh_off) * T.dim;
+                            const float* __restrict__ w = wrow + T.w_col;
+                            if ((T.dim & 3) == 0 && (T.w_col & 3) == 0 && (k.ldw & 3) == 0 &&
+                                (reinterpret_cast<uintptr_t>(k.W) & 15u) == 0 && (reinterpret_cast<uintptr_t>(T.grad) & 15u) == 0) {
+                                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                                for (int c = 0; c < T.dim; c += 4) {
+                                    const float4 ev = *reinterpret_cast<const float4*>(em + c), wv = *reinterpret_cast<const float4*>(w + c);
+                                    a0 = fmaf(ev.x, wv.x, a0); a1 = fmaf(ev.y, wv.y, a1); a2 = fmaf(ev.z, wv.z, a2); a3 = fmaf(ev.w, wv.w, a3);
+                                }
+                                v[e] = (a0 + a1) + (a2 + a3);
+                            } else {
+                                float acc = 0.f;
+                                for (int c = 0; c < T.dim; ++c) acc = fmaf(em[c], w[c], acc);
+                                v[e] = acc;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        bf16x8 h, m, l;
+        fl_split8(v, h, m, l);
+        bf16x8* d = reinterpret_cast<bf16x8*>(k.ws + k.off_b3 + static_cast<int64_t>(chunk) * k.pitch_blocks * 1024) +
+                    ((gq * k.NT + t) * 3) * 64 + lane;
+        d[0] = h;
+        d[64] = m;
+        d[128] = l;
+        return;
+    }
+    blk -= k.blocks_a;
+    if (blk < k.blocks_b) {
+        // ---- table shadows: thread = (row, 8-column piece) of one small table
+        const int it = blk * FL_THREADS + tid;
+        if (it >= k.items_planes) return;
+        int t = 0;
+        while (t + 1 < k.n_tbl && k.tbl[t + 1].first_item <= it) ++t;
+        const FlTable& T = k.tbl[t];
+        const int local = it - T.first_item, pieces = T.dim >> 3;
+        const int row = local / pieces, pc = local - row * pieces;
+        const float4* src = reinterpret_cast<const float4*>(T.w + static_cast<int64_t>(row) * T.dim + 8 * pc);
+        const float4 x0 = src[0], x1 = src[1];
+        const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        bf16x8 h, m, l;
+        fl_split8(v, h, m, l);
+        bf16x8* d = reinterpret_cast<bf16x8*>(k.ws + T.planes_off + static_cast<int64_t>(local) * FL_PIECE_BYTES);
+        d[0] = h;
+        d[1] = m;
+        d[2] = l;
+        return;
+    }
+    blk -= k.blocks_b;
+    // ---- Wt_sel[r, n] = W[n, sel[r]] (thread = one element, consecutive lanes along n)
+    const int64_t i = static_cast<int64_t>(blk) * FL_THREADS + tid;
+    if (i < static_cast<int64_t>(k.n_sel) * k.N) {
+        const int r = static_cast<int>(i / k.N), n = static_cast<int>(i - static_cast<int64_t>(r) * k.N);
+        k.Wt[r * k.ldt + n] = k.W[n * k.ldw + k.sel[r]];
+    }
+}
+
+extern "C" int swr_fl_prep(const swr_fl_plan* plan, const float* W, int64_t ldw, int K, const int32_t* oh_table,
+                           const swr_onehot_table* tables, int n_tables, const int64_t* sel, int n_sel, float* Wt_sel, int64_t ldt,
+                           void* workspace, void* stream) {
+    FlHost h;
+    int rc = fl_build(plan, h);
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(W && workspace && ldw >= K && K > 0 && n_tables >= 0 && n_tables <= FL_MAX_OHT && plan->N >= 1, SWR_ERR_ARG);
+    SWR_REQUIRE(plan->oh_width == 0 || (oh_table && tables && n_tables > 0), SWR_ERR_ARG);
+    SWR_REQUIRE(n_sel >= 0 && (n_sel == 0 || (sel && Wt_sel && ldt >= plan->N)), SWR_ERR_ARG);
+    FlPrepK k;
+    for (int q = 0; q < 2 * h.NR; ++q) {
+        const swr_fl_piece& pc = plan->piece[q];
+        SWR_REQUIRE(pc.kind == SWR_FL_ZERO || pc.w_col + (pc.kind == SWR_FL_DENSE ? pc.n_valid : 8) <= K, SWR_ERR_ARG);
+        k.piece[q].kind = static_cast<int16_t>(pc.kind);
+        k.piece[q].n_valid = static_cast<int16_t>(pc.kind == SWR_FL_DENSE ? pc.n_valid : 8);
+        k.piece[q].w_col = pc.w_col;
+    }
+    for (int t = 0; t < n_tables; ++t) {
+        SWR_REQUIRE(tables[t].grad && tables[t].vocab > 0 && tables[t].dim > 0 && tables[t].oh_off >= 0 &&
+                        tables[t].oh_off + tables[t].vocab <= plan->oh_width && tables[t].w_col >= 0 &&
+                        tables[t].w_col + tables[t].dim <= K, SWR_ERR_ARG);
+        k.tab[t] = tables[t];
+    }
+    for (int t = 0; t < h.n_tbl; ++t) k.tbl[t] = h.tbl[t];
+    k.n_tbl = h.n_tbl; k.items_planes = h.items_planes;
+    k.NR = h.NR; k.NOg = h.NOg; k.ncr = h.ncr; k.nco = h.nco; k.NT = h.NT; k.N = plan->N;
+    k.pitch_blocks = fl_pitch_blocks(h.NT);
+    k.W = W; k.ldw = ldw; k.oh_table = oh_table;
+    k.sel = sel; k.n_sel = n_sel; k.Wt = Wt_sel; k.ldt = ldt;
+    k.ws = static_cast<char*>(workspace); k.off_b3 = h.o.b3; k.off_zero = h.o.zero;
+    k.blocks_a = static_cast<int>(swr_ceil_div(static_cast<int64_t>(2 * (h.ncr + h.nco)) * h.NT * 64, FL_THREADS));
+    k.blocks_b = static_cast<int>(swr_ceil_div(h.items_planes, FL_THREADS));
+    const int blocks_c = static_cast<int>(swr_ceil_div(static_cast<int64_t>(n_sel) * plan->N, FL_THREADS));
+    hipLaunchKernelGGL(fl_prep_kernel, dim3(static_cast<unsigned>(k.blocks_a + k.blocks_b + blocks_c)), dim3(FL_THREADS), 0,
+                       static_cast<hipStream_t>(stream), k);
+    return swr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ keys
+#define FLK_TILE 64
+struct FlKeysK {
+    swr_sparse_slot sparse[FL_MAX_SPARSE];
+    swr_dense_slot dense[FL_MAX_DENSE];
+    FlDevPiece piece[2 * FL_MAX_GROUPS];
+    int16_t oh_off[FL_MAX_SPARSE];
+    int8_t fpiece[2 * FL_MAX_GROUPS];
+    int n_sparse, n_dense, n_keys, NR, ohw, nfp, nd4, n_tiles;
+    int64_t B;
+    char* ws;
+    int64_t off_keys, off_mask, off_mask_t, off_voff, off_a3f, off_densef;
+    uint32_t off_zero32, off_a3f32;
+    uint32_t* err;
+};
+
+__global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
+    __shared__ uint32_t s_row[FL_MAX_SPARSE][FLK_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b0 = static_cast<int64_t>(blockIdx.x) * FLK_TILE;
+    const int rows = static_cast<int>(min<int64_t>(FLK_TILE, a.B - b0));
+    uint32_t* __restrict__ keys = reinterpret_cast<uint32_t*>(a.ws + a.off_keys);
+
+    // 1. ids -> rows (layers.py:70 `.long()` lookup index; optional hash stage; out-of-range -> row 0 + sticky flag)
+    for (int s = wave; s < a.n_sparse; s += FL_THREADS / 64) {
+        const swr_sparse_slot& sl = a.sparse[s];
+        uint32_t row = 0;
+        if (lane < rows) {
+            int64_t id = swr_load_index(sl.idx, sl.idx_dtype, b0 + lane);
+            if (sl.hash_seed != 0u)
+                id = static_cast<int64_t>(fl_mix64(static_cast<uint64_t>(id) ^ sl.hash_seed) % static_cast<uint64_t>(sl.vocab));
+            if (id < 0 || id >= sl.vocab) {
+                if (a.err) atomicOr(a.err, SWR_FLAG_INDEX_OOR);
+                id = 0;
+            }
+            row = static_cast<uint32_t>(id);
+            if (s < a.n_keys) keys[static_cast<int64_t>(s) * a.B + b0 + lane] = row;
+        }
+        s_row[s][lane] = row;
+    }
+    __syncthreads();
+
+    // 2. one-hot block as bits: bit (oh_off_s + row_s) per small table
+    if (a.ohw > 0 && tid < rows) {
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+        for (int s = 0; s < a.n_sparse; ++s) {
+            const int off = a.oh_off[s];
+            if (off >= 0) {
+                const uint32_t bit = static_cast<uint32_t>(off) + s_row[s][tid];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if ((bit >> 5) == static_cast<uint32_t>(w)) m[w] |= 1u << (bit & 31u);
+            }
+        }
+        reinterpret_cast<uint4*>(a.ws + a.off_mask)[b0 + tid] = make_uint4(m[0], m[1], m[2], m[3]);
+        uint32_t* mt = reinterpret_cast<uint32_t*>(a.ws + a.off_mask_t);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mt[static_cast<int64_t>(w) * a.B + b0 + tid] = m[w];
+    }
+
+    // 3. the byte offset of every lane's piece: [tile][group][lane (s * 32 + i)]
+    uint32_t* __restrict__ voff = reinterpret_cast<uint32_t*>(a.ws + a.off_voff);
+    const int per_tile = a.NR * 64;
+    for (int it = tid; it < 2 * per_tile; it += FL_THREADS) {
+        const int tt = it >= per_tile ? 1 : 0;
+        const int rem = it - tt * per_tile;
+        const int g = rem >> 6, ln = rem & 63, i = ln & 31, s = ln >> 5;
+        const int64_t T = b0 / 32 + tt;
+        if (T >= a.n_tiles) continue;
+        const int r = 32 * tt + i;
+        const FlDevPiece& pc = a.piece[2 * g + s];
+        uint32_t v = a.off_zero32;
+        if (r < rows) {
+            if (pc.kind == SWR_FL_PLANES) v = pc.base + s_row[pc.slot][r] * pc.rowbytes;
+            else if (pc.kind != SWR_FL_ZERO) v = a.off_a3f32 + static_cast<uint32_t>((T * a.nfp + pc.fp) * 32 + i) * FL_PIECE_BYTES;
+        }
+        voff[(T * a.NR + g) * 64 + ln] = v;
+    }
+
+    // 4. pieces with fp32 sources: gather / cast, split into the three bf16 terms, 48 bytes per (sample, piece)
+    for (int it = tid; it < FLK_TILE * a.nfp; it += FL_THREADS) {
+        const int fp = it >> 6, r = it & 63;
+        if (r >= rows) continue;
+        const FlDevPiece& pc = a.piece[a.fpiece[fp]];
+        float v[8];
+        if (pc.kind == SWR_FL_ROWS) {
+            const swr_sparse_slot& sl = a.sparse[pc.slot];
+            const float4* src = reinterpret_cast<const float4*>(sl.weight + static_cast<int64_t>(s_row[pc.slot][r]) * sl.dim + pc.off);
+            const float4 x0 = src[0], x1 = src[1];
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = e < pc.n_valid ? swr_load_value(a.dense[pc.slot + e].values, a.dense[pc.slot + e].dtype, b0 + r) : 0.f;
+        }
+        bf16x8 h, m, l;
+        fl_split8(v, h, m, l);
+        const int64_t T = (b0 + r) / 32;
+        bf16x8* d = reinterpret_cast<bf16x8*>(a.ws + a.off_a3f + ((T * a.nfp + fp) * 32 + (r & 31)) * FL_PIECE_BYTES);
+        d[0] = h;
+        d[1] = m;
+        d[2] = l;
+    }
+
+    // 5. x[name].float() of the dense features (layers.py:88-89) as an fp32 block [B][nd4]: the weight-gradient product's operand
+    if (a.nd4 > 0) {
+        float* __restrict__ df = reinterpret_cast<float*>(a.ws + a.off_densef);
+        for (int it = tid; it < rows * a.nd4; it += FL_THREADS) {
+            const int r = it / a.nd4, c = it - r * a.nd4;
+            df[(b0 + r) * a.nd4 + c] = c < a.n_dense ? swr_load_value(a.dense[c].values, a.dense[c].dtype, b0 + r) : 0.f;
+        }
+    }
+}
+
+extern "C" int swr_fl_keys(const swr_fl_plan* plan, void* workspace, uint32_t* err_flag, void* stream) {
+    FlHost h;
+    int rc = fl_build(plan, h);
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(workspace != nullptr, SWR_ERR_ARG);
+    if (plan->B == 0) return SWR_OK;
+    FlKeysK a;
+    for (int s = 0; s < plan->n_sparse; ++s) {
+        a.sparse[s] = plan->sparse_host[s];
+        a.oh_off[s] = static_cast<int16_t>(plan->oh_width > 0 ? plan->oh_off_host[s] : -1);
+    }
+    for (int s = 0; s < plan->n_dense; ++s) a.dense[s] = plan->dense_host[s];
+    for (int q = 0; q < 2 * h.NR; ++q) a.piece[q] = h.piece[q];
+    for (int f = 0; f < h.o.n_fpieces; ++f) a.fpiece[f] = h.fpiece[f];
+    a.n_sparse = plan->n_sparse; a.n_dense = plan->n_dense; a.n_keys = plan->n_keys; a.NR = h.NR; a.ohw = plan->oh_width;
+    a.nfp = h.o.n_fpieces; a.nd4 = h.o.nd4; a.n_tiles = h.n_tiles; a.B = plan->B;
+    a.ws = static_cast<char*>(workspace);
+    a.off_keys = h.o.keys; a.off_mask = h.o.mask; a.off_mask_t = h.o.mask_t; a.off_voff = h.o.voff; a.off_a3f = h.o.a3f;
+    a.off_densef = h.o.densef;
+    a.off_zero32 = static_cast<uint32_t>(h.o.zero); a.off_a3f32 = static_cast<uint32_t>(h.o.a3f);
+    a.err = err_flag;
+    hipLaunchKernelGGL(fl_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(plan->B, FLK_TILE))), dim3(FL_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return swr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ forward product
+typedef __attribute__((address_space(3))) void* fl_lds_ptr;
+typedef __attribute__((address_space(1))) const void* fl_glb_ptr;
+
+// a lane's three 16-byte terms: 32-bit byte offset (VGPR) + the workspace base (SGPR pair)
+#define FL_ALOAD(dst, voff, sbase, OFF) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+
+typedef unsigned fl_u32x4 __attribute__((ext_vector_type(4)));
+
+struct FlFwdK {
+    swr_gemm_args e;              // epilogue fields: M, N, C, ldc, bias, stat_partials (groups = 1)
+    const char* ws;
+    const uint4* b3;
+    const uint32_t* voff;
+    const uint4* mask;
+    int NR, NOg, ncr, nco, n_tiles;
+};
+
+template <int NT>
+__global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
+    constexpr int PITCH_U4 = ((6 * NT + 3) / 4 * 4) * 64;       // uint4 per chunk (global pitch = LDS buffer size)
+    constexpr int PPW = PITCH_U4 / 64 / 4;                      // 1-KB DMA pieces per wave per chunk
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[]; // [2][PITCH_U4]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int i = lane & 31, s = lane >> 5;
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const bool live = tile < k.n_tiles;                         // (wave-uniform) a wave past the end computes the last tile again, stores nothing
+    const int64_t T = live ? tile : k.n_tiles - 1;
+    const int NR = k.NR, ncr = k.ncr, nct = k.ncr + k.nco;
+    const char* __restrict__ wsb = k.ws;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // piece offsets of all real groups (groups past NR repeat the last one: never used), the sample's one-hot bits
+    uint32_t vo[FL_MAX_GROUPS];
+    const uint32_t* __restrict__ vp = k.voff + T * NR * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < FL_MAX_GROUPS; ++g) vo[g] = vp[min(g, NR - 1) * 64];
+    fl_u32x4 mk = {0u, 0u, 0u, 0u};
+    if (k.nco > 0) mk = reinterpret_cast<const fl_u32x4*>(k.mask)[min<int64_t>(T * 32 + i, k.e.M - 1)];
+
+    fl_u32x4 ar[4][3];     // (native vectors: a HIP uint4 is a struct, which an asm "+v" operand cannot be)
+    auto a_issue = [&](uint32_t off, fl_u32x4 (&dst)[3]) {
+        FL_ALOAD(dst[0], off, wsb, 0);
+        FL_ALOAD(dst[1], off, wsb, 16);
+        FL_ALOAD(dst[2], off, wsb, 32);
+    };
+    // weights of chunk c -> LDS buffer: PITCH_U4 / 64 DMA pieces of 1 KB, PPW per wave
+    auto dma_chunk = [&](int c, int buf) {
+        const uint4* src = k.b3 + static_cast<size_t>(c) * PITCH_U4 + wave * (PPW * 64) + lane;
+        uint4* dst = lds + buf * PITCH_U4 + wave * (PPW * 64);
+#pragma unroll
+        for (int u = 0; u < PPW; ++u)
+            __builtin_amdgcn_global_load_lds((fl_glb_ptr)(src + u * 64), (fl_lds_ptr)(dst + u * 64), 16, 0, 0);
+    };
+    // six (real group) or three (exact A: one-hot group) products per column tile, small terms first
+    auto mma_group = [&](const uint4* bp, bf16x8 ah, bf16x8 am, bf16x8 al, auto exact_c) {
+        constexpr bool EX = decltype(exact_c)::value;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
+            f32x16 c_ = acc[t];
+            if (!EX) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, c_, 0, 0, 0);
+            if (!EX) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1, c_, 0, 0, 0);
+            if (!EX) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0, c_, 0, 0, 0);
+            acc[t] = c_;
+        }
+    };
+
+    a_issue(vo[0], ar[0]);
+    a_issue(vo[1], ar[1]);
+    if (NR > 2) a_issue(vo[2], ar[2]);
+    if (NR > 3) a_issue(vo[3], ar[3]);
+    dma_chunk(0, 0);
+    // everything has landed; the ring registers become usable HERE (the asm ties them: nothing that reads them moves above).
+    // The offsets and the mask are tied too: hipcc does not count the asm loads, so a wait it inserted in front of their
+    // first use further down would be a vmcnt(0) in the middle of the pipeline
+    {
+        // (operands are locals: an asm operand reached through the lambdas' by-reference captures is "indirect" to hipcc)
+        fl_u32x4 t0 = ar[0][0], t1 = ar[0][1], t2 = ar[0][2], t3 = ar[1][0], t4 = ar[1][1], t5 = ar[1][2];
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5),
+                       "+v"(vo[0]), "+v"(vo[4]), "+v"(vo[5]), "+v"(vo[6]), "+v"(vo[7]), "+v"(vo[8]), "+v"(vo[9]), "+v"(vo[10]),
+                       "+v"(vo[11]), "+v"(vo[12]), "+v"(vo[13]), "+v"(vo[14]), "+v"(vo[15]), "+v"(mk)
+                     :: "memory");
+        ar[0][0] = t0; ar[0][1] = t1; ar[0][2] = t2; ar[1][0] = t3; ar[1][1] = t4; ar[1][2] = t5;
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- real groups: chunk C = groups 2 C, 2 C + 1 (ring slots 2 (C & 1) + gq); fully unrolled over the maximum, a chunk
+    // past the end is skipped by a wave-uniform branch -- every index and every wait count inside is a compile-time constant
+    auto real_chunk = [&](auto c_c) {
+        constexpr int C = decltype(c_c)::value, BUF = C & 1;
+        if (C >= ncr) return;
+        if (C + 1 < nct) dma_chunk(C + 1, BUF ^ 1);
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = 2 * BUF + gq;
+            const uint4* bp = lds + BUF * PITCH_U4 + gq * (NT * 3 * 64) + lane;
+            // (an odd group count leaves the second half of the last chunk empty: its ring slot was never loaded, and
+            // whatever bits it holds -- NaN patterns included -- must not meet the zero weights)
+            if (2 * C + gq < NR)
+                mma_group(bp, __builtin_bit_cast(bf16x8, ar[slot][0]), __builtin_bit_cast(bf16x8, ar[slot][1]),
+                          __builtin_bit_cast(bf16x8, ar[slot][2]), std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);       // the slot's MFMAs are issued before its registers are re-loaded
+            // group 2 C + 4 + gq takes the slot (never a dummy load: the hardware would write the slot's registers after
+            // the compiler has given them to something else)
+            const int gn = 2 * C + 4 + gq;
+            if (gn < FL_MAX_GROUPS && gn < NR) a_issue(vo[gn < FL_MAX_GROUPS ? gn : 0], ar[slot]);
+        }
+        // all but the loads issued in THIS chunk have landed: the weights of chunk C + 1 and the A pieces of groups
+        // 2 C + 2, 2 C + 3 (slots of the other parity).  (wave-uniform choice between three counted waits)
+        constexpr int NB = 2 * (BUF ^ 1);
+        const int n_issued = __builtin_amdgcn_readfirstlane(min(2, max(0, NR - (2 * C + 4))));      // A groups loaded in this chunk (SGPR)
+        fl_u32x4 t0 = ar[NB][0], t1 = ar[NB][1], t2 = ar[NB][2], t3 = ar[NB + 1][0], t4 = ar[NB + 1][1], t5 = ar[NB + 1][2];
+        // ONE asm statement (the choice between the three counted waits is made inside it): with one statement per case
+        // hipcc resolved the tied operands of the three branches by copying the ring registers IN FRONT of the waits --
+        // reading registers whose loads were still in flight
+        asm volatile("s_cmp_eq_u32 %6, 2\n\t"
+                     "s_cbranch_scc1 1f\n\t"
+                     "s_cmp_eq_u32 %6, 1\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_branch 3f\n"
+                     "2:\n\t"
+                     "s_waitcnt vmcnt(3)\n\t"
+                     "s_branch 3f\n"
+                     "1:\n\t"
+                     "s_waitcnt vmcnt(6)\n"
+                     "3:\n\t"
+                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5)
+                     : "s"(n_issued)
+                     : "memory", "scc");
+        ar[NB][0] = t0; ar[NB][1] = t1; ar[NB][2] = t2; ar[NB + 1][0] = t3; ar[NB + 1][1] = t4; ar[NB + 1][2] = t5;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    real_chunk(std::integral_constant<int, 0>{}); real_chunk(std::integral_constant<int, 1>{});
+    real_chunk(std::integral_constant<int, 2>{}); real_chunk(std::integral_constant<int, 3>{});
+    real_chunk(std::integral_constant<int, 4>{}); real_chunk(std::integral_constant<int, 5>{});
+    real_chunk(std::integral_constant<int, 6>{}); real_chunk(std::integral_constant<int, 7>{});
+
+    // ---- one-hot groups: the A fragment is 8 bits of the sample's mask, expanded to bf16 1.0 / 0.0; exact in bf16, so the
+    // middle / low terms of A vanish and three products remain
+    auto oh_chunk = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        if (Q >= k.nco) return;
+        const int c = ncr + Q, buf = c & 1;
+        if (c + 1 < nct) dma_chunk(c + 1, buf ^ 1);
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            constexpr int dummy = 0; (void)dummy;
+            const int q = 2 * Q + gq;                                        // one-hot group: mask bytes 2 q, 2 q + 1
+            const uint32_t word = mk[q >> 1];
+            const uint32_t byte = (word >> (16 * (q & 1) + 8 * s)) & 0xFFu;
+            fl_u32x4 f;
+            f[0] = ((byte >> 0) & 1u) * 0x3F80u | ((byte >> 1) & 1u) * 0x3F800000u;
+            f[1] = ((byte >> 2) & 1u) * 0x3F80u | ((byte >> 3) & 1u) * 0x3F800000u;
+            f[2] = ((byte >> 4) & 1u) * 0x3F80u | ((byte >> 5) & 1u) * 0x3F800000u;
+            f[3] = ((byte >> 6) & 1u) * 0x3F80u | ((byte >> 7) & 1u) * 0x3F800000u;
+            const uint4* bp = lds + buf * PITCH_U4 + gq * (NT * 3 * 64) + lane;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, f);
+            if (q < k.NOg) mma_group(bp, ah, ah, ah, std::true_type{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    oh_chunk(std::integral_constant<int, 0>{}); oh_chunk(std::integral_constant<int, 1>{});
+    oh_chunk(std::integral_constant<int, 2>{}); oh_chunk(std::integral_constant<int, 3>{});
+    // (the ring's last re-loads may still be in flight: their registers are dead)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (!live) return;
+    rows_epilogue<NT>(k.e, k.n_tiles, acc, 0, T, T * 32, 0, i, s);
+}
+
+extern "C" int swr_fl_fwd(const swr_fl_plan* plan, const void* workspace, const float* bias, float* Z, int64_t ldz,
+                          float* stat_partials, void* stream) {
+    FlHost h;
+    int rc = fl_build(plan, h);
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(workspace && Z && plan->N >= 1 && ldz >= plan->N, SWR_ERR_ARG);
+    if (plan->B == 0) return SWR_OK;
+    FlFwdK k;
+    std::memset(&k, 0, sizeof(k));
+    k.e.M = plan->B; k.e.N = plan->N; k.e.K = 16 * h.NR + plan->oh_width;
+    k.e.C = Z; k.e.ldc = ldz; k.e.bias = bias; k.e.stat_partials = stat_partials; k.e.groups = 1;
+    const char* ws = static_cast<const char*>(workspace);
+    k.ws = ws;
+    k.b3 = reinterpret_cast<const uint4*>(ws + h.o.b3);
+    k.voff = reinterpret_cast<const uint32_t*>(ws + h.o.voff);
+    k.mask = reinterpret_cast<const uint4*>(ws + h.o.mask);
+    k.NR = h.NR; k.NOg = h.NOg; k.ncr = h.ncr; k.nco = h.nco; k.n_tiles = h.n_tiles;
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(h.n_tiles, 4)));
+    const unsigned lds = static_cast<unsigned>(2 * fl_pitch_blocks(h.NT) * 1024);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define FL_GO(NTV)                                                                                                      \
+    do {                                                                                                                \
+        static bool raised = false;                                                                                     \
+        if (lds >= 64 * 1024 && !raised) {                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fl_fwd_kernel<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    80 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;                                     \
+            raised = true;                                                                                              \
+        }                                                                                                               \
+        hipLaunchKernelGGL(fl_fwd_kernel<NTV>, grid, dim3(FL_THREADS), lds, st, k);                                     \
+    } while (0)
+    switch (h.NT) {
+        case 1: FL_GO(1); break;
+        case 2: FL_GO(2); break;
+        case 3: FL_GO(3); break;
+        case 4: FL_GO(4); break;
+        default: FL_GO(5); break;
+    }
+#undef FL_GO
+    return swr_launch_status();
+}

@@ -168,6 +168,26 @@ class OnehotTable(C.Structure):
     _fields_ = [("grad", C.c_void_p), ("vocab", C.c_int32), ("dim", C.c_int32), ("oh_off", C.c_int32), ("w_col", C.c_int32)]
 
 
+class FlPiece(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("slot", C.c_int32), ("off", C.c_int32), ("n_valid", C.c_int32), ("w_col", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+class FlPlan(C.Structure):
+    _fields_ = [("sparse_host", C.c_void_p), ("n_sparse", C.c_int32), ("dense_host", C.c_void_p), ("n_dense", C.c_int32),
+                ("n_keys", C.c_int32), ("n_real_groups", C.c_int32), ("piece", FlPiece * 32), ("oh_width", C.c_int32),
+                ("oh_off_host", C.c_void_p), ("B", C.c_int64), ("N", C.c_int32), ("pad", C.c_int32)]
+
+
+class FlOffsets(C.Structure):
+    _fields_ = [("zero", C.c_int64), ("planes", C.c_int64), ("a3f", C.c_int64), ("b3", C.c_int64), ("keys", C.c_int64),
+                ("mask", C.c_int64), ("mask_t", C.c_int64), ("voff", C.c_int64), ("densef", C.c_int64), ("total", C.c_int64),
+                ("nd4", C.c_int32), ("n_fpieces", C.c_int32)]
+
+
+FL_ZERO, FL_PLANES, FL_ROWS, FL_DENSE = 0, 1, 2, 3
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("step", C.c_int64), ("step_size", C.c_float),
@@ -188,6 +208,11 @@ _SIGS = {
     "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P]),
     "swr_fold_first_layer_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P, _I, _P]),
     "swr_onehot_table_grads": (C.c_int, [_P, _L, _P, _L, _I, _P, _I, _I, _P]),
+    "swr_fl_layout": (C.c_int, [_P, _P]),
+    "swr_fl_workspace_bytes": (_Z, [_P]),
+    "swr_fl_prep": (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _P, _I, _P, _L, _P, _P]),
+    "swr_fl_keys": (C.c_int, [_P, _P, _P, _P]),
+    "swr_fl_fwd": (C.c_int, [_P, _P, _P, _P, _L, _P, _P]),
     "swr_adam_catchup_multi": (C.c_int, [_P, _I, _P, _P, _P]),
     "swr_adam_rows_multi": (C.c_int, [_P, _I, _P, _P]),
     "swr_embed_bag_fwd": (C.c_int, [_P, _L, _I, _P, _I, _L, _I, _I, _I, _L, C.c_uint32, _P, _L, _I, _P, _P, _P, _P]),

@@ -78,7 +78,7 @@ def _new_plan(layer):
     plan = ops._GatherPlan()
     plan.sparse, plan.dense, plan.width = [], [], 0
     plan.bags = []
-    plan.onehot, plan.oh, plan.ctx, plan.fold, plan.wide = False, None, None, None, None
+    plan.onehot, plan.oh, plan.ctx, plan.fold, plan.wide, plan.fl = False, None, None, None, None, None
     plan.lazy = {}
     plan.dense_limit_bytes = layer.dense_table_limit_bytes
     return plan, []
@@ -138,6 +138,7 @@ def _run_plan(plan, weights):
         info.compact, info.n_sel = compact, len(cols)
         info.sel = _sel_tensor(tuple(cols), out.device) if cols else None
         info.fold, info.wide, info.K = plan.fold is not None, plan.wide, plan.width
+        info.fl = getattr(plan, "fl", None)
         if plan.fold is not None:
             f = plan.fold
             info.col0, info.Kp = f["col0"], f["Kp"]

@@ -436,7 +436,7 @@ def _split_like(flat, tensors):
 # =========================================================================== embedding gather
 class _GatherPlan:
     """Static description of one EmbeddingLayer lookup (built per call, cheap)."""
-    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide")
+    __slots__ = ("sparse", "dense", "width", "ld", "dense_limit_bytes", "lazy", "want_grad", "bags", "onehot", "oh", "ctx", "fold", "wide", "fl")
     # onehot: the caller promises that ONE LinearBNAct consumes the lookup (see OneHotInfo); oh: the block laid out by forward
     # bags: SequenceFeature lookups, dicts(wpos, idx [B, L], vocab, dim, col, L, mode 0 sum / 1 mean / 2 concat, pad, seed)
 
@@ -445,6 +445,9 @@ ONEHOT = os.environ.get("SWR_ONEHOT", "1") != "0"
 ONEHOT_MAX_VOCAB = int(os.environ.get("SWR_ONEHOT_MAX_VOCAB", "16"))
 ONEHOT_MAX_WIDTH = int(os.environ.get("SWR_ONEHOT_MAX_WIDTH", "128"))
 FOLD = os.environ.get("SWR_FOLD", "1") != "0"       # the lookup writes [E_big | dense | one-hot] only; the layer folds the rest
+# fused lookup + first layer (csrc/first_layer.hip): the lookup writes NOTHING but keys / one-hot bits / piece offsets; the
+# consuming layer's products fetch table rows through the keys ("0": the folded layout is written as before)
+FUSED_LOOKUP = os.environ.get("SWR_FUSED_LOOKUP", "1") != "0"
 
 
 class OneHotInfo(object):
@@ -455,7 +458,20 @@ class OneHotInfo(object):
       * computes dX only for the columns of the other tables (`sel`), compactly, and passes it to the lookup's backward
         through `ctx` (autograd carries a zero-stride placeholder)."""
     __slots__ = ("ctx", "oh_col", "oh_width", "tables", "tables_p", "params", "sel", "n_sel", "compact",
-                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K")
+                 "fold", "wide", "col0", "Kp", "src", "inv", "ohtab", "K", "fl")
+
+    def materialize(self):
+        """The written folded layout [B, ld] of a FUSED lookup (`fl`), produced on demand by the ordinary gather launch: for
+        a consumer the fused product does not take (more than 160 output columns, SWR_GEMM=f32 / bf16)."""
+        if self.wide is None:
+            f = self.fl
+            wide = torch.empty((f["B"], f["ld"]), dtype=torch.float32, device=f["dev"])
+            sp, dn, oh_off = f["gather"]
+            H.check(lib.swr_embed_gather_fwd_onehot(sp, f["ns"], dn, f["nd"], f["B"], H.ptr(wide), f["ld"], None, oh_off, f["pad_col"],
+                                                    f["oh_col"], f["oh_width"], H.ptr(H.err_flag(f["dev"])), H.stream()),
+                    "swr_embed_gather_fwd_onehot")
+            self.wide = wide
+        return self.wide
 
 
 def _grad_slot_layout(plan, weights, n_grad_slots):
@@ -527,16 +543,34 @@ class EmbedGather(Function):
                         dn_col.append(cc)
                         src.append(col)
                         cc += 1
-                    Kp = (cc - col0 + 3) // 4 * 4
+                    # fused lookup (FUSED_LOOKUP, csrc/first_layer.hip): k axis in 8-column pieces, 16-column groups -- every
+                    # table takes a gradient and has a multiple of 8 columns, at most 16 groups in front of the one-hot block
+                    n_pieces = sum(sl[3] // 8 for i, sl in enumerate(plan.sparse) if i not in oh_set) + (len(plan.dense) + 7) // 8
+                    # (the LAYOUT -- 16-column groups -- is taken whenever the lookup qualifies; FUSED_LOOKUP only chooses between the
+                    # fused launches and the written block, so that the two can be compared bit for bit)
+                    fl_ok = (ctx.n_grad_slots == ns and n_pieces <= 32 and len(plan.dense) <= 32
+                             and all(sl[3] % 8 == 0 and weights[sl[0]].is_contiguous() and weights[sl[0]].dtype == torch.float32
+                                     and weights[sl[0]].data_ptr() % 16 == 0
+                                     for i, sl in enumerate(plan.sparse) if i not in oh_set)
+                             and all(weights[sl[0]].numel() * 4 > plan.dense_limit_bytes or sl[2] < (1 << 24) for sl in plan.sparse)
+                             and lib.swr_gemm_precision_mode() == 1)
+                    Kp = (cc - col0 + 15) // 16 * 16 if fl_ok else (cc - col0 + 3) // 4 * 4
+                    if fl_ok:
+                        oh_width = (off + 15) // 16 * 16
                     src.extend([-1] * (Kp - (cc - col0)))
                     pad_col, oh_col = cc, col0 + Kp
-                    plan.fold = {"col0": col0, "Kp": Kp, "src": tuple(src), "sp_col": sp_col, "dn_col": dn_col}
+                    plan.fold = {"col0": col0, "Kp": Kp, "src": tuple(src), "sp_col": sp_col, "dn_col": dn_col, "fl": fl_ok and FUSED_LOOKUP}
                 plan.ld = oh_col + oh_width
         fold = getattr(plan, "fold", None) if plan.oh else None
-        out = torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
+        fl = fold is not None and fold.get("fl", False) and B > 0
+        # (fused lookup: nothing of the concat is written -- autograd carries a zero-stride placeholder of its shape)
+        out = _zero_scalar(dev).expand(B, plan.ld) if fl else torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
         sp = (H.SparseSlot * max(ns, 1))()
+        sp_fl = (H.SparseSlot * max(ns, 1))() if fl else None
         for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse):
             H.require_device(idx, weights[wpos])
+            if fl:                          # the fused launches see the slot as it is: real width, its column in W
+                sp_fl[i] = H.SparseSlot(weights[wpos].data_ptr(), idx.data_ptr(), vocab, dim, H.dtype_code(idx), col, seed)
             if fold is not None:            # compact column; a folded (one-hot) slot writes no embedding at all (dim 0)
                 col, dim = (fold["sp_col"][i], dim) if i in fold["sp_col"] else (0, 0)
             sp[i] = H.SparseSlot(weights[wpos].data_ptr(), idx.data_ptr(), vocab, dim, H.dtype_code(idx), col, seed)
@@ -557,9 +591,41 @@ class EmbedGather(Function):
             from .optim import catchup_many
             catchup_many(behind)               # one claim + one replay launch for all large tables of the lookup
         need_keys = ctx.n_grad_slots > 0
-        keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns) else None
+        keys = torch.empty(ns * B, dtype=torch.int32, device=dev) if (need_keys and ns and not fl) else None
         flag = H.err_flag(dev)
-        if plan.oh:
+        plan.fl = None
+        if fl:
+            # keys, one-hot bits, piece offsets and the fp32-sourced pieces -- one launch; the products of the consuming layer
+            # fetch the rows themselves (csrc/first_layer.hip)
+            n_k3 = ns - len(plan.oh)
+            fp = H.FlPlan()
+            fp.sparse_host, fp.n_sparse = C.cast(sp_fl, C.c_void_p), ns
+            fp.dense_host, fp.n_dense = C.cast(dn, C.c_void_p), nd
+            fp.n_keys, fp.oh_width, fp.oh_off_host, fp.B, fp.N = n_k3, oh_width, C.cast(oh_off, C.c_void_p), B, 0
+            q = 0
+            for i, (wpos, idx, vocab, dim, col, seed) in enumerate(plan.sparse):
+                if i not in fold["sp_col"]:
+                    continue
+                kind = H.FL_ROWS if weights[wpos].numel() * 4 > plan.dense_limit_bytes else H.FL_PLANES
+                for o8 in range(0, dim, 8):
+                    fp.piece[q] = H.FlPiece(kind, i, o8, 8, col + o8, 0)
+                    q += 1
+            for d0 in range(0, nd, 8):
+                fp.piece[q] = H.FlPiece(H.FL_DENSE, d0, 0, min(8, nd - d0), plan.dense[d0][1], 0)
+                q += 1
+            fp.n_real_groups = fold["Kp"] // 16
+            while q < 2 * fp.n_real_groups:
+                fp.piece[q] = H.FlPiece(H.FL_ZERO, 0, 0, 0, 0, 0)
+                q += 1
+            offs = H.FlOffsets()
+            H.check(lib.swr_fl_layout(C.byref(fp), C.byref(offs)), "swr_fl_layout")
+            ws = torch.empty(offs.total, dtype=torch.uint8, device=dev)
+            H.check(lib.swr_fl_keys(C.byref(fp), H.ptr(ws), H.ptr(flag), H.stream()), "swr_fl_keys")
+            keys = ws[offs.keys:offs.keys + 4 * n_k3 * B].view(torch.int32) if n_k3 else None
+            plan.fl = {"plan": fp, "ws": ws, "offs": offs, "keep": (sp_fl, dn, oh_off), "gather": (sp, dn, oh_off), "ns": ns, "nd": nd,
+                       "B": B, "ld": plan.ld, "dev": dev, "pad_col": pad_col, "oh_col": oh_col, "oh_width": oh_width}
+            plan.wide = None
+        elif plan.oh:
             H.check(lib.swr_embed_gather_fwd_onehot(sp, ns, dn, nd, B, H.ptr(out), plan.ld, H.ptr(keys), oh_off, pad_col,
                                                     oh_col, oh_width, H.ptr(flag), H.stream()), "swr_embed_gather_fwd_onehot")
             plan.wide = out
@@ -822,7 +888,9 @@ class LinearBNAct(Function):
         rest = rest[nw:] if cfg["has_bias"] else rest
         gammas, betas = (rest[:cfg["n_bn"]], rest[cfg["n_bn"]:]) if cfg["bn"] is not None else ((), ())
         H.require_device(x, Ws[0])
-        x = H.f32c(x)
+        oh_in = getattr(x_in, "_swr_onehot", None)
+        if oh_in is None or oh_in.fl is None:
+            x = H.f32c(x)                    # (a fused lookup hands over a zero-stride placeholder: nothing to make contiguous)
         W = _cat_params(Ws)
         b = _cat_params(bs) if bs else None
         G = cfg["groups"]
@@ -836,19 +904,15 @@ class LinearBNAct(Function):
         partials = torch.empty((n_tiles, Ntot, 2), dtype=torch.float32, device=dev) if training else None
         planes = planes_t = None
         ctx.wt_sel = None
+        ctx.fl_fused = False
         # (weights pre-split into bf16 planes once per step -- ops.split_weights + gemm(B_split=...) -- were measured 16 us
         # per step SLOWER at config 2 than the split inside every workgroup; the entry points stay, the layers do not use them)
-        oh_in = getattr(x_in, "_swr_onehot", None)
         if oh_in is not None and oh_in.fold:
             # the lookup wrote [E_big | dense | one-hot] only (OneHotInfo / include/swr.h "folded first layer"): multiply
             # that with the folded weights [W_big | W_dense | P], P_t[:, v] = W_t emb_t[v]
             if G != 1 or K != oh_in.K or not oh_tables(oh_in):
                 raise H.SwrError("a lookup made with onehot=True must feed ONE ungrouped Linear over all its columns")
             Kf = oh_in.Kp + oh_in.oh_width
-            x = oh_in.wide[:, oh_in.col0:oh_in.col0 + Kf]
-            # (launching this fold on the side stream beside the lookup -- it depends on parameters only -- was measured: the
-            # extra fork / join pair costs more than the 6 us it hides, 0.4988 vs 0.4937 ms per step)
-            Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
             tabs = (H.OnehotTable * len(oh_in.tables_p))()
             for j, (p_t, vocab, dim, off, col) in enumerate(oh_in.tables_p):
                 tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
@@ -856,13 +920,30 @@ class LinearBNAct(Function):
             # forward-time fork, no cross-stream edge in front of dX)
             want_t = bool(ctx.needs_input_grad[1]) and oh_in.n_sel > 0 and Ntot % 4 == 0
             Wt_sel = torch.empty((oh_in.n_sel, Ntot), dtype=torch.float32, device=dev) if want_t else None
-            H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
-                                                 H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf,
-                                                 H.ptr(oh_in.sel) if want_t else None, oh_in.n_sel if want_t else 0,
-                                                 H.ptr(Wt_sel), Ntot, H.stream()),
-                    "swr_fold_first_layer_fwd")
             ctx.wt_sel = Wt_sel
-            gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp)
+            if oh_in.fl is not None and Ntot <= 160 and lib.swr_gemm_precision_mode() == 1:
+                # fused lookup (csrc/first_layer.hip): the product fetches its A operand through the row keys -- one
+                # parameter-sized launch (folded weights in fragment order, the small tables' bf16-term shadows, W^T rows),
+                # then the product
+                f = oh_in.fl
+                f["plan"].N = Ntot
+                H.check(lib.swr_fl_prep(C.byref(f["plan"]), H.ptr(W), W.stride(0), K, H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p),
+                                        H.ptr(oh_in.sel) if want_t else None, oh_in.n_sel if want_t else 0, H.ptr(Wt_sel), Ntot,
+                                        H.ptr(f["ws"]), H.stream()), "swr_fl_prep")
+                H.check(lib.swr_fl_fwd(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(b), H.ptr(Z), Ntot, H.ptr(partials), H.stream()),
+                        "swr_fl_fwd")
+                ctx.fl_fused = True
+            else:
+                x = (oh_in.materialize() if oh_in.fl is not None else oh_in.wide)[:, oh_in.col0:oh_in.col0 + Kf]
+                # (launching this fold on the side stream beside the lookup -- it depends on parameters only -- was measured: the
+                # extra fork / join pair costs more than the 6 us it hides, 0.4988 vs 0.4937 ms per step)
+                Wf = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
+                H.check(lib.swr_fold_first_layer_fwd(H.ptr(W), W.stride(0), Ntot, K, oh_in.Kp, oh_in.oh_width, H.ptr(oh_in.src),
+                                                     H.ptr(oh_in.inv), H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p), H.ptr(Wf), Kf,
+                                                     H.ptr(oh_in.sel) if want_t else None, oh_in.n_sel if want_t else 0,
+                                                     H.ptr(Wt_sel), Ntot, H.stream()),
+                        "swr_fold_first_layer_fwd")
+                gemm("nt", x, Wf, Z, M, N, Kf, bias=b, stat_partials=partials, a_exact_from=oh_in.Kp)
             planes_t = None
             epi_act = 0
         else:
@@ -1007,7 +1088,10 @@ class LinearBNAct(Function):
                 Kf = oh.Kp + oh.oh_width
                 dWp = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
                 dbp = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
-                gemm_tn(dZ, x, dWp, M, N, Kf, colsum=dbp)
+                xa = x
+                if ctx.fl_fused:      # the forward never wrote A': the gather launch writes it now, on this (the weight-gradient) branch
+                    xa = oh.materialize()[:, oh.col0:oh.col0 + Kf]
+                gemm_tn(dZ, xa, dWp, M, N, Kf, colsum=dbp)
                 tw = (H.OnehotTable * len(oh.tables_p))()
                 tg = (H.OnehotTable * len(oh.tables))()
                 for j, ((p_t, vocab, dim, off, col), (g_t, *_r)) in enumerate(zip(oh.tables_p, oh.tables)):

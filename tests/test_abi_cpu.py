@@ -51,7 +51,8 @@ def test_struct_layouts_match_the_header():
                "swr_mix_desc": H.MixDesc, "swr_adam_hyper": H.AdamHyper, "swr_adam_table": H.AdamTable,
                "swr_dp_table": H.DpTable, "swr_star_layer_args": H.StarLayerArgs,
                "swr_take_column": H.TakeColumn, "swr_layernorm_args": H.LayerNormArgs,
-               "swr_onehot_table": H.OnehotTable}
+               "swr_onehot_table": H.OnehotTable, "swr_fl_piece": H.FlPiece, "swr_fl_plan": H.FlPlan,
+               "swr_fl_offsets": H.FlOffsets}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "swr.h"', 'int main(void){']
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -957,16 +957,19 @@ def test_sequence_pooled_lookup(B, L, dim, pooling, pad, idx_dtype, limit, monke
     np.testing.assert_allclose(got_grad, want_grad, rtol=0, atol=2e-6 * max(1.0, np.abs(want_grad).max()))
 
 
-@pytest.mark.parametrize("fold", [False, True], ids=["block", "folded"])
+@pytest.mark.parametrize("fold", [False, True, "fused"], ids=["block", "folded", "fused"])
 def test_gather_one_hot_block_of_small_tables(fold, monkeypatch):
     """`onehot=True` (training): behind the concat, ONE-HOT columns of the tables with <= 16 rows -- out[b, oh + off_t + v]
-    = (id_t(b) == v), exact 0.0 / 1.0; the alignment column in between is zero.  `block`: the embeddings themselves are
+    = (id_t(b) == v), exact 0.0 / 1.0; the alignment columns in between are zero.  `block`: the embeddings themselves are
     unchanged; `folded`: only [embeddings of the other tables | dense | 0 | one-hot] is written, behind the ordinary
-    columns (the consuming layer folds the small tables into its weights)."""
+    columns (the consuming layer folds the small tables into its weights), in 16-column groups; `fused`: nothing is written
+    at all (csrc/first_layer.hip) -- the same block appears when a consumer asks for it (OneHotInfo.materialize), and the
+    keys / one-hot bits the fused products read are checked here against the ids."""
     from scenario_wise_rec import ops
     from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
     from scenario_wise_rec.basic.layers import EmbeddingLayer
-    monkeypatch.setattr(ops, "FOLD", fold)
+    monkeypatch.setattr(ops, "FOLD", bool(fold))
+    monkeypatch.setattr(ops, "FUSED_LOOKUP", fold == "fused")
     rng = np.random.default_rng(5)
     B, vocabs = 333, [2, 200, 7, 16, 17, 3]
     feats = [SparseFeature(f"s{i}", v, 16) for i, v in enumerate(vocabs)] + [DenseFeature("d0"), DenseFeature("d1"), DenseFeature("d2")]
@@ -980,21 +983,34 @@ def test_gather_one_hot_block_of_small_tables(fold, monkeypatch):
     plain = layer(xd, feats, squeeze_dim=True)
     out = layer(xd, feats, squeeze_dim=True, onehot=True)
     info = out._swr_onehot
-    assert out.shape[1] == 6 * 16 + 3 and info.oh_width == 28    # 2 + 7 + 16 + 3 = 28 one-hot columns
-    want = np.zeros((B, 28), np.float32)
+    assert out.shape[1] == 6 * 16 + 3 and info.oh_width == (32 if fold else 28)    # 2 + 7 + 16 + 3 = 28 one-hot columns
+    want = np.zeros((B, info.oh_width), np.float32)
     if fold:
-        wide = info.wide.detach().cpu().numpy()
+        assert (info.wide is None) == (fold == "fused") and (info.fl is not None) == (fold == "fused")
+        wide = info.materialize().detach().cpu().numpy() if fold == "fused" else info.wide.detach().cpu().numpy()
         pl = plain.detach().cpu().numpy()
-        # compact block from column 100: tables s1 (200 rows) and s4 (17 rows), the three dense features, one pad column
-        assert info.col0 == 100 and info.Kp == 36 and info.oh_col == 136 and wide.shape[1] == 164
+        # compact block from column 100: tables s1 (200 rows) and s4 (17 rows), the three dense features, 13 pad columns
+        assert info.col0 == 100 and info.Kp == 48 and info.oh_col == 148 and wide.shape[1] == 180
         assert np.array_equal(wide[:, 100:116], pl[:, 16:32]) and np.array_equal(wide[:, 116:132], pl[:, 64:80])
-        assert np.array_equal(wide[:, 132:135], pl[:, 96:99]) and np.array_equal(wide[:, 135], np.zeros(B, np.float32))
+        assert np.array_equal(wide[:, 132:135], pl[:, 96:99]) and np.array_equal(wide[:, 135:148], np.zeros((B, 13), np.float32))
         off = 0
         for i, v in enumerate(vocabs):
             if v <= 16:
                 want[np.arange(B), off + x[f"s{i}"]] = 1.0
                 off += v
-        assert np.array_equal(wide[:, 136:], want)
+        assert np.array_equal(wide[:, 148:], want)
+        if fold == "fused":
+            f = info.fl
+            ws, o = f["ws"], f["offs"]
+            keys = ws[o.keys:o.keys + 4 * 2 * B].view(torch.int32).cpu().numpy().reshape(2, B)
+            assert np.array_equal(keys[0], x["s1"]) and np.array_equal(keys[1], x["s4"])          # the slots that keep an embedding
+            mask = ws[o.mask:o.mask + 16 * B].cpu().numpy().reshape(B, 16)
+            bits = np.unpackbits(mask, axis=1, bitorder="little")[:, :32]
+            assert np.array_equal(bits.astype(np.float32), want)
+            mt = ws[o.mask_t:o.mask_t + 16 * B].view(torch.int32).cpu().numpy().reshape(4, B)
+            assert np.array_equal(mt.T.copy().view(np.uint8).reshape(B, 16), mask)
+            df = ws[o.densef:o.densef + 4 * o.nd4 * B].view(torch.float32).cpu().numpy().reshape(B, o.nd4)
+            assert o.nd4 == 4 and np.array_equal(df[:, :3], pl[:, 96:99]) and not df[:, 3].any()
         return
     assert torch.equal(out, plain)
     assert info.oh_col == 100                                    # behind column 99 (+1 pad)
@@ -1250,3 +1266,104 @@ def test_gemm_presplit_weights_give_the_same_bits(M, N, K):
     ops.gemm("nt", G, W.t().contiguous(), D0, M, K, N)
     ops.gemm("nt", G, W, D1, M, K, N, ldb=N, B_split=planes_t)
     assert torch.equal(D0, D1)
+
+
+def _fused_case(family, E, vocabs, n_dense, B, limit, seed):
+    """One training step of a model whose first layer reads the lookup alone: (probabilities, loss, every gradient)."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.models.multi_domain import MMOE, SharedBottom
+    from scenario_wise_rec.trainers import CTRTrainer
+    from _golden import perturb_product
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    feats = [SparseFeature(f"s{i}", v, E) for i, v in enumerate(vocabs)] + [DenseFeature(f"d{i}") for i in range(n_dense)]
+    if family == "MMOE":
+        model = MMOE(feats, domain_num=5, n_expert=4, expert_params={"dims": [32]}, tower_params={"dims": [16]})
+    else:
+        model = SharedBottom(feats, domain_num=3, bottom_params={"dims": [128]}, tower_params={"dims": [8]})
+    perturb_product(model, seed)
+    if limit is not None:
+        model.set_dense_table_limit(limit)
+    x = {f"s{i}": rng.integers(0, v, size=B).astype([np.int64, np.int32, np.int16][i % 3] if v < 30000 else np.int64)
+         for i, v in enumerate(vocabs)}
+    x.update({f"d{i}": (rng.random(B).astype(np.float32) if i % 2 == 0 else rng.integers(0, 5, size=B).astype(np.float16))
+              for i in range(n_dense)})
+    x["domain_indicator"] = rng.integers(0, 5 if family == "MMOE" else 3, size=B)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    trainer = CTRTrainer(model, "fused-case", optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device="cuda")
+    model.train()
+    xd = {k: _dev(v) for k, v in x.items()}
+    p = model(xd)
+    loss = trainer.criterion(p, _dev(y))
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    H.check_errors()
+    grads = {}
+    for k, prm in model.named_parameters():
+        sg = getattr(prm, "_swr_sparse_grad", None)
+        grads[k] = (sg[0].cpu().numpy(), sg[1].cpu().numpy()) if sg is not None else prm.grad.cpu().numpy().copy()
+    return p.detach().cpu().numpy(), float(loss.detach()), grads, model, x, y
+
+
+@pytest.mark.parametrize("family,E,vocabs,n_dense,B,limit", [
+    ("MMOE", 16, [1000, 5000, 8, 2, 3, 51, 1472, 16, 35, 4, 119, 455, 6, 3, 200, 300], 4, 4096 + 37, 65536),   # KuaiRand-like: 9 + 1 real groups incl. a row-sparse table, 5 one-hot groups
+    ("MMOE", 16, [7, 50, 3000, 2], 2, 1000, None),                    # (the smoke shape) odd group counts: 3 real + 1 one-hot
+    ("MMOE", 16, [40, 50, 5], 0, 250, None),                          # no dense features
+    ("SharedBottom", 8, [6040, 3706, 2, 21, 3439, 18], 1, 4096, None),   # MovieLens shape: E = 8 (two tables per group), N = 128
+    ("SharedBottom", 32, [300, 9, 1000], 3, 65, 20000),               # E = 32: four pieces per table; one tile and a bit
+], ids=["kuairand_like", "smoke_shape", "no_dense", "movielens_e8", "e32_ragged"])
+def test_fused_lookup_step_is_bitwise_the_written_layout(family, E, vocabs, n_dense, B, limit, monkeypatch):
+    """csrc/first_layer.hip against the path it replaces: with SWR_FUSED_LOOKUP off the lookup WRITES the folded block
+    [E_big | dense | 0 | one-hot] and swr_gemm_nt multiplies it; with it on, nothing is written and the product fetches
+    table rows through the keys.  Same k order, same six / three bf16 products per group, same epilogue: every
+    probability, the loss and every gradient must agree BIT FOR BIT (the written path itself is pinned against the
+    reference-generated fixtures and the oracle by the family tests)."""
+    from scenario_wise_rec import ops
+    monkeypatch.setattr(ops, "FUSED_LOOKUP", False)
+    p0, l0, g0, *_ = _fused_case(family, E, vocabs, n_dense, B, limit, 3)
+    monkeypatch.setattr(ops, "FUSED_LOOKUP", True)
+    calls = []
+    real = ops.lib.swr_fl_fwd
+    monkeypatch.setattr(ops.lib, "swr_fl_fwd", lambda *a: (calls.append(1), real(*a))[1])
+    p1, l1, g1, *_ = _fused_case(family, E, vocabs, n_dense, B, limit, 3)
+    assert calls, "the fused product was not taken"
+    assert np.array_equal(p0, p1) and l0 == l1
+    assert set(g0) == set(g1)
+    for k in g0:
+        if isinstance(g0[k], tuple):
+            assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]), k
+        else:
+            assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
+
+
+def test_fused_lookup_step_against_the_oracle():
+    """The fused lookup + first layer directly against the fp64 oracle (KuaiRand-like shape, a row-sparse table, fp16 / int
+    dense features): logits within 1e-4, loss, every gradient."""
+    from _golden import assert_probs_close
+    from oracle.models import OracleModel
+    from oracle.nn import Dense, Sparse
+    vocabs = [1000, 5000, 8, 2, 3, 51, 1472, 16, 35, 4, 119, 455, 6, 3, 200, 300]
+    from scenario_wise_rec import ops
+    assert ops.FUSED_LOOKUP
+    p, loss, grads, model, x, y = _fused_case("MMOE", 16, vocabs, 4, 2048 + 5, 65536, 9)
+    # (perturb_product ran before the step: the state the step started from = the current parameters, untouched by backward)
+    state0 = {k: (v.detach().cpu().numpy().astype(np.float64) if v.dtype.is_floating_point else v.cpu().numpy().copy())
+              for k, v in model.state_dict().items()}
+    # running statistics moved in the forward pass: the oracle's train-mode forward does not read them
+    ofe = [Sparse(f"s{i}", v, 16) for i, v in enumerate(vocabs)] + [Dense(f"d{i}") for i in range(4)]
+    om = OracleModel("MMOE", dict(features=ofe, domain_num=5, n_expert=4, expert_params={"dims": [32]}, tower_params={"dims": [16]}),
+                     state0, dtype=np.float64)
+    xo = {k: (v.astype(np.float64) if k.startswith("d") and k != "domain_indicator" else v) for k, v in x.items()}
+    op, oloss, ograds = om.loss_and_grads(xo, y)
+    assert_probs_close(p, op, tol=1e-4)
+    assert abs(loss - oloss) < 2e-6 * max(1.0, abs(oloss))
+    for k, g in ograds.items():
+        if isinstance(grads[k], tuple):
+            r, gg = grads[k]
+            got = np.zeros(g.shape)
+            np.add.at(got, r[r >= 0], gg[r >= 0].astype(np.float64))
+        else:
+            got = grads[k]
+        np.testing.assert_allclose(got, g, rtol=0, atol=2e-4 * max(1e-6, float(np.abs(g).max())) + 3e-7, err_msg=k)
