@@ -214,6 +214,16 @@ int swr_fl_prep(const swr_fl_plan* plan_host, const float* W, int64_t ldw, int K
 int swr_fl_keys(const swr_fl_plan* plan_host, void* workspace, uint32_t* err_flag, void* stream);
 int swr_fl_fwd(const swr_fl_plan* plan_host, const void* workspace, const float* bias /* nullable */,
                float* Z, int64_t ldz, float* stat_partials /* nullable, [ceil(B/32)][N][2] */, void* stream);
+/* Weight gradient of the layer with the same gathered operand: dWp[N, Kp + ohw] = dZ^T A' and colsum[n] = sum_b dZ[b, n]
+ * (nullable) -- what swr_gemm_tn(dZ, written block) gives, bit for bit (same batch splits, same fixed-order reduction; the
+ * one-hot column tiles take three products instead of six: their middle / low terms are zero).  The staging threads read 8
+ * row keys per column pair and stage, then 8-byte pieces of the table rows.  `workspace`: swr_fl_dw_workspace_bytes.
+ * swr_fl_dw_supported = 0: the shape is not the bf16-split kernel's (batch < 4096, N > 160, SWR_GEMM != default) -- the
+ * caller writes the block (swr_embed_gather_fwd_onehot) and uses swr_gemm_tn. */
+int swr_fl_dw_supported(const swr_fl_plan* plan_host, int64_t lddz);
+size_t swr_fl_dw_workspace_bytes(const swr_fl_plan* plan_host);
+int swr_fl_dw(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,
+              float* colsum /* nullable */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K3 ----
  * Backward of the lookup: replaces aten::embedding_dense_backward (32 calls

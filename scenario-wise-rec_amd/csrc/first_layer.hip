@@ -23,6 +23,7 @@
 
 #include "rows_epilogue.h"
 #include "split3.h"
+#include "tn_gather.h"
 
 #define FL_MAX_GROUPS 16
 #define FL_MAX_OH_GROUPS 8
@@ -210,66 +211,56 @@ __global__ __launch_bounds__(FL_THREADS) void fl_prep_kernel(const FlPrepK k) {
     const int tid = threadIdx.x;
     int blk = blockIdx.x;
     if (blk < k.blocks_a) {
-        // ---- B3: thread = (chunk group, column tile, lane) -> 8 folded weights -> three 16-byte terms
+        // ---- B3: thread = ONE folded weight (chunk group, column tile, lane, element): its three bf16 terms go out as three
+        // 2-byte stores, the 8 threads of a 16-byte fragment piece are adjacent lanes (a thread per piece walked its eight
+        // dot products one after the other: 13 us for a parameter-sized launch)
         if (blk == 0 && tid < 16) reinterpret_cast<uint4*>(k.ws + k.off_zero)[tid] = make_uint4(0u, 0u, 0u, 0u);
         const int idx = blk * FL_THREADS + tid;
         const int n_cg = 2 * (k.ncr + k.nco);
-        if (idx >= n_cg * k.NT * 64) return;
-        const int lane = idx & 63, t = (idx >> 6) % k.NT, cg = idx / (64 * k.NT);
+        if (idx >= n_cg * k.NT * 512) return;
+        const int e = idx & 7, lane = (idx >> 3) & 63, t = (idx >> 9) % k.NT, cg = idx / (512 * k.NT);
         const int j = lane & 31, s = lane >> 5, n = 32 * t + j;
         const int chunk = cg >> 1, gq = cg & 1;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        float v = 0.f;
         if (n < k.N) {
             const float* __restrict__ wrow = k.W + static_cast<int64_t>(n) * k.ldw;
             if (chunk < k.ncr) {
                 const int g = 2 * chunk + gq;
                 if (g < k.NR) {
                     const FlPrepPiece pc = k.piece[2 * g + s];
-                    if (pc.kind != SWR_FL_ZERO) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (e < pc.n_valid) v[e] = wrow[pc.w_col + e];
-                    }
+                    if (pc.kind != SWR_FL_ZERO && e < pc.n_valid) v = wrow[pc.w_col + e];
                 }
             } else {
                 const int q = 2 * (chunk - k.ncr) + gq;
-                if (q < k.NOg) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int o = 16 * q + 8 * s + e;
-                        const int tb = k.oh_table[o];
-                        if (tb >= 0) {
-                            // P[n, o] = sum_e emb_t[v, e] W[n, col_t + e]: the arithmetic of fold_fwd_kernel (embed_fwd.hip)
-                            const swr_onehot_table& T = k.tab[tb];
-                            const float* __restrict__ em = T.grad + static_cast<int64_t>(o - T.oh_off) * T.dim;
-                            const float* __restrict__ w = wrow + T.w_col;
-                            if ((T.dim & 3) == 0 && (T.w_col & 3) == 0 && (k.ldw & 3) == 0 &&
-                                (reinterpret_cast<uintptr_t>(k.W) & 15u) == 0 && (reinterpret_cast<uintptr_t>(T.grad) & 15u) == 0) {
-                                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                                for (int c = 0; c < T.dim; c += 4) {
-                                    const float4 ev = *reinterpret_cast<const float4*>(em + c), wv = *reinterpret_cast<const float4*>(w + c);
-                                    a0 = fmaf(ev.x, wv.x, a0); a1 = fmaf(ev.y, wv.y, a1); a2 = fmaf(ev.z, wv.z, a2); a3 = fmaf(ev.w, wv.w, a3);
-                                }
-                                v[e] = (a0 + a1) + (a2 + a3);
-                            } else {
-                                float acc = 0.f;
-                                for (int c = 0; c < T.dim; ++c) acc = fmaf(em[c], w[c], acc);
-                                v[e] = acc;
-                            }
+                const int o = 16 * q + 8 * s + e;
+                const int tb = q < k.NOg ? k.oh_table[o] : -1;
+                if (tb >= 0) {
+                    // P[n, o] = sum_e emb_t[v, e] W[n, col_t + e]: the arithmetic of fold_fwd_kernel (embed_fwd.hip)
+                    const swr_onehot_table& T = k.tab[tb];
+                    const float* __restrict__ em = T.grad + static_cast<int64_t>(o - T.oh_off) * T.dim;
+                    const float* __restrict__ w = wrow + T.w_col;
+                    if ((T.dim & 3) == 0 && (T.w_col & 3) == 0 && (k.ldw & 3) == 0 &&
+                        (reinterpret_cast<uintptr_t>(k.W) & 15u) == 0 && (reinterpret_cast<uintptr_t>(T.grad) & 15u) == 0) {
+                        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                        for (int c = 0; c < T.dim; c += 4) {
+                            const float4 ev = *reinterpret_cast<const float4*>(em + c), wv = *reinterpret_cast<const float4*>(w + c);
+                            a0 = fmaf(ev.x, wv.x, a0); a1 = fmaf(ev.y, wv.y, a1); a2 = fmaf(ev.z, wv.z, a2); a3 = fmaf(ev.w, wv.w, a3);
                         }
+                        v = (a0 + a1) + (a2 + a3);
+                    } else {
+                        float acc = 0.f;
+                        for (int c = 0; c < T.dim; ++c) acc = fmaf(em[c], w[c], acc);
+                        v = acc;
                     }
                 }
             }
         }
-        bf16x8 h, m, l;
-        fl_split8(v, h, m, l);
-        bf16x8* d = reinterpret_cast<bf16x8*>(k.ws + k.off_b3 + static_cast<int64_t>(chunk) * k.pitch_blocks * 1024) +
-                    ((gq * k.NT + t) * 3) * 64 + lane;
-        d[0] = h;
-        d[64] = m;
-        d[128] = l;
+        const Bf3 sp3 = split3(v);
+        __bf16* d = reinterpret_cast<__bf16*>(k.ws + k.off_b3 + static_cast<int64_t>(chunk) * k.pitch_blocks * 1024) +
+                    (((gq * k.NT + t) * 3) * 64 + lane) * 8 + e;
+        d[0] = sp3.h;
+        d[512] = sp3.m;
+        d[1024] = sp3.l;
         return;
     }
     blk -= k.blocks_a;
@@ -332,7 +323,7 @@ extern "C" int swr_fl_prep(const swr_fl_plan* plan, const float* W, int64_t ldw,
     k.W = W; k.ldw = ldw; k.oh_table = oh_table;
     k.sel = sel; k.n_sel = n_sel; k.Wt = Wt_sel; k.ldt = ldt;
     k.ws = static_cast<char*>(workspace); k.off_b3 = h.o.b3; k.off_zero = h.o.zero;
-    k.blocks_a = static_cast<int>(swr_ceil_div(static_cast<int64_t>(2 * (h.ncr + h.nco)) * h.NT * 64, FL_THREADS));
+    k.blocks_a = static_cast<int>(swr_ceil_div(static_cast<int64_t>(2 * (h.ncr + h.nco)) * h.NT * 512, FL_THREADS));
     k.blocks_b = static_cast<int>(swr_ceil_div(h.items_planes, FL_THREADS));
     const int blocks_c = static_cast<int>(swr_ceil_div(static_cast<int64_t>(n_sel) * plan->N, FL_THREADS));
     hipLaunchKernelGGL(fl_prep_kernel, dim3(static_cast<unsigned>(k.blocks_a + k.blocks_b + blocks_c)), dim3(FL_THREADS), 0,
@@ -347,7 +338,7 @@ struct FlKeysK {
     swr_dense_slot dense[FL_MAX_DENSE];
     FlDevPiece piece[2 * FL_MAX_GROUPS];
     int16_t oh_off[FL_MAX_SPARSE];
-    int8_t fpiece[2 * FL_MAX_GROUPS];
+    int32_t fpiece[2 * FL_MAX_GROUPS];      // (32-bit: read with scalar loads)
     int n_sparse, n_dense, n_keys, NR, ohw, nfp, nd4, n_tiles;
     int64_t B;
     char* ws;
@@ -356,37 +347,136 @@ struct FlKeysK {
     uint32_t* err;
 };
 
+// Everything a thread loads from HBM is issued before anything is consumed: the launch is a chain of dependent round trips
+// (ids -> rows -> table rows) on a few MB, i.e. latency, and a thread that walks its slots one load at a time (the first
+// form: 22 us) pays a round trip per slot.
+#define FLK_IDS 16        // ids per thread: slots (tid >> 6) + 4 j of sample tid & 63
+#define FLK_FP 4          // fp32-sourced pieces per thread (64 samples x at most 16 pieces)
+template <int DDT>
+__device__ __forceinline__ float fl_dense(const swr_dense_slot& d, int64_t i) {
+    return DDT == SWR_F32 ? static_cast<const float*>(d.values)[i] : swr_load_value(d.values, d.dtype, i);
+}
+// IDT: the common dtype of all id columns (SWR_I64 / SWR_I32), or 0: per-slot dispatch; DDT: SWR_F32 when every dense
+// feature is fp32 (a per-load dtype switch makes every load wait where it stands)
+template <int IDT, int DDT>
 __global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
     __shared__ uint32_t s_row[FL_MAX_SPARSE][FLK_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the descriptor arrays, copied out of the kernel argument once (one coalesced round of vector loads): indexed in place
+    // with anything but a compile-time constant, hipcc fetched every field with a vector load from the kernarg segment and
+    // waited for it on the spot -- a round trip per field per slot (22 us for this launch)
+    __shared__ swr_sparse_slot c_sp[FL_MAX_SPARSE];
+    __shared__ swr_dense_slot c_dn[FL_MAX_DENSE];
+    __shared__ FlDevPiece c_pc[2 * FL_MAX_GROUPS];
+    __shared__ int32_t c_fp[2 * FL_MAX_GROUPS];
+    __shared__ int16_t c_oh[FL_MAX_SPARSE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.sparse);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(c_sp);
+        for (int w = tid; w < a.n_sparse * static_cast<int>(sizeof(swr_sparse_slot) / 4); w += FL_THREADS) dst[w] = src[w];
+        src = reinterpret_cast<const uint32_t*>(a.dense);
+        dst = reinterpret_cast<uint32_t*>(c_dn);
+        for (int w = tid; w < a.n_dense * static_cast<int>(sizeof(swr_dense_slot) / 4); w += FL_THREADS) dst[w] = src[w];
+        src = reinterpret_cast<const uint32_t*>(a.piece);
+        dst = reinterpret_cast<uint32_t*>(c_pc);
+        for (int w = tid; w < 2 * a.NR * static_cast<int>(sizeof(FlDevPiece) / 4); w += FL_THREADS) dst[w] = src[w];
+        if (tid < 2 * FL_MAX_GROUPS) c_fp[tid] = a.fpiece[tid];
+        if (tid < FL_MAX_SPARSE) c_oh[tid] = a.oh_off[tid];
+    }
+    __syncthreads();
     const int64_t b0 = static_cast<int64_t>(blockIdx.x) * FLK_TILE;
     const int rows = static_cast<int>(min<int64_t>(FLK_TILE, a.B - b0));
     uint32_t* __restrict__ keys = reinterpret_cast<uint32_t*>(a.ws + a.off_keys);
+    const int64_t bl = b0 + min(lane, rows - 1);                 // (lanes past the end re-read the last sample; nothing is stored)
 
     // 1. ids -> rows (layers.py:70 `.long()` lookup index; optional hash stage; out-of-range -> row 0 + sticky flag)
-    for (int s = wave; s < a.n_sparse; s += FL_THREADS / 64) {
-        const swr_sparse_slot& sl = a.sparse[s];
-        uint32_t row = 0;
-        if (lane < rows) {
-            int64_t id = swr_load_index(sl.idx, sl.idx_dtype, b0 + lane);
-            if (sl.hash_seed != 0u)
-                id = static_cast<int64_t>(fl_mix64(static_cast<uint64_t>(id) ^ sl.hash_seed) % static_cast<uint64_t>(sl.vocab));
-            if (id < 0 || id >= sl.vocab) {
-                if (a.err) atomicOr(a.err, SWR_FLAG_INDEX_OOR);
-                id = 0;
-            }
-            row = static_cast<uint32_t>(id);
-            if (s < a.n_keys) keys[static_cast<int64_t>(s) * a.B + b0 + lane] = row;
+    int64_t id[FLK_IDS];
+#pragma unroll
+    for (int j = 0; j < FLK_IDS; ++j) {
+        const int s = wave + 4 * j;
+        id[j] = 0;
+        if (s < a.n_sparse) {
+            if (IDT == SWR_I64) id[j] = static_cast<const int64_t*>(c_sp[s].idx)[bl];
+            else if (IDT == SWR_I32) id[j] = static_cast<const int32_t*>(c_sp[s].idx)[bl];
+            else id[j] = swr_load_index(c_sp[s].idx, c_sp[s].idx_dtype, bl);
         }
+    }
+    // (two passes: every id is turned into a row before the first store -- with the stores interleaved, hipcc waited for
+    // each store to retire before it would look at the next id)
+    bool oor = false;
+    uint32_t rowj[FLK_IDS];
+#pragma unroll
+    for (int j = 0; j < FLK_IDS; ++j) {
+        const int s = wave + 4 * j;
+        rowj[j] = 0u;
+        if (s < a.n_sparse) {
+            const int64_t v = id[j];
+            const bool bad = (v < 0 || v >= c_sp[s].vocab) && c_sp[s].hash_seed == 0u;
+            oor = oor || bad;
+            rowj[j] = (lane < rows && !bad) ? static_cast<uint32_t>(v) : 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FLK_IDS; ++j) {
+        const int s = wave + 4 * j;
+        if (s < a.n_sparse && c_sp[s].hash_seed == 0u) {
+            if (s < a.n_keys && lane < rows) keys[static_cast<int64_t>(s) * a.B + b0 + lane] = rowj[j];
+            s_row[s][lane] = rowj[j];
+        }
+    }
+    // hashed slots (none in the reference's configurations): a rolled loop -- the 64-bit modulo is ~100 instructions, and
+    // sixteen inlined copies of it evicted the rest of the kernel from the instruction cache
+#pragma unroll 1
+    for (int s = wave; s < a.n_sparse; s += FL_THREADS / 64) {
+        const swr_sparse_slot& sl = c_sp[s];
+        if (sl.hash_seed == 0u) continue;
+        const int64_t raw = swr_load_index(sl.idx, sl.idx_dtype, bl);
+        const uint32_t row = lane < rows ? static_cast<uint32_t>(fl_mix64(static_cast<uint64_t>(raw) ^ sl.hash_seed) % static_cast<uint64_t>(sl.vocab)) : 0u;
+        if (s < a.n_keys && lane < rows) keys[static_cast<int64_t>(s) * a.B + b0 + lane] = row;
         s_row[s][lane] = row;
     }
+    if (oor && lane < rows && a.err) atomicOr(a.err, SWR_FLAG_INDEX_OOR);
     __syncthreads();
 
-    // 2. one-hot block as bits: bit (oh_off_s + row_s) per small table
+    // 2. the fp32-sourced pieces and the dense block: every load now, the splits and stores at the end
+    float fv[FLK_FP][8];
+#pragma unroll
+    for (int u = 0; u < FLK_FP; ++u) {
+        const int fp = wave + 4 * u, r = min(lane, rows - 1);      // item tid + 256 u: piece (wave-uniform), sample
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[u][e] = 0.f;
+        if (fp < a.nfp) {
+            const FlDevPiece& pc = c_pc[c_fp[fp]];
+            if (pc.kind == SWR_FL_ROWS) {
+                const swr_sparse_slot& sl = c_sp[pc.slot];
+                const float4* src = reinterpret_cast<const float4*>(sl.weight + static_cast<int64_t>(s_row[pc.slot][r]) * sl.dim + pc.off);
+                const float4 x0 = src[0], x1 = src[1];
+                fv[u][0] = x0.x; fv[u][1] = x0.y; fv[u][2] = x0.z; fv[u][3] = x0.w;
+                fv[u][4] = x1.x; fv[u][5] = x1.y; fv[u][6] = x1.z; fv[u][7] = x1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < pc.n_valid) fv[u][e] = fl_dense<DDT>(c_dn[pc.slot + e], b0 + r);
+            }
+        }
+    }
+    // x[name].float() of the dense features (layers.py:88-89) as an fp32 block [B][nd4]: the weight-gradient product's operand
+    float dv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * FL_THREADS;
+        if (it < rows * a.nd4) {
+            const int r = it / a.nd4, c = it - r * a.nd4;
+            if (c < a.n_dense) dv[u] = fl_dense<DDT>(c_dn[c], b0 + r);
+        }
+    }
+
+    // 3. one-hot block as bits: bit (oh_off_s + row_s) per small table
     if (a.ohw > 0 && tid < rows) {
         uint32_t m[4] = {0u, 0u, 0u, 0u};
         for (int s = 0; s < a.n_sparse; ++s) {
-            const int off = a.oh_off[s];
+            const int off = c_oh[s];
             if (off >= 0) {
                 const uint32_t bit = static_cast<uint32_t>(off) + s_row[s][tid];
 #pragma unroll
@@ -400,40 +490,60 @@ __global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
         for (int w = 0; w < 4; ++w) mt[static_cast<int64_t>(w) * a.B + b0 + tid] = m[w];
     }
 
-    // 3. the byte offset of every lane's piece: [tile][group][lane (s * 32 + i)]
+    // 4. the byte offset of every lane's piece: [tile][group][lane (s * 32 + i)]
     uint32_t* __restrict__ voff = reinterpret_cast<uint32_t*>(a.ws + a.off_voff);
-    const int per_tile = a.NR * 64;
-    for (int it = tid; it < 2 * per_tile; it += FL_THREADS) {
-        const int tt = it >= per_tile ? 1 : 0;
-        const int rem = it - tt * per_tile;
-        const int g = rem >> 6, ln = rem & 63, i = ln & 31, s = ln >> 5;
+    for (int wg = wave; wg < 2 * a.NR; wg += FL_THREADS / 64) {       // (tile of the block, group): wave-uniform
+        const int tt = wg >= a.NR ? 1 : 0, g = wg - tt * a.NR;
+        const int i = lane & 31, s = lane >> 5;
         const int64_t T = b0 / 32 + tt;
         if (T >= a.n_tiles) continue;
         const int r = 32 * tt + i;
-        const FlDevPiece& pc = a.piece[2 * g + s];
+        const FlDevPiece p0 = c_pc[2 * g], p1 = c_pc[2 * g + 1];
+        const int kind = s ? p1.kind : p0.kind, slot = s ? p1.slot : p0.slot, fp = s ? p1.fp : p0.fp;
+        const uint32_t base = s ? p1.base : p0.base, rowbytes = s ? p1.rowbytes : p0.rowbytes;
         uint32_t v = a.off_zero32;
         if (r < rows) {
-            if (pc.kind == SWR_FL_PLANES) v = pc.base + s_row[pc.slot][r] * pc.rowbytes;
-            else if (pc.kind != SWR_FL_ZERO) v = a.off_a3f32 + static_cast<uint32_t>((T * a.nfp + pc.fp) * 32 + i) * FL_PIECE_BYTES;
+            if (kind == SWR_FL_PLANES) v = base + s_row[slot][r] * rowbytes;
+            else if (kind != SWR_FL_ZERO) v = a.off_a3f32 + static_cast<uint32_t>((T * a.nfp + fp) * 32 + i) * FL_PIECE_BYTES;
         }
-        voff[(T * a.NR + g) * 64 + ln] = v;
+        voff[(T * a.NR + g) * 64 + lane] = v;
     }
 
-    // 4. pieces with fp32 sources: gather / cast, split into the three bf16 terms, 48 bytes per (sample, piece)
-    for (int it = tid; it < FLK_TILE * a.nfp; it += FL_THREADS) {
+    // 5. split the gathered pieces into the three bf16 terms, 48 bytes per (sample, piece); store the dense block
+#pragma unroll
+    for (int u = 0; u < FLK_FP; ++u) {
+        const int fp = wave + 4 * u, r = lane;
+        if (fp < a.nfp && r < rows) {
+            bf16x8 h, m, l;
+            fl_split8(fv[u], h, m, l);
+            const int64_t T = (b0 + r) / 32;
+            bf16x8* d = reinterpret_cast<bf16x8*>(a.ws + a.off_a3f + ((T * a.nfp + fp) * 32 + (r & 31)) * FL_PIECE_BYTES);
+            d[0] = h;
+            d[1] = m;
+            d[2] = l;
+        }
+    }
+    float* __restrict__ df = reinterpret_cast<float*>(a.ws + a.off_densef);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * FL_THREADS;
+        if (it < rows * a.nd4) df[b0 * a.nd4 + it] = dv[u];
+    }
+    // (more than 16 fp32-sourced pieces or more than 8 dense features: the rest, item by item)
+    for (int it = tid + FLK_FP * FL_THREADS; it < FLK_TILE * a.nfp; it += FL_THREADS) {
         const int fp = it >> 6, r = it & 63;
         if (r >= rows) continue;
-        const FlDevPiece& pc = a.piece[a.fpiece[fp]];
+        const FlDevPiece& pc = c_pc[c_fp[fp]];
         float v[8];
         if (pc.kind == SWR_FL_ROWS) {
-            const swr_sparse_slot& sl = a.sparse[pc.slot];
+            const swr_sparse_slot& sl = c_sp[pc.slot];
             const float4* src = reinterpret_cast<const float4*>(sl.weight + static_cast<int64_t>(s_row[pc.slot][r]) * sl.dim + pc.off);
             const float4 x0 = src[0], x1 = src[1];
             v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                v[e] = e < pc.n_valid ? swr_load_value(a.dense[pc.slot + e].values, a.dense[pc.slot + e].dtype, b0 + r) : 0.f;
+                v[e] = e < pc.n_valid ? swr_load_value(c_dn[pc.slot + e].values, c_dn[pc.slot + e].dtype, b0 + r) : 0.f;
         }
         bf16x8 h, m, l;
         fl_split8(v, h, m, l);
@@ -443,14 +553,9 @@ __global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
         d[1] = m;
         d[2] = l;
     }
-
-    // 5. x[name].float() of the dense features (layers.py:88-89) as an fp32 block [B][nd4]: the weight-gradient product's operand
-    if (a.nd4 > 0) {
-        float* __restrict__ df = reinterpret_cast<float*>(a.ws + a.off_densef);
-        for (int it = tid; it < rows * a.nd4; it += FL_THREADS) {
-            const int r = it / a.nd4, c = it - r * a.nd4;
-            df[(b0 + r) * a.nd4 + c] = c < a.n_dense ? swr_load_value(a.dense[c].values, a.dense[c].dtype, b0 + r) : 0.f;
-        }
+    for (int it = tid + 2 * FL_THREADS; it < rows * a.nd4; it += FL_THREADS) {
+        const int r = it / a.nd4, c = it - r * a.nd4;
+        df[b0 * a.nd4 + it] = c < a.n_dense ? swr_load_value(c_dn[c].values, c_dn[c].dtype, b0 + r) : 0.f;
     }
 }
 
@@ -475,8 +580,16 @@ extern "C" int swr_fl_keys(const swr_fl_plan* plan, void* workspace, uint32_t* e
     a.off_densef = h.o.densef;
     a.off_zero32 = static_cast<uint32_t>(h.o.zero); a.off_a3f32 = static_cast<uint32_t>(h.o.a3f);
     a.err = err_flag;
-    hipLaunchKernelGGL(fl_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(plan->B, FLK_TILE))), dim3(FL_THREADS), 0,
-                       static_cast<hipStream_t>(stream), a);
+    int common = plan->sparse_host[0].idx_dtype;
+    for (int s = 1; s < plan->n_sparse; ++s)
+        if (plan->sparse_host[s].idx_dtype != common) common = 0;
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(plan->B, FLK_TILE)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    bool f32 = true;
+    for (int s = 0; s < plan->n_dense; ++s) f32 = f32 && plan->dense_host[s].dtype == SWR_F32;
+    if (common == SWR_I64 && f32) hipLaunchKernelGGL((fl_keys_kernel<SWR_I64, SWR_F32>), grid, dim3(FL_THREADS), 0, st, a);
+    else if (common == SWR_I32 && f32) hipLaunchKernelGGL((fl_keys_kernel<SWR_I32, SWR_F32>), grid, dim3(FL_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((fl_keys_kernel<0, 0>), grid, dim3(FL_THREADS), 0, st, a);
     return swr_launch_status();
 }
 
@@ -709,4 +822,83 @@ extern "C" int swr_fl_fwd(const swr_fl_plan* plan, const void* workspace, const 
     }
 #undef FL_GO
     return swr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dWp[N, Kp + ohw] = dZ^T A' (+ column sums of dZ) with A' gathered by the staging threads of gemm.hip's gemm_tn_x6g_kernel:
+// the product that needed the written block.  Falls to the caller's written-block path when the shape is not the
+// bf16-split kernel's (swr_fl_dw_supported).
+static int fl_dw_args(const swr_fl_plan* plan, const FlHost& h, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,
+                      float* colsum, swr_gemm_tn_args& a) {
+    std::memset(&a, 0, sizeof(a));
+    a.M = plan->B; a.K1 = plan->N; a.K2 = 16 * h.NR + plan->oh_width;
+    a.A = dZ; a.lda = lddz; a.C = dWp; a.ldc = lddwp; a.colsum = colsum; a.groups = 1;
+    return SWR_OK;
+}
+
+extern "C" int swr_fl_dw_supported(const swr_fl_plan* plan, int64_t lddz) {
+    FlHost h;
+    if (fl_build(plan, h) != SWR_OK || plan->N < 1) return 0;
+    swr_gemm_tn_args a;
+    float* fake = reinterpret_cast<float*>(static_cast<uintptr_t>(256));       // (alignment is checked again at launch)
+    fl_dw_args(plan, h, fake, lddz, fake, 16 * h.NR + plan->oh_width, nullptr, a);
+    return tn_x6_gather_ok(a) ? 1 : 0;
+}
+
+extern "C" size_t swr_fl_dw_workspace_bytes(const swr_fl_plan* plan) {
+    FlHost h;
+    if (fl_build(plan, h) != SWR_OK || plan->N < 1) return 0;
+    swr_gemm_tn_args a;
+    float* fake = reinterpret_cast<float*>(static_cast<uintptr_t>(256));       // (only the pointers' alignment is looked at)
+    fl_dw_args(plan, h, fake, plan->N + (plan->N & 1), fake, 16 * h.NR + plan->oh_width, fake, a);
+    a.B = fake; a.ldb = a.K2;
+    return swr_gemm_tn_workspace_bytes(&a);
+}
+
+extern "C" int swr_fl_dw(const swr_fl_plan* plan, const void* fl_workspace, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,
+                         float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+    FlHost h;
+    int rc = fl_build(plan, h);
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(fl_workspace && dZ && dWp && plan->N >= 1 && lddz >= plan->N && lddwp >= 16 * h.NR + plan->oh_width, SWR_ERR_ARG);
+    swr_gemm_tn_args a;
+    fl_dw_args(plan, h, dZ, lddz, dWp, lddwp, colsum, a);
+    SWR_REQUIRE(tn_x6_gather_ok(a), SWR_ERR_UNSUPPORTED);
+    const char* ws = static_cast<const char*>(fl_workspace);
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(ws + h.o.keys);
+    const uint32_t* mask_t = reinterpret_cast<const uint32_t*>(ws + h.o.mask_t);
+    const float* densef = reinterpret_cast<const float*>(ws + h.o.densef);
+    TnGather g;
+    std::memset(&g, 0, sizeof(g));
+    g.kp = 16 * h.NR;
+    g.n_pieces = 2 * h.NR + plan->oh_width / 8;
+    SWR_REQUIRE(g.n_pieces <= TNG_MAX_PIECES, SWR_ERR_UNSUPPORTED);
+    for (int q = 0; q < 2 * h.NR; ++q) {
+        const swr_fl_piece& pc = plan->piece[q];
+        TnGatherPiece& P = g.piece[q];
+        P.kwp = keys;
+        if (pc.kind == SWR_FL_PLANES || pc.kind == SWR_FL_ROWS) {
+            SWR_REQUIRE(pc.slot < plan->n_keys, SWR_ERR_ARG);            // its keys were written
+            const swr_sparse_slot& sl = plan->sparse_host[pc.slot];
+            P.kind = TNG_TABLE;
+            P.vbase = sl.weight + pc.off;
+            P.vstride = static_cast<uint32_t>(sl.dim);
+            P.kmax = static_cast<uint32_t>(sl.vocab - 1);
+            P.kwp = keys + static_cast<int64_t>(pc.slot) * plan->B;
+        } else if (pc.kind == SWR_FL_DENSE) {
+            P.kind = TNG_ROWIDX;
+            P.vbase = densef + pc.slot;
+            P.vstride = static_cast<uint32_t>(h.o.nd4);
+            P.n_valid = static_cast<int16_t>(std::min(8, h.o.nd4 - pc.slot));      // (the block's pad columns hold zeros)
+        } else {
+            P.kind = TNG_ZERO;
+        }
+    }
+    for (int o8 = 0; o8 < plan->oh_width / 8; ++o8) {
+        TnGatherPiece& P = g.piece[2 * h.NR + o8];
+        P.kind = TNG_ONEHOT;
+        P.kwp = mask_t + static_cast<int64_t>((8 * o8) / 32) * plan->B;
+        P.bit0 = static_cast<int16_t>((8 * o8) % 32);
+    }
+    return tn_x6_gather(a, g, workspace, workspace_bytes, stream);
 }

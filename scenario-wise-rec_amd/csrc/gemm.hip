@@ -1081,6 +1081,312 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
     }
 }
 
+// ---- the same product with the second operand GATHERED (tn_gather.h; csrc/first_layer.hip): the staging thread of a
+// column pair of A' reads its 8 rows' keys (two 16-byte loads, one stage ahead of the values), then 8-byte pieces of the
+// table rows the keys name -- the access granularity is the one the written block had (8 bytes per (row, column pair)),
+// only the rows now come from the tables (L2-resident but for the row-sparse ones) instead of a 72 MB block; one-hot column
+// pairs are expanded from two bits of the sample's mask word and, being exact in bf16, take three products instead of six.
+#include "tn_gather.h"
+template <int PT, bool TAIL>
+__global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, const TnGather g) {
+    constexpr int ACOLS = PT * 32, COLS = ACOLS + TX_QCOLS + (TAIL ? 32 : 0);
+    constexpr int UNITS = 2 * (COLS / 2);
+    constexpr int PA = (PT + 1) / 2;
+    constexpr int PLANE = COLS * TX_PM, BUF = 3 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) __bf16 Lx[];        // [2][3][COLS][TX_PM]
+    const swr_gemm_tn_args& a = kk.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, s = lane >> 5;
+    const int qt = wave & 3, p_first = (wave >> 2) ? PA : 0;
+    const int p_count = (wave >> 2) ? PT - PA : PA;
+    const unsigned per_xcd = gridDim.x / 8;
+    const unsigned lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (lin >= kk.n_tiles) return;
+    const int qb = static_cast<int>(lin % kk.qblk);
+    const int q0 = qb * TX_QCOLS;
+    const int pb = static_cast<int>((lin / kk.qblk) % kk.pblk);
+    const int p0 = pb * ACOLS;
+    const int split = static_cast<int>(lin / (kk.qblk * kk.pblk));
+    const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
+    const int64_t me = min(ms + kk.rows_per_split, a.M);
+    // exact (one-hot) column tiles: three products instead of six (wave-uniform)
+    const bool q_exact = q0 + 32 * qt >= g.kp;
+    const bool t_exact = TAIL && kk.tail_q0 >= g.kp;
+
+    f32x16 acc[PA];
+#pragma unroll
+    for (int t = 0; t < PA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    constexpr int TT = TAIL ? (PT > 4 ? 2 : 1) : 1;
+    f32x16 acc_tail[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_tail[t][r] = 0.f;
+
+    // ---- this thread's staging unit and where its column pair comes from
+    const int uid = (threadIdx.x + TX_THREADS / 2) & (TX_THREADS - 1);
+    const bool unit_on = uid < UNITS;
+    const int ro = uid & 1, cp = unit_on ? (uid >> 1) : 0;
+    const int scol = 2 * cp;
+    const bool isA = scol < ACOLS;
+    const bool isT = TAIL && scol >= ACOLS + TX_QCOLS;
+    const int gcol = isA ? p0 + scol : (isT ? kk.tail_q0 + (scol - ACOLS - TX_QCOLS) : q0 + (scol - ACOLS));
+    bool col_ok = unit_on && (isA ? gcol < a.K1 : gcol < a.K2);
+    const float* __restrict__ vbase = a.A;      // (a harmless address for the units that load nothing)
+    uint32_t vstride = 0, kmax = 0;
+    const uint32_t* __restrict__ kwp = g.piece[0].kwp;
+    bool keyed = false, is_oh = false;
+    int bit = 0;
+    if (isA) {
+        if (col_ok) { vbase = a.A + gcol; vstride = static_cast<uint32_t>(a.lda); }
+    } else if (col_ok) {
+        const TnGatherPiece P = g.piece[min(gcol >> 3, g.n_pieces - 1)];
+        const int e = gcol & 7;
+        if (P.kind == TNG_TABLE) { vbase = P.vbase + e; vstride = P.vstride; kwp = P.kwp; kmax = P.kmax; keyed = true; }
+        else if (P.kind == TNG_ROWIDX && e < P.n_valid) { vbase = P.vbase + e; vstride = P.vstride; }
+        else if (P.kind == TNG_ONEHOT) { kwp = P.kwp; keyed = true; is_oh = true; bit = P.bit0 + e; }
+        else col_ok = false;
+    }
+    // the middle / low planes of a one-hot column are read only when its 32-column tile also holds real columns
+    const bool oh_planes = is_oh && (gcol & ~31) < g.kp;
+    float cs0 = 0.f, cs1 = 0.f;
+
+    typedef uint32_t kw_t[8];
+    float2 st[TX_DEPTH][8];
+    uint32_t ob[TX_DEPTH];                  // one-hot units: two bits per row of the stage
+    kw_t kw[2];                             // keys / mask words of the stage whose values are loaded NEXT step
+    const uint32_t m_last = static_cast<uint32_t>(a.M - 1);
+    const uint32_t row0 = static_cast<uint32_t>(ms) + 8u * ro;
+    auto kw_load = [&](int stage, kw_t& dst) {
+        // 8 consecutive rows' words (read past row M - 1 at the very end: still inside the workspace, see TnGatherPiece)
+        if (keyed) {
+            const uint4* p = reinterpret_cast<const uint4*>(kwp + (row0 + static_cast<uint32_t>(stage) * TX_ROWS));
+            const uint4 x = p[0], y = p[1];
+            dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w; dst[4] = y.x; dst[5] = y.y; dst[6] = y.z; dst[7] = y.w;
+        }
+    };
+    auto val_load = [&](int stage, const kw_t& k8, float2 (&dst)[8], uint32_t& bits) {
+        const uint32_t rbase = row0 + static_cast<uint32_t>(stage) * TX_ROWS;
+        uint32_t b2 = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t idx = keyed ? min(k8[r], kmax) : min(rbase + r, m_last);
+            dst[r] = *reinterpret_cast<const float2*>(vbase + static_cast<uint64_t>(idx) * vstride);
+            b2 |= ((k8[r] >> bit) & 3u) << (2 * r);
+        }
+        bits = b2;
+    };
+    const int rows_total = static_cast<int>(me - ms);
+    auto stage_store = [&](int stage, const float2 (&raw)[8], uint32_t bits, __bf16* buf) {
+        if (!col_ok) return;
+        const int left = rows_total - stage * TX_ROWS - 8 * ro;
+        bf16x8 h0, m0_, l0, h1, m1, l1;
+        __bf16* d = buf + scol * TX_PM + 8 * ro;
+        if (is_oh) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool ok = r < left;
+                h0[r] = static_cast<__bf16>((ok && ((bits >> (2 * r)) & 1u)) ? 1.f : 0.f);
+                h1[r] = static_cast<__bf16>((ok && ((bits >> (2 * r + 1)) & 1u)) ? 1.f : 0.f);
+                m0_[r] = static_cast<__bf16>(0.f); l0[r] = m0_[r]; m1[r] = m0_[r]; l1[r] = m0_[r];
+            }
+            *reinterpret_cast<bf16x8*>(d) = h0;
+            *reinterpret_cast<bf16x8*>(d + TX_PM) = h1;
+            if (oh_planes) {
+                *reinterpret_cast<bf16x8*>(d + PLANE) = m0_;
+                *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l0;
+                *reinterpret_cast<bf16x8*>(d + TX_PM + PLANE) = m1;
+                *reinterpret_cast<bf16x8*>(d + TX_PM + 2 * PLANE) = l1;
+            }
+            return;
+        }
+        if (left >= 8) {
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                SPLIT3_PAIR(raw[r].x, raw[r + 1].x, h0, m0_, l0, r);
+                SPLIT3_PAIR(raw[r].y, raw[r + 1].y, h1, m1, l1, r);
+                cs0 += raw[r].x;
+                cs1 += raw[r].y;
+                cs0 += raw[r + 1].x;
+                cs1 += raw[r + 1].y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool ok = r < left;
+                const float vx = ok ? raw[r].x : 0.f, vy = ok ? raw[r].y : 0.f;
+                SPLIT3_INTO(vx, h0, m0_, l0, r);
+                SPLIT3_INTO(vy, h1, m1, l1, r);
+                cs0 += vx;
+                cs1 += vy;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(d) = h0;
+        *reinterpret_cast<bf16x8*>(d + PLANE) = m0_;
+        *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l0;
+        *reinterpret_cast<bf16x8*>(d + TX_PM) = h1;
+        *reinterpret_cast<bf16x8*>(d + TX_PM + PLANE) = m1;
+        *reinterpret_cast<bf16x8*>(d + TX_PM + 2 * PLANE) = l1;
+    };
+    auto frag = [&](bf16x8 (&f)[3], const __bf16* buf, int col) {
+        const __bf16* p = buf + (col + i) * TX_PM + 8 * s;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
+    };
+    auto frag1 = [&](bf16x8 (&f)[3], const __bf16* buf, int col) {          // the high plane only (exact columns)
+        f[0] = *reinterpret_cast<const bf16x8*>(buf + (col + i) * TX_PM + 8 * s);
+    };
+
+    const int n_stages = static_cast<int>((me - ms + TX_ROWS - 1) / TX_ROWS);
+    // prologue: keys of stages 0 .. DEPTH, values of stages 0 .. DEPTH - 1 in flight, stage 0 into buffer 0
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { kw[0][r] = 0u; kw[1][r] = 0u; }
+    {
+        kw_t k0, k1, k2;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { k0[r] = 0u; k1[r] = 0u; k2[r] = 0u; }
+        kw_load(0, k0); kw_load(1, k1); kw_load(2, k2);
+        kw_load(TX_DEPTH, kw[0]);                                          // values of stage DEPTH are loaded in step 0
+        val_load(0, k0, st[0], ob[0]);
+        val_load(1, k1, st[1], ob[1]);
+        val_load(2, k2, st[2], ob[2]);
+    }
+    static_assert(TX_DEPTH == 3, "prologue written for three stages in flight");
+    if (unit_on && !col_ok) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = static_cast<__bf16>(0.f);
+#pragma unroll
+        for (int bsel = 0; bsel < 2; ++bsel)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                __bf16* d = Lx + bsel * BUF + pl * PLANE + scol * TX_PM + 8 * ro;
+                *reinterpret_cast<bf16x8*>(d) = z;
+                *reinterpret_cast<bf16x8*>(d + TX_PM) = z;
+            }
+    }
+    stage_store(0, st[0], ob[0], Lx);
+    kw_load(TX_DEPTH + 1, kw[1]);
+    val_load(TX_DEPTH, kw[0], st[0], ob[0]);
+    __syncthreads();
+    // steady state, unrolled by 2 * DEPTH: the value slots (3) and the key slots (2) are both static
+    auto step = [&](int sg, auto slot_c, auto kslot_c) {
+        constexpr int NEXT = (decltype(slot_c)::value + 1) % TX_DEPTH;      // slot holding stage sg + 1
+        constexpr int KS = decltype(kslot_c)::value;                       // key slot holding stage sg + 1 + DEPTH
+        const __bf16* buf = Lx + (sg & 1) * BUF;
+        bf16x8 b[3], a0[3], a1[3];
+        if (q_exact) frag1(b, buf, ACOLS + 32 * qt); else frag(b, buf, ACOLS + 32 * qt);
+        frag(a0, buf, 32 * p_first);
+#pragma unroll
+        for (int t = 0; t < PA; ++t) {
+            if (t < p_count) {
+                bf16x8 (&af)[3] = (t & 1) ? a1 : a0;
+                bf16x8 (&nx)[3] = (t & 1) ? a0 : a1;
+                if (t + 1 < PA && t + 1 < p_count) frag(nx, buf, 32 * (p_first + t + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 c_ = acc[t];
+                if (!q_exact) {
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
+                } else {
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
+                }
+                acc[t] = c_;
+            }
+        }
+        if (TAIL && wave >= 4 && (sg % static_cast<int>(kk.qblk)) == qb) {
+            bf16x8 tb[3], ta[3];
+            if (t_exact) frag1(tb, buf, ACOLS + TX_QCOLS); else frag(tb, buf, ACOLS + TX_QCOLS);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int pt_ = (wave - 4) + 4 * t;
+                if (pt_ < PT) {
+                    frag(ta, buf, 32 * pt_);
+                    f32x16 c_ = acc_tail[t];
+                    if (!t_exact) {
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[2], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[1], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[0], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[1], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[0], c_, 0, 0, 0);
+                    } else {
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[0], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[0], c_, 0, 0, 0);
+                    }
+                    acc_tail[t] = c_;
+                }
+            }
+        }
+        if (sg + 1 < n_stages) stage_store(sg + 1, st[NEXT], ob[NEXT], Lx + ((sg + 1) & 1) * BUF);
+        // keys of stage sg + 2 + DEPTH first, then the values of stage sg + 1 + DEPTH through the keys loaded a step ago
+        kw_load(sg + 2 + TX_DEPTH, kw[KS ^ 1]);
+        val_load(sg + 1 + TX_DEPTH, kw[KS], st[NEXT], ob[NEXT]);
+        __syncthreads();
+    };
+    // (key slot of step sg: stage sg + 1 + DEPTH was loaded into kw[(sg + 1) & 1] -- step 0 reads kw[1])
+    int sg = 0;
+    for (; sg + 2 * TX_DEPTH <= n_stages; sg += 2 * TX_DEPTH) {
+        step(sg, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        step(sg + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        step(sg + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+        step(sg + 3, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        step(sg + 4, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        step(sg + 5, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); ++sg; }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); ++sg; }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); ++sg; }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); ++sg; }
+    if (sg < n_stages) { step(sg, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); ++sg; }
+
+    const int k2p = kk.k2p;
+    float* __restrict__ P = kk.part + static_cast<int64_t>(split) * a.K1 * k2p;
+    const int q = q0 + 32 * qt + i;
+    const int q_end = TAIL ? kk.tail_q0 : a.K2;
+#pragma unroll
+    for (int t = 0; t < PA; ++t) {
+        if (t < p_count) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + 32 * (p_first + t) + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (p < a.K1 && q < q_end) P[static_cast<int64_t>(p) * k2p + q] = acc[t][r];
+            }
+        }
+    }
+    if (TAIL && wave >= 4) {
+        const int qtl = kk.tail_q0 + 32 * qb + i;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int pt_ = (wave - 4) + 4 * t;
+            if (pt_ < PT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = p0 + 32 * pt_ + (r & 3) + 8 * (r >> 2) + 4 * s;
+                    if (p < a.K1 && kk.tail_q0 + i < a.K2) P[static_cast<int64_t>(p) * k2p + qtl] = acc_tail[t][r];
+                }
+            }
+        }
+    }
+    if (kk.part_cs && q0 == 0) {
+        cs0 += __shfl_xor(cs0, 1);
+        cs1 += __shfl_xor(cs1, 1);
+        if (col_ok && isA && ro == 0) {
+            kk.part_cs[static_cast<int64_t>(split) * a.K1 + gcol] = cs0;
+            kk.part_cs[static_cast<int64_t>(split) * a.K1 + gcol + 1] = cs1;
+        }
+    }
+}
+
 // fixed-order sum of the per-workgroup partial tiles.  A workgroup owns 256 / L consecutive output elements; thread
 // (sub, o) adds partials sub, sub + L, ... of element o in order (UNROLL loads in flight), so the 64 lanes of a wave read
 // 64 CONSECUTIVE floats of one partial matrix (coalesced; with the L lanes of an element adjacent, as before, every lane
@@ -1180,6 +1486,63 @@ static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
     want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (8 * TX_ROWS)));
     rps = swr_ceil_div(swr_ceil_div(a.M, want), TX_ROWS) * TX_ROWS;
     n_splits = static_cast<int>(swr_ceil_div(a.M, rps));
+}
+
+extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args);
+// the gathered form: same plan, same partial layout, same fixed-order reduction as the x6 branch of swr_gemm_tn
+bool tn_x6_gather_ok(const swr_gemm_tn_args& a) {
+    return use_x6() && !use_bf16() && a.groups == 1 && a.K1 <= 32 * TN_TA_MAX && a.K1 % 2 == 0 && a.K2 % 2 == 0 && a.lda % 2 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && a.M >= 4096 && a.M * a.lda < (1ll << 31) && !a.C2 && a.K2 <= 8 * TNG_MAX_PIECES;
+}
+
+int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, size_t workspace_bytes, void* stream) {
+    SWR_REQUIRE(tn_x6_gather_ok(a) && a.A && a.C && a.lda >= a.K1 && a.ldc >= a.K2 && g.n_pieces * 8 >= a.K2 && g.kp % 16 == 0, SWR_ERR_ARG);
+    swr_gemm_tn_args sized = a;
+    sized.B = a.A; sized.ldb = a.K2;                               // (workspace size: B is only looked at for alignment)
+    const size_t need = swr_gemm_tn_workspace_bytes(&sized);
+    SWR_REQUIRE(workspace != nullptr && workspace_bytes >= need, SWR_ERR_WORKSPACE);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TnK kk;
+    kk.a = a;
+    int n_splits;
+    tn_x6_plan(a, n_splits, kk.rows_per_split);
+    kk.splits = n_splits * GEMM_WAVES;
+    const bool tail = tn_x6_tail(a);
+    kk.qblk = tail ? static_cast<unsigned>(a.K2 / TX_QCOLS) : static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
+    kk.tail_q0 = tail ? static_cast<int>(kk.qblk) * TX_QCOLS : 0;
+    kk.tail_rep = tail ? static_cast<int>(kk.qblk) : 0;
+    kk.k2p = tail ? static_cast<int>(kk.qblk) * (TX_QCOLS + 32) : a.K2;
+    kk.part = static_cast<float*>(workspace);
+    kk.part_cs = a.colsum ? kk.part + static_cast<size_t>(n_splits) * a.K1 * kk.k2p : nullptr;
+    const int pt_all = static_cast<int>(swr_ceil_div(a.K1, 32));
+    kk.pblk = 1;
+    kk.n_tiles = kk.qblk * static_cast<unsigned>(n_splits);
+    const dim3 grid((kk.n_tiles + 7) / 8 * 8);
+    const unsigned lds = static_cast<unsigned>(2 * 3 * (pt_all * 32 + TX_QCOLS + (tail ? 32 : 0)) * TX_PM * sizeof(__bf16));
+    const void* fn = nullptr;
+#define TNG(PTV) (tail ? reinterpret_cast<const void*>(gemm_tn_x6g_kernel<PTV, true>) : reinterpret_cast<const void*>(gemm_tn_x6g_kernel<PTV, false>))
+    switch (pt_all) {
+        case 1: fn = TNG(1); break;
+        case 2: fn = TNG(2); break;
+        case 3: fn = TNG(3); break;
+        case 4: fn = TNG(4); break;
+        default: fn = TNG(5); break;
+    }
+#undef TNG
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)
+        return SWR_ERR_LAUNCH;
+    TnGather gg = g;
+    void* kargs[] = {&kk, &gg};
+    if (hipLaunchKernel(fn, grid, dim3(TX_THREADS), kargs, lds, st) != hipSuccess) return SWR_ERR_LAUNCH;
+    const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
+    const dim3 rblock(256);
+#define TN_RED(LV)                                                                                                      \
+    hipLaunchKernelGGL(tn_reduce_kernel<LV>, dim3(static_cast<unsigned>(swr_ceil_div(n * LV, 256)), 1u), rblock, 0, st, kk)
+    if (n_splits > 128) TN_RED(32);
+    else if (n_splits > 64) TN_RED(8);
+    else TN_RED(4);
+#undef TN_RED
+    return swr_launch_status();
 }
 
 extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args) {

@@ -1,0 +1,29 @@
+// Operand description of the weight-gradient product whose second operand is GATHERED (first_layer.hip -> gemm.hip):
+//   dWp[n, c] = sum_b dZ[b, n] A'[b, c],   A' = the compact layout [table pieces | dense pieces | 0 | one-hot] that is never
+// written -- the staging threads of gemm_tn_x6g_kernel fetch table rows through the row keys, dense columns from the fp32
+// block of the keys launch, and expand the one-hot columns from the transposed mask words.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "swr.h"
+
+#define TNG_MAX_PIECES 48
+enum { TNG_ZERO = 0, TNG_TABLE = 1, TNG_ROWIDX = 2, TNG_ONEHOT = 3 };
+struct TnGatherPiece {        // 8 consecutive columns of A'
+    const float* vbase;       // TABLE: table + first column inside the row; ROWIDX: fp32 block [M][vstride] + first column
+    const uint32_t* kwp;      // TABLE: row keys of the slot [M]; ONEHOT: the 32-bit mask word that holds the piece's bits [M]
+    uint32_t vstride;         // floats per row of vbase
+    uint32_t kmax;            // TABLE: vocab - 1 (keys read past row M - 1 are garbage: clamped, their rows are zeroed)
+    int16_t kind, bit0;       // ONEHOT: bit of the piece's first column in its word
+    int16_t n_valid, pad;     // ROWIDX: valid columns of the piece
+};
+struct TnGather {
+    TnGatherPiece piece[TNG_MAX_PIECES];
+    int n_pieces;
+    int kp;                   // first one-hot column (a multiple of 16)
+};
+
+// a = the product's description with B ignored (K2 = columns of A'); same workspace size as swr_gemm_tn_workspace_bytes
+int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, size_t workspace_bytes, void* stream);
+bool tn_x6_gather_ok(const swr_gemm_tn_args& a);

@@ -496,6 +496,11 @@ class EmbedGather(Function):
         if _late["jobs"]:
             raise H.SwrError("a forward pass with held-back gradient work of the previous backward pending "
                              "(split backward: run_late_jobs() was not called)")
+        if _side["queued"] and not _in_backward():
+            # a backward pass died between queueing its end-of-pass callback and running it (an exception in a kernel
+            # launcher): without this the riders of every later pass would wait for a callback that is never queued again
+            _side["queued"] = False
+            _dw["riders"].clear()
         # slots whose table takes a gradient first: the backward reduces exactly that prefix
         plan.sparse = sorted(plan.sparse, key=lambda s: not weights[s[0]].requires_grad)
         ctx.n_grad_slots = sum(1 for s in plan.sparse if weights[s[0]].requires_grad)
@@ -1088,10 +1093,18 @@ class LinearBNAct(Function):
                 Kf = oh.Kp + oh.oh_width
                 dWp = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
                 dbp = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
-                xa = x
-                if ctx.fl_fused:      # the forward never wrote A': the gather launch writes it now, on this (the weight-gradient) branch
-                    xa = oh.materialize()[:, oh.col0:oh.col0 + Kf]
-                gemm_tn(dZ, xa, dWp, M, N, Kf, colsum=dbp)
+                if ctx.fl_fused and lib.swr_fl_dw_supported(C.byref(oh.fl["plan"]), dZ.stride(0)):
+                    # the product's staging threads fetch the table rows through the keys: A' is never written
+                    f = oh.fl
+                    nb = lib.swr_fl_dw_workspace_bytes(C.byref(f["plan"]))
+                    wsd = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+                    H.check(lib.swr_fl_dw(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(dZ), dZ.stride(0), H.ptr(dWp), Kf, H.ptr(dbp),
+                                          H.ptr(wsd), nb, H.stream()), "swr_fl_dw")
+                else:
+                    xa = x
+                    if ctx.fl_fused:  # a small batch: the gather launch writes A' now, on this (the weight-gradient) branch
+                        xa = oh.materialize()[:, oh.col0:oh.col0 + Kf]
+                    gemm_tn(dZ, xa, dWp, M, N, Kf, colsum=dbp)
                 tw = (H.OnehotTable * len(oh.tables_p))()
                 tg = (H.OnehotTable * len(oh.tables))()
                 for j, ((p_t, vocab, dim, off, col), (g_t, *_r)) in enumerate(zip(oh.tables_p, oh.tables)):

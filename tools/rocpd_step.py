@@ -12,7 +12,9 @@ def main():
     nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     kmax = int(sys.argv[3]) if len(sys.argv) > 3 else 200      # longer "steps" are the stand-alone launches of bench.py's roofline leg
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if "embed_gather_kernel" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "fl_keys_kernel" in r[0]]       # fused lookup: the keys launch opens a step
+    if len(marks) < 3:
+        marks = [i for i, r in enumerate(rows) if "embed_gather_kernel" in r[0]]
     steps = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1) if 10 <= marks[i + 1] - marks[i] <= kmax][-nlast:]  # skip the
     # stand-alone gather launches of bench.py's roofline leg
     spans, busys, per = [], [], defaultdict(list)
