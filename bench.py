@@ -422,28 +422,32 @@ def main():
 
 
 def measure_roofline(cfg, model, trainer, x, dev, iters, B):
-    """The three products of the stacked expert + gate layer ([B, 516] x [516, 148] algorithmically) and the gather,
-    each timed stand-alone at the shapes the step really launches.
+    """The launches of the stacked expert + gate layer ([B, 516] x [516, 148] algorithmically) and of the lookup in front of
+    it, each timed stand-alone at the shapes the step really launches.
 
-    The step runs the FOLDED first layer: the lookup writes A' = [E_big | dense | one-hot] (276
-    columns instead of 516) and the products run over A': forward Z = A' Wf^T, dW' = dZ^T A', dX only for the 144 columns
-    of the tables that go through K3.  `achieved` / `frac` use SURVEY.md 8(d)'s ALGORITHMIC flops of the layer,
-    2 * B * N * K with K = 516 -- what the reference's Linear computes -- against the dense bf16 MFMA peak;
-    `executed_flops_per_launch` is what the launch multiplies after the folding.  Every fp32 product is six bf16 MFMA
-    products (3-way operand split, fp32 accumulate: the 1e-4 logit bar rules plain bf16 out), so the matrix pipes issue
-    6 x the executed flops: `mfma_issue_util`.  `hbm_frac` prices the launch's executed bytes against the 8 TB/s HBM
-    peak: at N = 148 these products sit far below the ~300 flop/B ridge, HBM is the roofline that can bind.
-    Primary entry = the longest kernel of the step, the weight-gradient product (`gemm_tn_x6_kernel` + its fixed-order
+    The step runs the FUSED lookup + first layer (csrc/first_layer.hip): the lookup writes row keys,
+    one-hot bits and piece offsets only; the forward product Z = A' Wf^T and the weight gradient dWp = dZ^T A' fetch table
+    rows through the keys (A' = [9 tables x 16 | 4 dense | 12 zero | 128 one-hot] = 288 columns is never written); dX is
+    computed only for the 144 columns of the tables that go through K3.  `achieved` / `frac` use SURVEY.md 8(d)'s
+    ALGORITHMIC flops of the layer, 2 * B * N * K with K = 516 -- what the reference's Linear computes -- against the dense
+    bf16 MFMA peak; `executed_flops_per_launch` is what the launch multiplies after the folding.  Every fp32 product is six
+    bf16 MFMA products (3-way operand split, fp32 accumulate: the 1e-4 logit bar rules plain bf16 out; three for the
+    bf16-exact one-hot columns), so the matrix pipes issue up to 6 x the executed flops: `mfma_issue_util`.  `hbm_frac`
+    prices the launch's executed bytes against the 8 TB/s HBM peak.
+    Primary entry = the longest kernel of the step, the weight-gradient product (`gemm_tn_x6g_kernel` + its fixed-order
     partial-tile reduction).  Timed live with HIP events on the launch stream over graph-captured launches; four
-    operand sets (> the 256 MB Infinity Cache) are rotated."""
+    operand sets are rotated.  With SWR_FUSED_LOOKUP=0 (or SWR_GEMM != default) the written-block launches are timed
+    instead (`gemm_tn_x6_kernel`, `gemm_rows_x6_kernel`, `embed_gather_kernel`)."""
+    import ctypes as C
+    from scenario_wise_rec import _hip as H
     from scenario_wise_rec import ops
-    from scenario_wise_rec.basic.layers import _sel_tensor
+    from scenario_wise_rec._hip import lib
     fs, e, fd = len(cfg["vocabs"]), cfg["embed_dim"], cfg["n_dense"]
     k0 = fs * e + fd
     hyp = cfg["hyper"]
     n1 = hyp["n_expert"] * hyp["expert_params"]["dims"][0] + hyp["domain_num"] * hyp["n_expert"]
     g = torch.Generator(device=dev).manual_seed(1)
-    # A' exactly as the step's lookup lays it out (real one-hot block, real embeddings of the other tables)
+    # A' exactly as the step's lookup lays it out (real keys / one-hot bits, real embeddings of the other tables)
     was_training = model.training
     model.train()
     sets, info = [], None
@@ -457,10 +461,11 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
             kf = k0
         else:
             kf = info.Kp + info.oh_width
-            A = info.wide[:, info.col0:info.col0 + kf].detach()
-        sets.append((torch.randn(B, n1, device=dev, generator=g), A))
+            A = None if info.fl is not None else info.wide[:, info.col0:info.col0 + kf].detach()
+        sets.append((torch.randn(B, n1, device=dev, generator=g), A, info))
     model.train(was_training)
     folded = info is not None and info.fold
+    fused = folded and info.fl is not None
     n_sel = info.n_sel if folded else k0
     Wf = torch.randn(n1, kf, device=dev, generator=g) * 0.05
     Wsel = torch.randn(n_sel, n1, device=dev, generator=g) * 0.05
@@ -477,52 +482,91 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         st["i"] += 1
         return sets[st["i"] % 4]
 
-    def f_tn():
-        dZ, A = nxt()
-        ops.gemm_tn(dZ, A, dW, B, n1, kf, colsum=db)
+    if fused:
+        # the layer's own parameters through the parameter-sized launch (folded weights in fragment order + the small tables'
+        # bf16-term shadows), once per operand set; then the two products as the step launches them
+        W = ops._cat_params([m.block(0)[0].weight for m in model.experts] + [gt.block(0)[0].weight for gt in model.gates])
+        tabs = (H.OnehotTable * len(info.tables_p))()
+        for j, (p_t, vocab, dim, off, col) in enumerate(info.tables_p):
+            tabs[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
+        for _dz, _a, inf in sets:
+            inf.fl["plan"].N = n1
+            H.check(lib.swr_fl_prep(C.byref(inf.fl["plan"]), H.ptr(W), W.stride(0), k0, H.ptr(inf.ohtab), tabs, len(inf.tables_p), None, 0,
+                                    None, n1, H.ptr(inf.fl["ws"]), H.stream()), "swr_fl_prep")
+        nb = lib.swr_fl_dw_workspace_bytes(C.byref(info.fl["plan"]))
+        wsd = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
 
-    # the one-hot columns of A' are bf16-exact: the forward kernel issues 3 products instead of 6 for whole pairs of
-    # 32-column chunks behind `a_exact_from` (include/swr.h), as the model's own launch does
+        def f_tn():
+            dZ, _a, inf = nxt()
+            H.check(lib.swr_fl_dw(C.byref(inf.fl["plan"]), H.ptr(inf.fl["ws"]), H.ptr(dZ), n1, H.ptr(dW), kf, H.ptr(db), H.ptr(wsd), nb,
+                                  H.stream()), "swr_fl_dw")
+
+        def f_fwd():
+            _dz, _a, inf = nxt()
+            H.check(lib.swr_fl_fwd(C.byref(inf.fl["plan"]), H.ptr(inf.fl["ws"]), H.ptr(bias), H.ptr(Z), n1, H.ptr(parts), H.stream()),
+                    "swr_fl_fwd")
+    else:
+        def f_tn():
+            dZ, A, _i = nxt()
+            ops.gemm_tn(dZ, A, dW, B, n1, kf, colsum=db)
+
+        def f_fwd():
+            _dZ, A, _i = nxt()
+            ops.gemm("nt", A, Wf, Z, B, n1, kf, bias=bias, stat_partials=parts, a_exact_from=ex_from)
+
+    # the one-hot columns of A' are bf16-exact: 3 products instead of 6 (fused: every one-hot group / column tile; written
+    # block: whole pairs of 32-column chunks behind `a_exact_from`, include/swr.h)
     ex_from = info.Kp if folded else 0
-    k_half = max(0, kf - (ex_from + 63) // 64 * 64) if ex_from > 0 else 0      # columns on the 3-product body
-
-    def f_fwd():
-        _dZ, A = nxt()
-        ops.gemm("nt", A, Wf, Z, B, n1, kf, bias=bias, stat_partials=parts, a_exact_from=ex_from)
+    k_half = (kf - ex_from if fused else max(0, kf - (ex_from + 63) // 64 * 64)) if ex_from > 0 else 0
 
     def f_dx():
-        dZ, _A = nxt()
+        dZ, _A, _i = nxt()
         ops.gemm("nt", dZ, Wsel, dX, B, n_sel, n1)
 
     x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f"
     peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
     alg_flops = 2.0 * B * n1 * k0
 
-    def entry(kname, fn, pmc_name, k_exec, alg, k3=0):
+    def entry(kname, fn, pmc_name, k_exec, alg, k3=0, nbytes=None):
         """k3: columns of the reduction range that take 3 bf16 products instead of 6."""
         ms = time_kernel_events(fn, max(10, iters), stream)
         exe = 2.0 * B * n1 * k_exec
-        nbytes = 4.0 * B * (n1 + k_exec)
+        nbytes = 4.0 * B * (n1 + k_exec) if nbytes is None else nbytes
         tf = alg / (ms * 1e-3) / 1e12
         return {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe, "executed_bytes_per_launch": nbytes,
                 "avg_launch_ms": ms,
                 "mfma_issue_util": ((6.0 - 3.0 * k3 / k_exec) if x6 else 1.0) * exe / (ms * 1e-3) / 1e12 / peak,
-                "mfma_dtype": "bf16 x 6 products per fp32 product (3-way operand split, fp32 accumulate)" if x6 else "f32",
+                "mfma_dtype": "bf16 x 6 products per fp32 product (3-way operand split, fp32 accumulate; 3 for one-hot columns)" if x6 else "f32",
                 "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_name),
                 "shape": f"[{B}, {k_exec}] x [{k_exec}, {n1}]" + (" (folded from K = %d)" % k0 if folded and k_exec != n_sel else "")}
 
-    kname = "gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"
-    roof = entry(kname + " (+tn_reduce_kernel)", f_tn, "void %s<" % kname, kf, alg_flops)
+    if fused:
+        # bytes the fused launches move per sample: forward = 32 B of piece offsets per real group half ... in total the
+        # offsets, the mask, 48 B per (sample, piece) of bf16 terms (mostly L2 hits on the shadows) and the Z row; the weight
+        # gradient = the dZ row (read once per 128-column block), keys / mask words, 4 B per real column of A'
+        nr = info.Kp // 16
+        fwd_bytes = float(B) * (nr * 8 + 16 + 2 * nr * 48 + 4 * n1)
+        n_qblk = max(1, kf // 128)
+        dw_bytes = float(B) * (n_qblk * 4 * n1 + 4 * info.Kp + 4 * (info.Kp // 16) + 16)
+        roof = entry("gemm_tn_x6g_kernel (+tn_reduce_kernel): dWp = dZ^T A', A' gathered through the row keys", f_tn,
+                     "void gemm_tn_x6g_kernel<", kf, alg_flops, k3=k_half, nbytes=dw_bytes)
+        fwd_ent = entry("fl_fwd_kernel (forward Z = A' Wf^T, lookup fused as the A-operand producer, BN partials in the epilogue)", f_fwd,
+                        "void fl_fwd_kernel<", kf, alg_flops, k3=k_half, nbytes=fwd_bytes)
+    else:
+        kname = "gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"
+        roof = entry(kname + " (+tn_reduce_kernel)", f_tn, "void %s<" % kname, kf, alg_flops)
+        fwd_ent = entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd, "void gemm_rows_x6_kernel<5", kf, alg_flops,
+                        k3=k_half)
     roof["traffic_unit"] = "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)"
     roof["also"] = {
-        "gemm_rows_x6_kernel(forward)": entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd,
-                                              "void gemm_rows_x6_kernel<5", kf, alg_flops, k3=k_half),
+        ("fl_fwd_kernel(forward)" if fused else "gemm_rows_x6_kernel(forward)"): fwd_ent,
         # dX is algorithmically [B, 148] x [148, 512]; the small tables' columns are never computed (their gradients
         # come out of the weight-gradient product's one-hot block)
         "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W, columns of the K3 tables only)", f_dx,
                                          "void gemm_rows_x6_kernel<5", n_sel, 2.0 * B * n1 * fs * e),
-        "embed_gather_kernel": gather_roofline(cfg, model, x, dev, iters, B),
+        ("fl_keys_kernel" if fused else "embed_gather_kernel"): gather_roofline(cfg, model, x, dev, iters, B),
         "k3_direct_sums": k3_roofline(cfg, dev, iters, B),
     }
     return roof
@@ -647,17 +691,28 @@ def gather_roofline(cfg, model, x, dev, iters, B, config=2):
            "note": "SURVEY.md 8(d)'s per-sample bytes of the REFERENCE lookup (F_s (idx + 4E) + 4 F_d + 4 K0) over this launch's "
                    "time: a speed-up figure against the reference's traffic, not an HBM efficiency"}
     exe, layout = nbytes, "plain concat [B, K0]: executed = algorithmic"
+    kernel, pmc = "embed_gather_kernel", "void embed_gather_kernel<4>"
     last = state["keep"][-1] if state["keep"] else None
     info = getattr(last, "_swr_onehot", None)
-    if info is not None and info.fold:
+    if info is not None and info.fold and info.fl is not None:
+        # fused lookup (csrc/first_layer.hip): ids in; row keys of the tables that keep an embedding, 32 B of one-hot bits, a
+        # 4-byte piece offset per (sample, 8-column piece), the bf16 terms of the fp32-sourced pieces (row-sparse tables, dense
+        # features: 48 B each, their 32-byte sources read), the fp32 dense block out
+        fs_ = len(cfg["vocabs"])
+        o = info.fl["offs"]
+        exe = B * (fs_ * 8 + 4 * len(info.compact) + 32 + 4 * 2 * (info.Kp // 16) + o.n_fpieces * (48 + 32) + 4 * o.nd4)
+        layout = (f"fused: keys of {len(info.compact)} tables, {info.oh_width} one-hot bits, {2 * (info.Kp // 16)} piece offsets, "
+                  f"{o.n_fpieces} fp32-sourced pieces per sample; nothing of the concat is written")
+        kernel, pmc = "fl_keys_kernel", "void fl_keys_kernel<"
+    elif info is not None and info.fold:
         # folded layout: the small tables' embeddings are neither read nor written; what the launch really moves
         fs_, e_ = len(cfg["vocabs"]), cfg["embed_dim"]
         exe = B * (fs_ * 8 + 4 * (info.Kp + info.oh_width) + 4 * e_ * len(info.compact) + 4 * cfg["n_dense"])
         layout = f"folded: [{len(info.compact)} tables x {e_} | {cfg['n_dense']} dense | {info.oh_width} one-hot columns]"
     achieved = exe / (ms * 1e-3) / 1e9
-    return {"kernel": "embed_gather_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "executed_bytes_per_launch": exe, "avg_launch_ms": ms, "layout": layout,
-            "traffic": pmc_traffic("void embed_gather_kernel<4>", config), "vs_reference_bytes": ref}
+            "traffic": pmc_traffic(pmc, config), "vs_reference_bytes": ref}
 
 
 if __name__ == "__main__":

@@ -937,6 +937,7 @@ class LinearBNAct(Function):
                                         H.ptr(f["ws"]), H.stream()), "swr_fl_prep")
                 H.check(lib.swr_fl_fwd(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(b), H.ptr(Z), Ntot, H.ptr(partials), H.stream()),
                         "swr_fl_fwd")
+                _flush_deferred()      # the forward-time fork (the large tables' sort) is enqueued behind the product, as gemm() does
                 ctx.fl_fused = True
             else:
                 x = (oh_in.materialize() if oh_in.fl is not None else oh_in.wide)[:, oh_in.col0:oh_in.col0 + Kf]
