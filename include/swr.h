@@ -200,7 +200,7 @@ typedef struct {
     int32_t pad;
 } swr_fl_plan;
 typedef struct {                    /* byte offsets of the workspace sections (keys: what swr_embed_bwd* take) */
-    int64_t zero, planes, a3f, b3, keys, mask, mask_t, voff, densef, total;
+    int64_t zero, planes, a3f, b3, keys, mask, mask_t, voff, densef, b3x, total;
     int32_t nd4;                    /* row pitch of densef (fp32 dense features, [B][nd4]) */
     int32_t n_fpieces;              /* pieces of kind ROWS / DENSE */
 } swr_fl_offsets;
@@ -220,6 +220,14 @@ int swr_fl_fwd(const swr_fl_plan* plan_host, const void* workspace, const float*
  * row keys per column pair and stage, then 8-byte pieces of the table rows.  `workspace`: swr_fl_dw_workspace_bytes.
  * swr_fl_dw_supported = 0: the shape is not the bf16-split kernel's (batch < 4096, N > 160, SWR_GEMM != default) -- the
  * caller writes the block (swr_embed_gather_fwd_onehot) and uses swr_gemm_tn. */
+/* BatchNorm backward of the layer + its dX product in one pass (no activation in between: the expert / gate level of
+ * swr_bnmix_bwd): dZ = ca * dY + cb * (Z - mean) + cc -- swr_act_bwd_apply's arithmetic, bit for bit -- is computed in the A
+ * fragment of the product dX[B, n_out] = dZ W[:, sel] (weights: the B3X image swr_fl_prep wrote for `sel`) and written out
+ * for the weight-gradient product.  K = plan->N <= 160, n_out = n_sel <= 160. */
+int swr_bn_bwd_dx_supported(int K, int n_out);
+int swr_bn_bwd_dx(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dY, int64_t lddy, const float* Z, int64_t ldz,
+                  const float* ca, const float* cb, const float* cc, const float* mean, int n_out,
+                  float* dZ, int64_t lddz, float* dX, int64_t lddx, void* stream);
 int swr_fl_dw_supported(const swr_fl_plan* plan_host, int64_t lddz);
 size_t swr_fl_dw_workspace_bytes(const swr_fl_plan* plan_host);
 int swr_fl_dw(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,

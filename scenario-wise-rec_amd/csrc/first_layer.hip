@@ -164,6 +164,9 @@ static int fl_build(const swr_fl_plan* p, FlHost& h) {
     o.mask_t = at; at += fl_align(p->B * 16);
     o.voff = at; at += fl_align(static_cast<int64_t>(h.n_tiles) * h.NR * 64 * 4);
     o.densef = at; at += fl_align(p->B * o.nd4 * 4);
+    // B3X: rows `sel` of W^T (the dX product's weights) in the same fragment order: 16-column k groups over the layer's
+    // N <= 160 outputs, column tiles over the <= 160 selected columns (sized for the widest)
+    o.b3x = at; at += fl_align(static_cast<int64_t>(FL_NT_MAX) * fl_pitch_blocks(FL_NT_MAX) * 1024);
     o.total = at;
     for (int t = 0; t < h.n_tbl; ++t) h.tbl[t].planes_off += static_cast<uint32_t>(o.planes);
     for (int q = 0; q < 2 * h.NR; ++q)
@@ -196,8 +199,9 @@ struct FlPrepK {
     const float* W; int64_t ldw;
     const int32_t* oh_table;
     const int64_t* sel; int n_sel; float* Wt; int64_t ldt;
-    char* ws; int64_t off_b3, off_zero;
-    int blocks_a, blocks_b;
+    char* ws; int64_t off_b3, off_zero, off_b3x;
+    int blocks_a, blocks_b, blocks_c;
+    int ntx, pitch_x;               // B3X: column tiles of the dX product, 1-KB blocks per chunk
 };
 
 __device__ __forceinline__ void fl_split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
@@ -285,11 +289,31 @@ __global__ __launch_bounds__(FL_THREADS) void fl_prep_kernel(const FlPrepK k) {
         return;
     }
     blk -= k.blocks_b;
-    // ---- Wt_sel[r, n] = W[n, sel[r]] (thread = one element, consecutive lanes along n)
-    const int64_t i = static_cast<int64_t>(blk) * FL_THREADS + tid;
-    if (i < static_cast<int64_t>(k.n_sel) * k.N) {
-        const int r = static_cast<int>(i / k.N), n = static_cast<int>(i - static_cast<int64_t>(r) * k.N);
-        k.Wt[r * k.ldt + n] = k.W[n * k.ldw + k.sel[r]];
+    if (blk < k.blocks_c) {
+        // ---- Wt_sel[r, n] = W[n, sel[r]] (thread = one element, consecutive lanes along n)
+        const int64_t i = static_cast<int64_t>(blk) * FL_THREADS + tid;
+        if (i < static_cast<int64_t>(k.n_sel) * k.N) {
+            const int r = static_cast<int>(i / k.N), n = static_cast<int>(i - static_cast<int64_t>(r) * k.N);
+            k.Wt[r * k.ldt + n] = k.W[n * k.ldw + k.sel[r]];
+        }
+        return;
+    }
+    blk -= k.blocks_c;
+    // ---- B3X: the same rows of W^T as the B operand of the dX product (swr_bn_bwd_dx): thread = one weight; k = the layer's
+    // output n (groups of 16), column = selected input column c (tiles of 32)
+    {
+        const int idx = blk * FL_THREADS + tid;
+        const int n_g = (k.N + 15) / 16, n_cg = 2 * ((n_g + 1) / 2);
+        if (idx >= n_cg * k.ntx * 512) return;
+        const int e = idx & 7, lane = (idx >> 3) & 63, t = (idx >> 9) % k.ntx, cg = idx / (512 * k.ntx);
+        const int j = lane & 31, s = lane >> 5, c = 32 * t + j, n = 16 * cg + 8 * s + e;
+        const float v = (c < k.n_sel && n < k.N) ? k.W[static_cast<int64_t>(n) * k.ldw + k.sel[c]] : 0.f;
+        const Bf3 sp3 = split3(v);
+        __bf16* d = reinterpret_cast<__bf16*>(k.ws + k.off_b3x + static_cast<int64_t>(cg >> 1) * k.pitch_x * 1024) +
+                    ((((cg & 1) * k.ntx + t) * 3) * 64 + lane) * 8 + e;
+        d[0] = sp3.h;
+        d[512] = sp3.m;
+        d[1024] = sp3.l;
     }
 }
 
@@ -325,8 +349,14 @@ extern "C" int swr_fl_prep(const swr_fl_plan* plan, const float* W, int64_t ldw,
     k.ws = static_cast<char*>(workspace); k.off_b3 = h.o.b3; k.off_zero = h.o.zero;
     k.blocks_a = static_cast<int>(swr_ceil_div(static_cast<int64_t>(2 * (h.ncr + h.nco)) * h.NT * 512, FL_THREADS));
     k.blocks_b = static_cast<int>(swr_ceil_div(h.items_planes, FL_THREADS));
-    const int blocks_c = static_cast<int>(swr_ceil_div(static_cast<int64_t>(n_sel) * plan->N, FL_THREADS));
-    hipLaunchKernelGGL(fl_prep_kernel, dim3(static_cast<unsigned>(k.blocks_a + k.blocks_b + blocks_c)), dim3(FL_THREADS), 0,
+    k.blocks_c = static_cast<int>(swr_ceil_div(static_cast<int64_t>(n_sel) * plan->N, FL_THREADS));
+    // the dX product's image only when it fits that kernel (<= 160 selected columns)
+    k.off_b3x = h.o.b3x;
+    k.ntx = (n_sel > 0 && n_sel <= 32 * FL_NT_MAX) ? (n_sel + 31) / 32 : 0;
+    k.pitch_x = fl_pitch_blocks(k.ntx > 0 ? k.ntx : 1);
+    const int n_gx = (plan->N + 15) / 16;
+    const int blocks_d = k.ntx > 0 ? static_cast<int>(swr_ceil_div(static_cast<int64_t>(2 * ((n_gx + 1) / 2)) * k.ntx * 512, FL_THREADS)) : 0;
+    hipLaunchKernelGGL(fl_prep_kernel, dim3(static_cast<unsigned>(k.blocks_a + k.blocks_b + k.blocks_c + blocks_d)), dim3(FL_THREADS), 0,
                        static_cast<hipStream_t>(stream), k);
     return swr_launch_status();
 }
@@ -358,9 +388,11 @@ __device__ __forceinline__ float fl_dense(const swr_dense_slot& d, int64_t i) {
 }
 // IDT: the common dtype of all id columns (SWR_I64 / SWR_I32), or 0: per-slot dispatch; DDT: SWR_F32 when every dense
 // feature is fp32 (a per-load dtype switch makes every load wait where it stands)
-template <int IDT, int DDT>
-__global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
-    __shared__ uint32_t s_row[FL_MAX_SPARSE][FLK_TILE];
+// SG: 64-sample groups per workgroup (4 waves each).  The descriptor copy -- a memory round trip before any work starts -- and
+// the launch's fixed costs are paid once per workgroup: four groups per workgroup at large batches.
+template <int IDT, int DDT, int SG>
+__global__ __launch_bounds__(FL_THREADS * SG) void fl_keys_kernel(const FlKeysK a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_row_all[];        // [SG][n_sparse][FLK_TILE]
     // the descriptor arrays, copied out of the kernel argument once (one coalesced round of vector loads): indexed in place
     // with anything but a compile-time constant, hipcc fetched every field with a vector load from the kernarg segment and
     // waited for it on the spot -- a round trip per field per slot (22 us for this launch)
@@ -369,26 +401,29 @@ __global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
     __shared__ FlDevPiece c_pc[2 * FL_MAX_GROUPS];
     __shared__ int32_t c_fp[2 * FL_MAX_GROUPS];
     __shared__ int16_t c_oh[FL_MAX_SPARSE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid_all = threadIdx.x, lane = tid_all & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
+    const int grp = wave_all >> 2, wave = wave_all & 3, tid = tid_all & (FL_THREADS - 1);     // the group's own 4 waves / 256 threads
+    uint32_t (*s_row)[FLK_TILE] = reinterpret_cast<uint32_t (*)[FLK_TILE]>(s_row_all) + grp * a.n_sparse;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.sparse);
         uint32_t* dst = reinterpret_cast<uint32_t*>(c_sp);
-        for (int w = tid; w < a.n_sparse * static_cast<int>(sizeof(swr_sparse_slot) / 4); w += FL_THREADS) dst[w] = src[w];
+        for (int w = tid_all; w < a.n_sparse * static_cast<int>(sizeof(swr_sparse_slot) / 4); w += FL_THREADS * SG) dst[w] = src[w];
         src = reinterpret_cast<const uint32_t*>(a.dense);
         dst = reinterpret_cast<uint32_t*>(c_dn);
-        for (int w = tid; w < a.n_dense * static_cast<int>(sizeof(swr_dense_slot) / 4); w += FL_THREADS) dst[w] = src[w];
+        for (int w = tid_all; w < a.n_dense * static_cast<int>(sizeof(swr_dense_slot) / 4); w += FL_THREADS * SG) dst[w] = src[w];
         src = reinterpret_cast<const uint32_t*>(a.piece);
         dst = reinterpret_cast<uint32_t*>(c_pc);
-        for (int w = tid; w < 2 * a.NR * static_cast<int>(sizeof(FlDevPiece) / 4); w += FL_THREADS) dst[w] = src[w];
-        if (tid < 2 * FL_MAX_GROUPS) c_fp[tid] = a.fpiece[tid];
-        if (tid < FL_MAX_SPARSE) c_oh[tid] = a.oh_off[tid];
+        for (int w = tid_all; w < 2 * a.NR * static_cast<int>(sizeof(FlDevPiece) / 4); w += FL_THREADS * SG) dst[w] = src[w];
+        if (tid_all < 2 * FL_MAX_GROUPS) c_fp[tid_all] = a.fpiece[tid_all];
+        if (tid_all < FL_MAX_SPARSE) c_oh[tid_all] = a.oh_off[tid_all];
     }
     __syncthreads();
-    const int64_t b0 = static_cast<int64_t>(blockIdx.x) * FLK_TILE;
-    const int rows = static_cast<int>(min<int64_t>(FLK_TILE, a.B - b0));
+    const int64_t b0 = (static_cast<int64_t>(blockIdx.x) * SG + grp) * FLK_TILE;
+    // (a group past the end of the batch keeps running -- the barriers are the workgroup's -- on the last sample, stores nothing)
+    const int rows = static_cast<int>(max<int64_t>(0, min<int64_t>(FLK_TILE, a.B - b0)));
     uint32_t* __restrict__ keys = reinterpret_cast<uint32_t*>(a.ws + a.off_keys);
-    const int64_t bl = b0 + min(lane, rows - 1);                 // (lanes past the end re-read the last sample; nothing is stored)
+    const int64_t bl = min<int64_t>(b0 + min(lane, max(rows, 1) - 1), a.B - 1);                 // (lanes past the end re-read the last sample; nothing is stored)
 
     // 1. ids -> rows (layers.py:70 `.long()` lookup index; optional hash stage; out-of-range -> row 0 + sticky flag)
     int64_t id[FLK_IDS];
@@ -443,7 +478,7 @@ __global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
     float fv[FLK_FP][8];
 #pragma unroll
     for (int u = 0; u < FLK_FP; ++u) {
-        const int fp = wave + 4 * u, r = min(lane, rows - 1);      // item tid + 256 u: piece (wave-uniform), sample
+        const int fp = wave + 4 * u, r = min(lane, max(rows, 1) - 1);      // item tid + 256 u: piece (wave-uniform), sample
 #pragma unroll
         for (int e = 0; e < 8; ++e) fv[u][e] = 0.f;
         if (fp < a.nfp) {
@@ -457,7 +492,7 @@ __global__ __launch_bounds__(FL_THREADS) void fl_keys_kernel(const FlKeysK a) {
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (e < pc.n_valid) fv[u][e] = fl_dense<DDT>(c_dn[pc.slot + e], b0 + r);
+                    if (e < pc.n_valid) fv[u][e] = fl_dense<DDT>(c_dn[pc.slot + e], min<int64_t>(b0 + r, a.B - 1));
             }
         }
     }
@@ -583,13 +618,21 @@ extern "C" int swr_fl_keys(const swr_fl_plan* plan, void* workspace, uint32_t* e
     int common = plan->sparse_host[0].idx_dtype;
     for (int s = 1; s < plan->n_sparse; ++s)
         if (plan->sparse_host[s].idx_dtype != common) common = 0;
-    const dim3 grid(static_cast<unsigned>(swr_ceil_div(plan->B, FLK_TILE)));
     hipStream_t st = static_cast<hipStream_t>(stream);
     bool f32 = true;
     for (int s = 0; s < plan->n_dense; ++s) f32 = f32 && plan->dense_host[s].dtype == SWR_F32;
-    if (common == SWR_I64 && f32) hipLaunchKernelGGL((fl_keys_kernel<SWR_I64, SWR_F32>), grid, dim3(FL_THREADS), 0, st, a);
-    else if (common == SWR_I32 && f32) hipLaunchKernelGGL((fl_keys_kernel<SWR_I32, SWR_F32>), grid, dim3(FL_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((fl_keys_kernel<0, 0>), grid, dim3(FL_THREADS), 0, st, a);
+    const int sg = plan->B >= 32768 ? 4 : 1;
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(plan->B, FLK_TILE * sg)));
+    const unsigned lds = static_cast<unsigned>(sg) * plan->n_sparse * FLK_TILE * sizeof(uint32_t);
+#define FLK_GO(SGV)                                                                                                              \
+    do {                                                                                                                         \
+        if (common == SWR_I64 && f32) hipLaunchKernelGGL((fl_keys_kernel<SWR_I64, SWR_F32, SGV>), grid, dim3(FL_THREADS * SGV), lds, st, a);   \
+        else if (common == SWR_I32 && f32) hipLaunchKernelGGL((fl_keys_kernel<SWR_I32, SWR_F32, SGV>), grid, dim3(FL_THREADS * SGV), lds, st, a); \
+        else hipLaunchKernelGGL((fl_keys_kernel<0, 0, SGV>), grid, dim3(FL_THREADS * SGV), lds, st, a);                           \
+    } while (0)
+    if (sg == 4) FLK_GO(4);
+    else FLK_GO(1);
+#undef FLK_GO
     return swr_launch_status();
 }
 
@@ -901,4 +944,242 @@ extern "C" int swr_fl_dw(const swr_fl_plan* plan, const void* fl_workspace, cons
         P.bit0 = static_cast<int16_t>((8 * o8) % 32);
     }
     return tn_x6_gather(a, g, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ BN backward + dX
+// dZ = ca * dY + cb * (Z - mean) + cc   (swr_act_bwd_apply without an activation: the BatchNorm backward of the stacked
+// expert / gate layer, mmoe.py:44-49 through layers.py:254-256) and dX = dZ W[:, sel] in ONE pass: a lane computes the 8
+// values of its A fragment from dY and Z (four 16-byte loads), writes them out as dZ -- the weight-gradient product reads it
+// -- and splits them into the three bf16 terms in registers; the weights arrive as the B3X image of swr_fl_prep.
+// Same arithmetic, in the same order, as swr_act_bwd_apply followed by swr_gemm_nt: identical bits.  Saves the dZ read of the
+// product, one launch, and the pass's latency: 23 + 31 us -> one HBM-bound pass over dY, Z, dZ, dX.
+struct FlDxK {
+    const char* dY; const char* Z;        // byte pointers: 32-bit lane offsets
+    const float* ca; const float* cb; const float* cc; const float* mean;
+    float* dZ; int64_t lddz;
+    float* dX; int64_t lddx;
+    const uint4* b3x;
+    int64_t M;
+    int K, n_out, n_groups, n_tiles;
+    uint32_t lddy_b, ldz_b;               // row pitches in bytes
+};
+
+#define FL_XLOAD(dst, voff, sbase, OFF) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+
+template <int NT>
+__global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
+    constexpr int PITCH_U4 = ((6 * NT + 3) / 4 * 4) * 64;
+    constexpr int PPW = PITCH_U4 / 64 / 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];          // [2][PITCH_U4] weights | 4 x 160 coefficients
+    float* coef = reinterpret_cast<float*>(lds + 2 * PITCH_U4);          // ca | cb | cc | mean, 160 each (zero past K)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int i = lane & 31, s = lane >> 5;
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const bool live = tile < k.n_tiles;
+    const int64_t T = live ? tile : k.n_tiles - 1;
+    const int K = k.K, ng = k.n_groups, nc = (ng + 1) / 2;
+    for (int c = threadIdx.x; c < 4 * 160; c += FL_THREADS) {
+        const int a = c / 160, n = c - a * 160;
+        const float* src = a == 0 ? k.ca : (a == 1 ? k.cb : (a == 2 ? k.cc : k.mean));
+        coef[c] = n < K ? src[n] : 0.f;
+    }
+    const int64_t row = min<int64_t>(T * 32 + i, k.M - 1);
+    const bool row_ok = live && T * 32 + i < k.M;
+    // byte offset of the lane's 32 bytes in group 0 of its row; group g = + 64 g (an immediate), the last group's loads are
+    // clamped to the row's last 16 bytes (K % 4 == 0) and masked
+    const uint32_t oy = static_cast<uint32_t>(row) * k.lddy_b + 32u * s;
+    const uint32_t oz = static_cast<uint32_t>(row) * k.ldz_b + 32u * s;
+    const int kt = 16 * (ng - 1) + 8 * s;                                // first k of the lane in the last group
+    const uint32_t t0 = static_cast<uint32_t>(min(kt, K - 4)) * 4u, t1 = static_cast<uint32_t>(min(kt + 4, K - 4)) * 4u;
+    const uint32_t oy_t0 = static_cast<uint32_t>(row) * k.lddy_b + t0, oy_t1 = static_cast<uint32_t>(row) * k.lddy_b + t1;
+    const uint32_t oz_t0 = static_cast<uint32_t>(row) * k.ldz_b + t0, oz_t1 = static_cast<uint32_t>(row) * k.ldz_b + t1;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    fl_u32x4 ar[4][4];                   // ring of 4 groups: dY (2 x 16 bytes), Z (2 x 16 bytes)
+    // (g is a constant wherever this is called -- unrolled loops, constexpr chunk numbers -- so the switch folds away; the
+    // byte offset of a group must be a literal of the instruction)
+    auto a_issue = [&](int g, fl_u32x4 (&dst)[4]) {
+        const char* by = k.dY;
+        const char* bz = k.Z;
+        if (g + 1 < ng) {
+            switch (g) {
+#define FL_XG(GV)                                                                              \
+                case GV:                                                                       \
+                    FL_XLOAD(dst[0], oy, by, GV * 64); FL_XLOAD(dst[1], oy, by, GV * 64 + 16);  \
+                    FL_XLOAD(dst[2], oz, bz, GV * 64); FL_XLOAD(dst[3], oz, bz, GV * 64 + 16);  \
+                    break;
+                FL_XG(0) FL_XG(1) FL_XG(2) FL_XG(3) FL_XG(4) FL_XG(5) FL_XG(6) FL_XG(7) FL_XG(8) FL_XG(9) FL_XG(10) FL_XG(11)
+                FL_XG(12) FL_XG(13) FL_XG(14) FL_XG(15)
+#undef FL_XG
+                default: break;
+            }
+        } else {
+            const uint32_t y0 = oy_t0, y1 = oy_t1, z0 = oz_t0, z1 = oz_t1;
+            FL_XLOAD(dst[0], y0, by, 0); FL_XLOAD(dst[1], y1, by, 0);
+            FL_XLOAD(dst[2], z0, bz, 0); FL_XLOAD(dst[3], z1, bz, 0);
+        }
+    };
+    auto dma_chunk = [&](int c, int buf) {
+        const uint4* src = k.b3x + static_cast<size_t>(c) * PITCH_U4 + wave * (PPW * 64) + lane;
+        uint4* dst = lds + buf * PITCH_U4 + wave * (PPW * 64);
+#pragma unroll
+        for (int u = 0; u < PPW; ++u)
+            __builtin_amdgcn_global_load_lds((fl_glb_ptr)(src + u * 64), (fl_lds_ptr)(dst + u * 64), 16, 0, 0);
+    };
+
+    a_issue(0, ar[0]);
+    if (ng > 1) a_issue(1, ar[1]);
+    if (ng > 2) a_issue(2, ar[2]);
+    if (ng > 3) a_issue(3, ar[3]);
+    dma_chunk(0, 0);
+    {
+        fl_u32x4 t0_ = ar[0][0], t1_ = ar[0][1], t2_ = ar[0][2], t3_ = ar[0][3], t4_ = ar[1][0], t5_ = ar[1][1], t6_ = ar[1][2],
+                 t7_ = ar[1][3];
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(t0_), "+v"(t1_), "+v"(t2_), "+v"(t3_), "+v"(t4_), "+v"(t5_), "+v"(t6_), "+v"(t7_) :: "memory");
+        ar[0][0] = t0_; ar[0][1] = t1_; ar[0][2] = t2_; ar[0][3] = t3_; ar[1][0] = t4_; ar[1][1] = t5_; ar[1][2] = t6_; ar[1][3] = t7_;
+    }
+    __syncthreads();                     // (the coefficients too)
+    __builtin_amdgcn_sched_barrier(0);
+
+    float* __restrict__ dzrow = k.dZ + row * k.lddz;
+    auto chunk = [&](auto c_c) {
+        constexpr int C = decltype(c_c)::value, BUF = C & 1;
+        if (C >= nc) return;
+        if (C + 1 < nc) dma_chunk(C + 1, BUF ^ 1);
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = 2 * BUF + gq;
+            const int g = 2 * C + gq;
+            if (g < ng) {
+                // dZ of the lane's 8 columns: the operations of act_bwd_apply_v4_kernel (bn.hip), in its order
+                const bool last = g + 1 == ng;
+                float v[8];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kk_ = last ? min(16 * g + 8 * s + 4 * hh, K - 4) : 16 * g + 8 * s + 4 * hh;
+                    const float4 a4 = *reinterpret_cast<const float4*>(coef + kk_), b4 = *reinterpret_cast<const float4*>(coef + 160 + kk_),
+                                 c4 = *reinterpret_cast<const float4*>(coef + 320 + kk_), mu = *reinterpret_cast<const float4*>(coef + 480 + kk_);
+                    const float4 dy = __builtin_bit_cast(float4, ar[slot][hh]), z = __builtin_bit_cast(float4, ar[slot][2 + hh]);
+                    float4 gq4 = make_float4(dy.x * a4.x, dy.y * a4.y, dy.z * a4.z, dy.w * a4.w);
+                    gq4.x = fmaf(b4.x, z.x - mu.x, gq4.x) + c4.x; gq4.y = fmaf(b4.y, z.y - mu.y, gq4.y) + c4.y;
+                    gq4.z = fmaf(b4.z, z.z - mu.z, gq4.z) + c4.z; gq4.w = fmaf(b4.w, z.w - mu.w, gq4.w) + c4.w;
+                    const bool ok = 16 * g + 8 * s + 4 * hh < K;          // (only the last group can be cut)
+                    if (!ok) gq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok && row_ok) *reinterpret_cast<float4*>(dzrow + 16 * g + 8 * s + 4 * hh) = gq4;
+                    v[4 * hh] = gq4.x; v[4 * hh + 1] = gq4.y; v[4 * hh + 2] = gq4.z; v[4 * hh + 3] = gq4.w;
+                }
+                bf16x8 ah, am, al;
+                fl_split8(v, ah, am, al);
+                const uint4* bp = lds + BUF * PITCH_U4 + gq * (NT * 3 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
+                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
+                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
+                    f32x16 c_ = acc[t];
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0, c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1, c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0, c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1, c_, 0, 0, 0);
+                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0, c_, 0, 0, 0);
+                    acc[t] = c_;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * C + 4 + gq < ng) a_issue(2 * C + 4 + gq, ar[slot]);
+        }
+        constexpr int NB = 2 * (BUF ^ 1);
+        const int n_issued = __builtin_amdgcn_readfirstlane(min(2, max(0, ng - (2 * C + 4))));
+        fl_u32x4 t0_ = ar[NB][0], t1_ = ar[NB][1], t2_ = ar[NB][2], t3_ = ar[NB][3], t4_ = ar[NB + 1][0], t5_ = ar[NB + 1][1],
+                 t6_ = ar[NB + 1][2], t7_ = ar[NB + 1][3];
+        // (the dZ stores of this chunk count too: stores and loads retire in order on the same counter -- the waits below
+        // leave only THIS chunk's loads and stores outstanding when every store was issued before its group's loads;
+        // counted conservatively: 4 loads per group issued here + up to 4 stores)
+        asm volatile("s_cmp_eq_u32 %8, 2\n\t"
+                     "s_cbranch_scc1 1f\n\t"
+                     "s_cmp_eq_u32 %8, 1\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_branch 3f\n"
+                     "2:\n\t"
+                     "s_waitcnt vmcnt(4)\n\t"
+                     "s_branch 3f\n"
+                     "1:\n\t"
+                     "s_waitcnt vmcnt(8)\n"
+                     "3:\n\t"
+                     : "+v"(t0_), "+v"(t1_), "+v"(t2_), "+v"(t3_), "+v"(t4_), "+v"(t5_), "+v"(t6_), "+v"(t7_)
+                     : "s"(n_issued)
+                     : "memory", "scc");
+        ar[NB][0] = t0_; ar[NB][1] = t1_; ar[NB][2] = t2_; ar[NB][3] = t3_; ar[NB + 1][0] = t4_; ar[NB + 1][1] = t5_;
+        ar[NB + 1][2] = t6_; ar[NB + 1][3] = t7_;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
+    chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!live) return;
+    swr_gemm_args e;
+    e.M = k.M; e.N = k.n_out; e.C = k.dX; e.ldc = k.lddx; e.bias = nullptr; e.stat_partials = nullptr; e.groups = 1; e.gsC = 0;
+    e.gsBias = 0; e.c_act = 0; e.accumulate = 0;
+    rows_epilogue<NT>(e, k.n_tiles, acc, 0, T, T * 32, 0, i, s);
+}
+
+extern "C" int swr_bn_bwd_dx_supported(int K, int n_out) {
+    return (K >= 16 && K <= 160 && K % 4 == 0 && n_out >= 1 && n_out <= 32 * FL_NT_MAX) ? 1 : 0;
+}
+
+extern "C" int swr_bn_bwd_dx(const swr_fl_plan* plan, const void* fl_workspace, const float* dY, int64_t lddy, const float* Z,
+                             int64_t ldz, const float* ca, const float* cb, const float* cc, const float* mean, int n_out,
+                             float* dZ, int64_t lddz, float* dX, int64_t lddx, void* stream) {
+    FlHost h;
+    int rc = fl_build(plan, h);
+    if (rc != SWR_OK) return rc;
+    const int K = plan->N;
+    SWR_REQUIRE(fl_workspace && dY && Z && ca && cb && cc && mean && dZ && dX, SWR_ERR_ARG);
+    SWR_REQUIRE(swr_bn_bwd_dx_supported(K, n_out) && lddy >= K && ldz >= K && lddz >= K && lddx >= n_out, SWR_ERR_UNSUPPORTED);
+    SWR_REQUIRE(lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 && swr_aligned16(dY) && swr_aligned16(Z) && swr_aligned16(dZ) &&
+                    plan->B * lddy * 4 < (1ll << 32) && plan->B * ldz * 4 < (1ll << 32), SWR_ERR_ALIGN);
+    if (plan->B == 0) return SWR_OK;
+    FlDxK k;
+    k.dY = reinterpret_cast<const char*>(dY); k.Z = reinterpret_cast<const char*>(Z);
+    k.ca = ca; k.cb = cb; k.cc = cc; k.mean = mean;
+    k.dZ = dZ; k.lddz = lddz; k.dX = dX; k.lddx = lddx;
+    k.b3x = reinterpret_cast<const uint4*>(static_cast<const char*>(fl_workspace) + h.o.b3x);
+    k.M = plan->B; k.K = K; k.n_out = n_out; k.n_groups = (K + 15) / 16; k.n_tiles = h.n_tiles;
+    k.lddy_b = static_cast<uint32_t>(lddy * 4); k.ldz_b = static_cast<uint32_t>(ldz * 4);
+    const int nt = (n_out + 31) / 32;
+    const dim3 grid(static_cast<unsigned>(swr_ceil_div(h.n_tiles, 4)));
+    const unsigned lds = static_cast<unsigned>(2 * fl_pitch_blocks(nt) * 1024 + 4 * 160 * sizeof(float));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define FL_GOX(NTV)                                                                                                     \
+    do {                                                                                                                \
+        static bool raised = false;                                                                                     \
+        if (lds >= 64 * 1024 && !raised) {                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fl_dx_kernel<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    80 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;                                     \
+            raised = true;                                                                                              \
+        }                                                                                                               \
+        hipLaunchKernelGGL(fl_dx_kernel<NTV>, grid, dim3(FL_THREADS), lds, st, k);                                      \
+    } while (0)
+    switch (nt) {
+        case 1: FL_GOX(1); break;
+        case 2: FL_GOX(2); break;
+        case 3: FL_GOX(3); break;
+        case 4: FL_GOX(4); break;
+        default: FL_GOX(5); break;
+    }
+#undef FL_GOX
+    return swr_launch_status();
 }

@@ -181,7 +181,7 @@ class FlPlan(C.Structure):
 
 class FlOffsets(C.Structure):
     _fields_ = [("zero", C.c_int64), ("planes", C.c_int64), ("a3f", C.c_int64), ("b3", C.c_int64), ("keys", C.c_int64),
-                ("mask", C.c_int64), ("mask_t", C.c_int64), ("voff", C.c_int64), ("densef", C.c_int64), ("total", C.c_int64),
+                ("mask", C.c_int64), ("mask_t", C.c_int64), ("voff", C.c_int64), ("densef", C.c_int64), ("b3x", C.c_int64), ("total", C.c_int64),
                 ("nd4", C.c_int32), ("n_fpieces", C.c_int32)]
 
 
@@ -213,6 +213,8 @@ _SIGS = {
     "swr_fl_prep": (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _P, _I, _P, _L, _P, _P]),
     "swr_fl_keys": (C.c_int, [_P, _P, _P, _P]),
     "swr_fl_fwd": (C.c_int, [_P, _P, _P, _P, _L, _P, _P]),
+    "swr_bn_bwd_dx_supported": (C.c_int, [_I, _I]),
+    "swr_bn_bwd_dx": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P]),
     "swr_fl_dw_supported": (C.c_int, [_P, _L]),
     "swr_fl_dw_workspace_bytes": (_Z, [_P]),
     "swr_fl_dw": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _Z, _P]),

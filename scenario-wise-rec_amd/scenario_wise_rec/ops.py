@@ -168,6 +168,7 @@ SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"      # "0": everythi
 # 0.506 ms at config 2; a fork / join pair costs ~10-20 us of edges, so smaller products stay on the main stream (forking
 # every product LOSES 0.02 ms at configs 1, 3, 4) and chip-filling ones only slow what they overlap
 SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = 2e9, 2e10
+FUSE_BN_DX = os.environ.get("SWR_FUSE_BN_DX", "1") != "0"      # BatchNorm backward applied inside the first layer's dX product
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
@@ -1030,6 +1031,7 @@ class LinearBNAct(Function):
         p_be = ctx.params[off + cfg["n_bn"]:off + 2 * cfg["n_bn"]] if cfg["bn"] is not None else ()
         dgamma = dbeta = None
         direct_bn = False
+        bn_dx = None
         dZ = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
         if ctx.training_bn:
             tile = lib.swr_bnmix_tile_rows() if ctx.mix is not None else 64
@@ -1063,9 +1065,20 @@ class LinearBNAct(Function):
             H.check(lib.swr_bn_bwd_finalize(H.ptr(partials), nt, M, Ntot, H.ptr(gamma), H.ptr(rstd), H.ptr(dgamma),
                                             H.ptr(dbeta), int(direct_bn), H.ptr(ca), H.ptr(cb), H.ptr(cc), H.stream()),
                     "swr_bn_bwd_finalize")
-            H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(ca), H.ptr(cb),
-                                          H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
-                    "swr_act_bwd_apply")
+            # fused lookup, gate-mix level (no activation left to differentiate), the weight-gradient product forked / held back
+            # behind dX: dZ is produced INSIDE the dX product (swr_bn_bwd_dx below) -- no pass of its own
+            oh0 = ctx.onehot
+            n_dw = 2.0 * M * Ntot * K
+            fuse_dx = (FUSE_BN_DX and ctx.fl_fused and ctx.mix is not None and oh0 is not None and oh0.n_sel > 0
+                       and ctx.needs_input_grad[1] and getattr(ctx, "wt_sel", None) is not None and dY.stride(0) % 4 == 0
+                       and lib.swr_bn_bwd_dx_supported(Ntot, oh0.n_sel)
+                       and ((SIDE_STREAM and SIDE_DW_MIN_FLOP <= n_dw < SIDE_DW_MAX_FLOP) or _late["on"]))
+            if fuse_dx:
+                bn_dx = (dY, ca, cb, cc)
+            else:
+                H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(ca), H.ptr(cb),
+                                              H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
+                        "swr_act_bwd_apply")
         else:
             # eval-mode BN (a fixed affine) or no BN: dZ = scale * act'(Y) dY
             identity = scale is None and all(a[2] in (None, "none") for a in _norm_acts(cfg["acts"], Ntot))
@@ -1146,7 +1159,15 @@ class LinearBNAct(Function):
             if oh.n_sel > 0:
                 dsel = torch.empty((M, oh.n_sel), dtype=torch.float32, device=dev)
                 wt = getattr(ctx, "wt_sel", None)
-                gemm("nt", dZ, wt if wt is not None else _selected_wt(W, oh.sel), dsel, M, oh.n_sel, Ntot)
+                if bn_dx is not None:
+                    dYb, ca_, cb_, cc_ = bn_dx
+                    H.check(lib.swr_bn_bwd_dx(C.byref(oh.fl["plan"]), H.ptr(oh.fl["ws"]), H.ptr(dYb), dYb.stride(0), H.ptr(Z), Ntot,
+                                              H.ptr(ca_), H.ptr(cb_), H.ptr(cc_), H.ptr(mean), oh.n_sel, H.ptr(dZ), Ntot, H.ptr(dsel),
+                                              oh.n_sel, H.stream()), "swr_bn_bwd_dx")
+                    if _side["deferred"]:
+                        _flush_deferred()
+                else:
+                    gemm("nt", dZ, wt if wt is not None else _selected_wt(W, oh.sel), dsel, M, oh.n_sel, Ntot)
             else:
                 dsel = dZ
             oh.ctx.fused_dx = (dsel, oh.compact)

@@ -1338,6 +1338,29 @@ def test_fused_lookup_step_is_bitwise_the_written_layout(family, E, vocabs, n_de
             assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
 
 
+def test_bn_backward_inside_the_dx_product_is_bitwise_the_two_launches(monkeypatch):
+    """swr_bn_bwd_dx (csrc/first_layer.hip): dZ = ca dY + cb (Z - mean) + cc computed in the A fragment of the first layer's dX
+    product and written out for the weight gradient, against swr_act_bwd_apply + swr_gemm_nt -- same operations in the same
+    order: every gradient BIT FOR BIT.  (Taken only where the weight-gradient product is forked behind dX: a batch of
+    32 768 at these widths.)"""
+    from scenario_wise_rec import ops
+    vocabs = [1000, 5000, 8, 2, 3, 51, 1472, 16, 35, 4, 119, 455, 6, 3, 200, 300]
+    monkeypatch.setattr(ops, "FUSE_BN_DX", False)
+    p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, 32768, 65536, 5)
+    monkeypatch.setattr(ops, "FUSE_BN_DX", True)
+    calls = []
+    real = ops.lib.swr_bn_bwd_dx
+    monkeypatch.setattr(ops.lib, "swr_bn_bwd_dx", lambda *a: (calls.append(1), real(*a))[1])
+    p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, 32768, 65536, 5)
+    assert calls, "the fused BatchNorm-backward + dX product was not taken"
+    assert np.array_equal(p0, p1) and l0 == l1
+    for k in g0:
+        if isinstance(g0[k], tuple):
+            assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]), k
+        else:
+            assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
+
+
 def test_fused_lookup_step_against_the_oracle():
     """The fused lookup + first layer directly against the fp64 oracle (KuaiRand-like shape, a row-sparse table, fp16 / int
     dense features): logits within 1e-4, loss, every gradient."""
