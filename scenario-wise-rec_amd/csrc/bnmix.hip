@@ -233,7 +233,6 @@ __global__ __launch_bounds__(BM_ROWS * H4N, NE <= 4 ? 4 : 2) void bnmix_bwd_kern
     // ---- expert columns: dY = relu'(.) dx; stage dY and dY * xhat, write dY
     float* row1 = t1 + r * P;
     float* row2 = t2 + r * P;
-    float* __restrict__ dyrow = a.dY + mm * a.lddy;
     // The statistics of expert j + 1 are requested BEFORE expert j's dY store: the compiler may not move a load of a.mean
     // above a store to a.dY (they could alias), so in the plain loop every iteration began with an exposed load latency.
     float4 mu = ldf4(a.mean + h), rs = ldf4(a.rstd + h);
@@ -253,7 +252,6 @@ __global__ __launch_bounds__(BM_ROWS * H4N, NE <= 4 ? 4 : 2) void bnmix_bwd_kern
             *reinterpret_cast<float4*>(row2 + c) =
                 make_float4(d.x * ((ze[j].x - mu_c.x) * rs_c.x), d.y * ((ze[j].y - mu_c.y) * rs_c.y),
                             d.z * ((ze[j].z - mu_c.z) * rs_c.z), d.w * ((ze[j].w - mu_c.w) * rs_c.w));
-            if (valid) *reinterpret_cast<float4*>(dyrow + c) = d;
         }
     }
     // ---- gate columns: softmax backward dZg[o][j] = g (dg - <dg_o, g_o>); lane (o*ne + j) % h4n keeps column o*ne + j
@@ -279,7 +277,6 @@ __global__ __launch_bounds__(BM_ROWS * H4N, NE <= 4 ? 4 : 2) void bnmix_bwd_kern
                 const int c = gc + cq;
                 row1[c] = d;
                 row2[c] = d * ((zq[q] - muq[q]) * rsq[q]);
-                if (valid) dyrow[c] = d;
             }
         }
     } else
@@ -297,12 +294,23 @@ __global__ __launch_bounds__(BM_ROWS * H4N, NE <= 4 ? 4 : 2) void bnmix_bwd_kern
                     const float d = valid ? g[o * NE + j] * (dg[o * NE + j] - dot) : 0.f;
                     row1[c] = d;
                     row2[c] = d * ((z[c] - a.mean[c]) * a.rstd[c]);
-                    if (valid) dyrow[c] = d;
-                }
+                    }
             }
         }
     }
     __syncthreads();
+    // ---- dY leaves from the LDS tile, row by row in 16-byte pieces of consecutive lanes: the tile's 64 rows are one
+    // contiguous block of dY when lddy == N.  (Written from the registers -- 128 bytes per (row, expert) at a 592-byte row
+    // pitch, the gate columns float by float -- the partially written lines left the L2 more than once: 100 MB of HBM
+    // writes for a 39 MB tensor, profiles/r04_a_pmc_hbm.txt.)
+    {
+        const int n4 = N >> 2;                                  // N % 4 == 0 (checked by the launcher)
+        const int rows_here = static_cast<int>(min<int64_t>(BM_ROWS, a.M - m0));
+        for (int item = threadIdx.x; item < rows_here * n4; item += blockDim.x) {
+            const int rr = item / n4, c4 = item - rr * n4;
+            *reinterpret_cast<float4*>(a.dY + (m0 + rr) * a.lddy + 4 * c4) = *reinterpret_cast<const float4*>(t1 + rr * P + 4 * c4);
+        }
+    }
     // ---- column sums over the 64 rows: 4 threads per column (rows i*4 + part), fixed order
     for (int item = threadIdx.x; item < N * 4; item += blockDim.x) {
         const int c = item >> 2, part = item & 3;
@@ -400,7 +408,7 @@ extern "C" int swr_bnmix_bwd(const swr_bnmix_args* args, void* stream) {
     const int rc = bnmix_common(args, kk);
     if (rc != SWR_OK) return rc;
     const swr_bnmix_args& a = kk.a;
-    SWR_REQUIRE(a.dP && a.lddp >= a.D * a.H && a.mean && a.rstd && a.dY && a.lddy >= kk.n_cols && a.bn_partials, SWR_ERR_ARG);
+    SWR_REQUIRE(a.dP && a.lddp >= a.D * a.H && a.mean && a.rstd && a.dY && a.lddy >= kk.n_cols && a.bn_partials && kk.n_cols % 4 == 0, SWR_ERR_ARG);
     SWR_REQUIRE(a.lddp % 4 == 0 && a.lddy % 4 == 0 && swr_aligned16(a.dP) && swr_aligned16(a.dY) && swr_aligned16(a.mean) &&
                     swr_aligned16(a.rstd) && (a.G == nullptr || swr_aligned16(a.G)), SWR_ERR_ALIGN);
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(a.M, BM_ROWS));

@@ -1366,6 +1366,10 @@ def _tower_backward(ctx, saved, dV=None, sel=None):
                 ldc=K)
     if direct_w and SIDE_STREAM and not _late["on"] and _in_backward():
         _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
+    elif direct_w and _late["on"]:
+        # split backward (data-parallel step): nothing but the optimizer reads it -- with the other weight-gradient work,
+        # behind the row lists (it sat on the critical path in front of the expert level's backward: 25 us at config 2)
+        _late["jobs"].append(launch_dw1)
     else:
         launch_dw1()
     grads = []

@@ -98,4 +98,32 @@ def dw(j):
 
 
 print(f"swr_fl_dw (+ reduce) {timed(dw):7.1f} us")
+
+# BatchNorm backward + dX in one pass against the two launches it replaces
+ca, cb, cc, mean = (torch.randn(N, device="cuda") * 0.1 for _ in range(4))
+dY = [torch.randn((B, N), device="cuda") * 1e-4 for _ in range(4)]
+Zs = [torch.randn((B, N), device="cuda") for _ in range(4)]
+dZo = torch.empty((B, N), device="cuda")
+dsel = torch.empty((B, oh.n_sel), device="cuda")
+for j in range(4):
+    prep(j)                        # (writes the B3X image of `sel` into each workspace)
+
+
+def dx_fused(j):
+    f = infos[j % 4].fl
+    H.check(lib.swr_bn_bwd_dx(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(dY[j % 4]), N, H.ptr(Zs[j % 4]), N, H.ptr(ca), H.ptr(cb), H.ptr(cc),
+                              H.ptr(mean), oh.n_sel, H.ptr(dZo), N, H.ptr(dsel), oh.n_sel, H.stream()), "bn_bwd_dx")
+
+
+acts, n_acts = H.act_ranges(None, N)
+
+
+def dx_two(j):
+    H.check(lib.swr_act_bwd_apply(H.ptr(dY[j % 4]), N, H.ptr(Zs[j % 4]), N, H.ptr(Zs[j % 4]), N, H.ptr(ca), H.ptr(cb), H.ptr(cc), H.ptr(mean),
+                                  acts, n_acts, H.ptr(dZo), N, B, N, H.stream()), "act_bwd_apply")
+    ops.gemm("nt", dZo, Wt, dsel, B, oh.n_sel, N)
+
+
+print(f"swr_bn_bwd_dx (BN backward + dX)      {timed(dx_fused):7.1f} us")
+print(f"swr_act_bwd_apply + swr_gemm_nt (dX)  {timed(dx_two):7.1f} us")
 H.check_errors()
