@@ -1050,61 +1050,68 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
     __builtin_amdgcn_sched_barrier(0);
 
     float* __restrict__ dzrow = k.dZ + row * k.lddz;
+    // dZ of the lane's 8 columns of group g (the operations of act_bwd_apply_v4_kernel, bn.hip, in its order), written out,
+    // and its three bf16 terms
+    auto make_frag = [&](int g, const fl_u32x4 (&raw)[4], bf16x8& ah, bf16x8& am, bf16x8& al) {
+        const bool last = g + 1 == ng;
+        float v[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int kk_ = last ? min(16 * g + 8 * s + 4 * hh, K - 4) : 16 * g + 8 * s + 4 * hh;
+            const float4 a4 = *reinterpret_cast<const float4*>(coef + kk_), b4 = *reinterpret_cast<const float4*>(coef + 160 + kk_),
+                         c4 = *reinterpret_cast<const float4*>(coef + 320 + kk_), mu = *reinterpret_cast<const float4*>(coef + 480 + kk_);
+            const float4 dy = __builtin_bit_cast(float4, raw[hh]), z = __builtin_bit_cast(float4, raw[2 + hh]);
+            float4 q4 = make_float4(dy.x * a4.x, dy.y * a4.y, dy.z * a4.z, dy.w * a4.w);
+            q4.x = fmaf(b4.x, z.x - mu.x, q4.x) + c4.x; q4.y = fmaf(b4.y, z.y - mu.y, q4.y) + c4.y;
+            q4.z = fmaf(b4.z, z.z - mu.z, q4.z) + c4.z; q4.w = fmaf(b4.w, z.w - mu.w, q4.w) + c4.w;
+            const bool ok = 16 * g + 8 * s + 4 * hh < K;          // (only the last group can be cut)
+            if (!ok) q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && row_ok) *reinterpret_cast<float4*>(dzrow + 16 * g + 8 * s + 4 * hh) = q4;
+            v[4 * hh] = q4.x; v[4 * hh + 1] = q4.y; v[4 * hh + 2] = q4.z; v[4 * hh + 3] = q4.w;
+        }
+        fl_split8(v, ah, am, al);
+    };
+    auto mma_group = [&](const uint4* bp, bf16x8 ah, bf16x8 am, bf16x8 al) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
+            f32x16 c_ = acc[t];
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0, c_, 0, 0, 0);
+            acc[t] = c_;
+        }
+    };
+    // A chunk = two groups: both fragments are built first (their ring slots are free at once: the loads of the groups two
+    // chunks ahead leave early), then the 2 x 6 NT products run as one block -- the two waves of a SIMD then alternate
+    // between a VALU phase and a matrix phase instead of each stalling its own products behind its own arithmetic
+    // (53.9 -> 50.5 us stand-alone, tools/micro/fl_probe.py).  (Tried on top: 16 consecutive k per lane half and chunk, so
+    // that a lane reads / writes 64 contiguous bytes and a row's 128-byte piece is completed inside one chunk: 54.4 us.)
     auto chunk = [&](auto c_c) {
         constexpr int C = decltype(c_c)::value, BUF = C & 1;
         if (C >= nc) return;
         if (C + 1 < nc) dma_chunk(C + 1, BUF ^ 1);
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-            constexpr int dummy = 0; (void)dummy;
-            const int slot = 2 * BUF + gq;
-            const int g = 2 * C + gq;
-            if (g < ng) {
-                // dZ of the lane's 8 columns: the operations of act_bwd_apply_v4_kernel (bn.hip), in its order
-                const bool last = g + 1 == ng;
-                float v[8];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int kk_ = last ? min(16 * g + 8 * s + 4 * hh, K - 4) : 16 * g + 8 * s + 4 * hh;
-                    const float4 a4 = *reinterpret_cast<const float4*>(coef + kk_), b4 = *reinterpret_cast<const float4*>(coef + 160 + kk_),
-                                 c4 = *reinterpret_cast<const float4*>(coef + 320 + kk_), mu = *reinterpret_cast<const float4*>(coef + 480 + kk_);
-                    const float4 dy = __builtin_bit_cast(float4, ar[slot][hh]), z = __builtin_bit_cast(float4, ar[slot][2 + hh]);
-                    float4 gq4 = make_float4(dy.x * a4.x, dy.y * a4.y, dy.z * a4.z, dy.w * a4.w);
-                    gq4.x = fmaf(b4.x, z.x - mu.x, gq4.x) + c4.x; gq4.y = fmaf(b4.y, z.y - mu.y, gq4.y) + c4.y;
-                    gq4.z = fmaf(b4.z, z.z - mu.z, gq4.z) + c4.z; gq4.w = fmaf(b4.w, z.w - mu.w, gq4.w) + c4.w;
-                    const bool ok = 16 * g + 8 * s + 4 * hh < K;          // (only the last group can be cut)
-                    if (!ok) gq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok && row_ok) *reinterpret_cast<float4*>(dzrow + 16 * g + 8 * s + 4 * hh) = gq4;
-                    v[4 * hh] = gq4.x; v[4 * hh + 1] = gq4.y; v[4 * hh + 2] = gq4.z; v[4 * hh + 3] = gq4.w;
-                }
-                bf16x8 ah, am, al;
-                fl_split8(v, ah, am, al);
-                const uint4* bp = lds + BUF * PITCH_U4 + gq * (NT * 3 * 64) + lane;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
-                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
-                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
-                    f32x16 c_ = acc[t];
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0, c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1, c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0, c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1, c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0, c_, 0, 0, 0);
-                    acc[t] = c_;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (2 * C + 4 + gq < ng) a_issue(2 * C + 4 + gq, ar[slot]);
-        }
+        bf16x8 h0, m0_, l0, h1, m1, l1;
+        const bool g1_on = 2 * C + 1 < ng;
+        make_frag(2 * C, ar[2 * BUF], h0, m0_, l0);
+        if (g1_on) make_frag(2 * C + 1, ar[2 * BUF + 1], h1, m1, l1);
+        __builtin_amdgcn_sched_barrier(0);       // the slots' values are consumed before their registers are re-loaded
+        if (2 * C + 4 < ng) a_issue(2 * C + 4, ar[2 * BUF]);
+        if (2 * C + 5 < ng) a_issue(2 * C + 5, ar[2 * BUF + 1]);
+        const uint4* bp = lds + BUF * PITCH_U4 + lane;
+        mma_group(bp, h0, m0_, l0);
+        if (g1_on) mma_group(bp + NT * 3 * 64, h1, m1, l1);
         constexpr int NB = 2 * (BUF ^ 1);
         const int n_issued = __builtin_amdgcn_readfirstlane(min(2, max(0, ng - (2 * C + 4))));
         fl_u32x4 t0_ = ar[NB][0], t1_ = ar[NB][1], t2_ = ar[NB][2], t3_ = ar[NB][3], t4_ = ar[NB + 1][0], t5_ = ar[NB + 1][1],
                  t6_ = ar[NB + 1][2], t7_ = ar[NB + 1][3];
-        // (the dZ stores of this chunk count too: stores and loads retire in order on the same counter -- the waits below
-        // leave only THIS chunk's loads and stores outstanding when every store was issued before its group's loads;
-        // counted conservatively: 4 loads per group issued here + up to 4 stores)
+        // everything but THIS chunk's loads has landed (its dZ stores were issued in front of them; stores and loads retire
+        // in order on the one counter): the weights of chunk C + 1 and the operands of groups 2 C + 2, 2 C + 3
         asm volatile("s_cmp_eq_u32 %8, 2\n\t"
                      "s_cbranch_scc1 1f\n\t"
                      "s_cmp_eq_u32 %8, 1\n\t"
