@@ -168,6 +168,7 @@ SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"      # "0": everythi
 # 0.506 ms at config 2; a fork / join pair costs ~10-20 us of edges, so smaller products stay on the main stream (forking
 # every product LOSES 0.02 ms at configs 1, 3, 4) and chip-filling ones only slow what they overlap
 SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = 2e9, 2e10
+PAD_ROWS = os.environ.get("SWR_PAD_ROWS", "1") != "0"          # 128-byte aligned rows for the tensors of a fused gate-mix level
 FUSE_BN_DX = os.environ.get("SWR_FUSE_BN_DX", "1") != "0"      # BatchNorm backward applied inside the first layer's dX product
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
@@ -904,8 +905,17 @@ class LinearBNAct(Function):
         Ntot = W.shape[0]
         N = Ntot // G
         dev = x.device
-        Z = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
         training = cfg["training"] and cfg["bn"] is not None
+        # fused lookup + gate-mix level: the level's [B, N] tensors (Z here; dY, dZ, the compact dX in the backward) get 128-byte
+        # ALIGNED rows (pitch a multiple of 32 floats).  At a 592-byte pitch a cache line belongs to two 64-byte k-groups that a
+        # product touches a chunk apart -- with ~15 MB of rows in flight per XCD the 4 MB L2 had dropped the line in between
+        # (fl_dx: HBM reads 1.6 x, writes 1.3 x the tensors' bytes) -- and the epilogues' 128-byte row segments straddle lines
+        pad_rows = (PAD_ROWS and oh_in is not None and oh_in.fold and oh_in.fl is not None and Ntot <= 160 and training
+                    and cfg.get("mix") is not None and G == 1)
+        ldz = (Ntot + 31) // 32 * 32 if pad_rows else Ntot
+        Z = torch.empty((M, ldz), dtype=torch.float32, device=dev)
+        if ldz != Ntot:
+            Z = Z[:, :Ntot]
         n_tiles = (M + 31) // 32
         partials = torch.empty((n_tiles, Ntot, 2), dtype=torch.float32, device=dev) if training else None
         planes = planes_t = None
@@ -936,7 +946,7 @@ class LinearBNAct(Function):
                 H.check(lib.swr_fl_prep(C.byref(f["plan"]), H.ptr(W), W.stride(0), K, H.ptr(oh_in.ohtab), tabs, len(oh_in.tables_p),
                                         H.ptr(oh_in.sel) if want_t else None, oh_in.n_sel if want_t else 0, H.ptr(Wt_sel), Ntot,
                                         H.ptr(f["ws"]), H.stream()), "swr_fl_prep")
-                H.check(lib.swr_fl_fwd(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(b), H.ptr(Z), Ntot, H.ptr(partials), H.stream()),
+                H.check(lib.swr_fl_fwd(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(b), H.ptr(Z), Z.stride(0), H.ptr(partials), H.stream()),
                         "swr_fl_fwd")
                 _flush_deferred()      # the forward-time fork (the large tables' sort) is enqueued behind the product, as gemm() does
                 ctx.fl_fused = True
@@ -990,7 +1000,7 @@ class LinearBNAct(Function):
             out = torch.empty((M, D * Hm), dtype=torch.float32, device=dev)
             a = H.BnMixArgs()
             a.M, a.ne, a.H, a.D = M, ne, Hm, D
-            a.Z, a.ldz, a.scale, a.shift = Z.data_ptr(), Ntot, scale.data_ptr(), shift.data_ptr()
+            a.Z, a.ldz, a.scale, a.shift = Z.data_ptr(), Z.stride(0), scale.data_ptr(), shift.data_ptr()
             a.P, a.ldp = out.data_ptr(), D * Hm
             gate_p = torch.empty((M, D * ne), dtype=torch.float32, device=dev)     # kept for the backward (tiny)
             a.G = gate_p.data_ptr()
@@ -999,7 +1009,7 @@ class LinearBNAct(Function):
             out = Y = Z                      # (epi_act: Z already holds the activated values; the backward reads only Y)
         else:
             out = Y = torch.empty_like(Z)
-            H.check(lib.swr_affine_act_fwd(H.ptr(Z), Ntot, H.ptr(scale), H.ptr(shift), acts, n_acts, H.ptr(Y), Ntot, M,
+            H.check(lib.swr_affine_act_fwd(H.ptr(Z), Z.stride(0), H.ptr(scale), H.ptr(shift), acts, n_acts, H.ptr(Y), Ntot, M,
                                            Ntot, H.stream()), "swr_affine_act_fwd")
         ctx.cfg, ctx.dims = cfg, (M, N, K, G, Ntot)
         ctx.grad_cols = getattr(x_in, "_swr_grad_cols", None)
@@ -1032,7 +1042,10 @@ class LinearBNAct(Function):
         dgamma = dbeta = None
         direct_bn = False
         bn_dx = None
-        dZ = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+        ldp = Z.stride(0) if M > 1 else Ntot                # (the forward's row pitch: padded at a fused gate-mix level)
+        dZ = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+        if ldp != Ntot:
+            dZ = dZ[:, :Ntot]
         if ctx.training_bn:
             tile = lib.swr_bnmix_tile_rows() if ctx.mix is not None else 64
             nt = (M + tile - 1) // tile
@@ -1041,19 +1054,21 @@ class LinearBNAct(Function):
                 # incoming gradient is dP (w.r.t. the pooled outputs): one pass gives dL/d(BN output) + the statistics
                 ne, Hm, D = ctx.mix
                 dP = dY if dY.stride(0) % 4 == 0 and dY.data_ptr() % 16 == 0 else dY.contiguous()
-                dY = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+                dY = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+                if ldp != Ntot:
+                    dY = dY[:, :Ntot]
                 a = H.BnMixArgs()
                 a.M, a.ne, a.H, a.D = M, ne, Hm, D
-                a.Z, a.ldz, a.scale, a.shift = Z.data_ptr(), Ntot, scale.data_ptr(), shift.data_ptr()
+                a.Z, a.ldz, a.scale, a.shift = Z.data_ptr(), ldp, scale.data_ptr(), shift.data_ptr()
                 a.dP, a.lddp = dP.data_ptr(), dP.stride(0)
                 a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
-                a.dY, a.lddy, a.bn_partials = dY.data_ptr(), Ntot, partials.data_ptr()
+                a.dY, a.lddy, a.bn_partials = dY.data_ptr(), ldp, partials.data_ptr()
                 a.G = gate_p.data_ptr()
                 H.check(lib.swr_bnmix_bwd(C.byref(a), H.stream()), "swr_bnmix_bwd")
                 acts, n_acts = H.act_ranges(None, Ntot)          # the activations are already differentiated
                 Y = Z                                            # placeholder operand (no activation reads it)
             else:
-                H.check(lib.swr_bn_act_bwd_stats(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(mean),
+                H.check(lib.swr_bn_act_bwd_stats(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), ldp, H.ptr(mean),
                                                  H.ptr(rstd), acts, n_acts, H.ptr(partials), M, Ntot, H.stream()),
                         "swr_bn_act_bwd_stats")
             dgamma, dbeta = _grad_alias(p_g, 2), _grad_alias(p_be, 2)
@@ -1076,8 +1091,8 @@ class LinearBNAct(Function):
             if fuse_dx:
                 bn_dx = (dY, ca, cb, cc)
             else:
-                H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(ca), H.ptr(cb),
-                                              H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
+                H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Y.stride(0) if M > 1 else Ntot, H.ptr(Z), ldp, H.ptr(ca),
+                                              H.ptr(cb), H.ptr(cc), H.ptr(mean), acts, n_acts, H.ptr(dZ), ldp, M, Ntot, H.stream()),
                         "swr_act_bwd_apply")
         else:
             # eval-mode BN (a fixed affine) or no BN: dZ = scale * act'(Y) dY
@@ -1085,8 +1100,8 @@ class LinearBNAct(Function):
             if identity:
                 dZ = dY if (M <= 1 or dY.stride(0) == Ntot) else dY.contiguous()
             else:
-                H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Ntot, H.ptr(Z), Ntot, H.ptr(scale), None,
-                                              None, None, acts, n_acts, H.ptr(dZ), Ntot, M, Ntot, H.stream()),
+                H.check(lib.swr_act_bwd_apply(H.ptr(dY), dY.stride(0), H.ptr(Y), Y.stride(0) if M > 1 else Ntot, H.ptr(Z), ldp, H.ptr(scale), None,
+                                              None, None, acts, n_acts, H.ptr(dZ), ldp, M, Ntot, H.stream()),
                         "swr_act_bwd_apply")
         # parameter gradients: dW[g] = dZ_g^T x_g (+ db = column sums), dX = dZ W.  When the layer's parameters sit
         # in the arena the kernels accumulate into the gradient arena directly (it was zeroed by zero_grad).
@@ -1157,13 +1172,16 @@ class LinearBNAct(Function):
             # dX only for the columns of the tables that go through K3, compact; the lookup's backward picks it up from its
             # ctx, autograd carries a zero-stride placeholder of the right shape
             if oh.n_sel > 0:
-                dsel = torch.empty((M, oh.n_sel), dtype=torch.float32, device=dev)
+                lds_ = (oh.n_sel + 31) // 32 * 32 if ldp != Ntot else oh.n_sel
+                dsel = torch.empty((M, lds_), dtype=torch.float32, device=dev)
+                if lds_ != oh.n_sel:
+                    dsel = dsel[:, :oh.n_sel]
                 wt = getattr(ctx, "wt_sel", None)
                 if bn_dx is not None:
                     dYb, ca_, cb_, cc_ = bn_dx
-                    H.check(lib.swr_bn_bwd_dx(C.byref(oh.fl["plan"]), H.ptr(oh.fl["ws"]), H.ptr(dYb), dYb.stride(0), H.ptr(Z), Ntot,
-                                              H.ptr(ca_), H.ptr(cb_), H.ptr(cc_), H.ptr(mean), oh.n_sel, H.ptr(dZ), Ntot, H.ptr(dsel),
-                                              oh.n_sel, H.stream()), "swr_bn_bwd_dx")
+                    H.check(lib.swr_bn_bwd_dx(C.byref(oh.fl["plan"]), H.ptr(oh.fl["ws"]), H.ptr(dYb), dYb.stride(0), H.ptr(Z), ldp,
+                                              H.ptr(ca_), H.ptr(cb_), H.ptr(cc_), H.ptr(mean), oh.n_sel, H.ptr(dZ), ldp, H.ptr(dsel),
+                                              lds_, H.stream()), "swr_bn_bwd_dx")
                     if _side["deferred"]:
                         _flush_deferred()
                 else:
