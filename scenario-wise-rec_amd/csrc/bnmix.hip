@@ -19,8 +19,18 @@
 #include "common.h"
 
 #ifndef BM_ROWS
-#define BM_ROWS 64            // rows per workgroup = one tile of partial sums for swr_bn_bwd_finalize
+#define BM_ROWS 32            // rows per workgroup = one tile of partial sums for swr_bn_bwd_finalize
 #endif
+// waves per SIMD the backward kernel is compiled for.  The kernel needs 157 VGPRs; capped at 128 (4 waves per SIMD, what two
+// 64-row workgroups per CU would be) hipcc SPILLS 27 registers per lane to scratch: 57 MB written + 57 MB read back per launch
+// at batch 65 536, the "2.1 x algorithmic" HBM traffic of profiles/r03_f_pmc_hbm.json.  At 3 waves per SIMD (cap 168) nothing
+// spills, and 32-row workgroups (4 waves at H = 32, 39 KB of LDS) let three of them share a CU: 12 waves per CU where a
+// 64-row workgroup under the same cap leaves 8.  Measured in one run at batch 65 536, config 2 (tools/micro/bnmix_time.py):
+// 64 rows / cap 128: 48.7 us;  64 rows / cap 256: 35.0 us;  32 rows / cap 168: 30.0 us (step 0.4309 -> 0.4140 ms).
+#ifndef SWR_BM_BWD_WAVES
+#define SWR_BM_BWD_WAVES 3
+#endif
+#define BM_BWD_WAVES(NE, DD) ((NE) <= 4 && (DD) <= 5 ? SWR_BM_BWD_WAVES : 2)     // six outputs or eight experts: > 168 registers
 #define BM_MAX_D 8
 #define BM_MAX_G 32           // D * ne
 
@@ -165,9 +175,9 @@ __global__ __launch_bounds__(256) void bnmix_fwd_kernel(const BnMixK kk) {
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// workgroup = one 64-row tile, 64 * H/4 threads.  LDS: the tile's dY and dY * xhat, [64][n_cols + 4] floats each.
+// workgroup = one BM_ROWS-row tile, BM_ROWS * H/4 threads.  LDS: the tile's dY and dY * xhat, [BM_ROWS][n_cols + 4] floats each.
 template <int NE, int DD, bool EXACT, int H4N>
-__global__ __launch_bounds__(BM_ROWS * H4N, NE <= 4 ? 4 : 2) void bnmix_bwd_kernel(const BnMixK kk) {
+__global__ __launch_bounds__(BM_ROWS * H4N, BM_BWD_WAVES(NE, DD)) void bnmix_bwd_kernel(const BnMixK kk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const swr_bnmix_args& a = kk.a;
     const int ne = EXACT ? NE : a.ne, D = EXACT ? DD : a.D;
