@@ -317,10 +317,12 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             loss = run(first + i)
+        t_issue = time.perf_counter() - t0         # host side only: how far ahead of the device the launch loop runs
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
+        print(f"[bench] {n_steps} steps issued in {t_issue * 1e3:.2f} ms, finished in {dt * 1e3:.2f} ms", file=sys.stderr)
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -334,6 +336,9 @@ def main():
     # ---- timed region: exactly K steps between barrier + synchronize ------------------------------------
     dt, loss = timed(args.steps, 0)
     H.check_errors()
+    if os.environ.get("SWR_STAMPS"):
+        from scenario_wise_rec import ops as _ops
+        print("[bench] stamps (us): " + "  ".join(f"{n}={t:.1f}" for n, t in _ops.read_stamps().items()), file=sys.stderr)
     final_loss = float(loss.detach())
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt

@@ -64,6 +64,9 @@ int swr_zero(void* p, size_t bytes, void* stream);
 /* Test instrument (tests/test_skew_gpu.py): keeps `stream` busy for `us` microseconds with one idle-spinning wave.  The
  * Python layer injects it at its stream forks when SWR_SKEW is set, to expose missing cross-stream dependencies. */
 int swr_spin_us(int us, void* stream);
+/* Measurement instrument (SWR_STAMPS): a one-lane kernel that writes the device's 100 MHz wall clock to *slot (device memory)
+ * when `stream` reaches it -- the true placement of the branches of a replayed hipGraph, which a kernel trace perturbs. */
+int swr_stamp(unsigned long long* slot, void* stream);
 const char* swr_status_str(int status);
 /* 1 when a HIP device is visible to the calling process (no compute is done) */
 int swr_device_available(void);

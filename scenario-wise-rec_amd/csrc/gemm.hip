@@ -574,6 +574,12 @@ static int gemm_mode() {
     }
     return v;
 }
+// SWR_TN_WIDE=0: the blocked x6 weight-gradient kernels where the wide one would run (A/B measurements)
+static bool tn_wide_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SWR_TN_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 static bool use_x6() { return gemm_mode() != 0; }
 static bool use_bf16() { return gemm_mode() == 2; }
 extern "C" int swr_gemm_precision_mode() { return gemm_mode(); }
@@ -1387,6 +1393,344 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, c
     }
 }
 
+// ---- the WIDE form of the gathered product: ONE workgroup per batch split stages A (<= 5 column tiles) and ALL column tiles of
+// A' (the slab holds CT <= 14 tiles of 32 columns: 129 KB of LDS), so dZ is read, split and transposed once per batch row
+// instead of once per 128-column block of A'.  The two kinds of work have waves of their own: waves 4-7 stage (a thread = up
+// to two units of 8 rows x 2 columns, two stages in flight in registers), waves 0-3 multiply -- every SIMD holds one wave of
+// each kind, so the VALU work of the split and the matrix pipe overlap by construction instead of alternating in lockstep
+// between barriers.  The (p, q) output tiles of a multiplying wave are a COMPILE-TIME table (wide_deal: <= 12 accumulator tiles
+// per wave, one code path per wave): with the table in registers hipcc copies the accumulators around every tile's branch and
+// waits for lgkmcnt(0) in front of every MFMA block (measured: 64 us, no faster than the blocked form).
+// The staging waves load the row keys of every unit unconditionally and BEFORE the values of the stage that uses the keys loaded
+// a step earlier: the loads of a step are then a fixed count and the waits are counted (vmcnt(N)); with `if (keyed)` around the
+// key loads hipcc waits for vmcnt(0) -- a full memory round trip per 16-row stage, which is what bounds gemm_tn_x6g_kernel
+// (removing its MFMAs, splits or loads alone gains 12 / 4 / 7 of 63 us).
+#define TXW_NT 12                        // output tiles per multiplying wave
+#define TXW_DEPTH 3                      // stages in flight in the staging waves' registers
+struct WideDeal {
+    int n[4];
+    int p[4][TXW_NT + 4], q[4][TXW_NT + 4];
+    bool ok;
+};
+// Each multiplying wave takes a run of the six-product tiles and a run of the three-product tiles (columns that are all
+// one-hot: q >= QE), both in q-major order (a wave's tiles share their B fragments); equal shares, the odd tiles of the two
+// kinds go to opposite ends.
+constexpr WideDeal wide_deal(int PT, int QT, int QE) {
+    WideDeal d{};
+    int lp[2][64] = {}, lq[2][64] = {}, nk[2] = {0, 0};
+    for (int q = 0; q < QT; ++q)
+        for (int p = 0; p < PT; ++p) {
+            const int k = q >= QE ? 1 : 0;
+            lp[k][nk[k]] = p; lq[k][nk[k]] = q; ++nk[k];
+        }
+    int at[2] = {0, 0};
+    d.ok = true;
+    for (int w = 0; w < 4; ++w) {
+        int n = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int base = nk[k] / 4, rem = nk[k] % 4;
+            const int take = base + ((k == 0 ? w >= 4 - rem : w < rem) ? 1 : 0);
+            for (int j = 0; j < take; ++j) {
+                if (n < TXW_NT + 4) { d.p[w][n] = lp[k][at[k]]; d.q[w][n] = lq[k][at[k]]; }
+                ++at[k]; ++n;
+            }
+        }
+        d.n[w] = n;
+        if (n > TXW_NT) d.ok = false;
+    }
+    return d;
+}
+
+template <int CT, int PT, int QT, int QE, int W>
+__device__ __forceinline__ void wide_mul(const TnK& kk, const __bf16* Lx, int n_stages, int lane, float* __restrict__ P) {
+    constexpr int COLS = CT * 32, PLANE = COLS * TX_PM, BUF = 3 * PLANE, ACOLS = PT * 32;
+    constexpr WideDeal D = wide_deal(PT, QT, QE);
+    static_assert(D.ok, "more than TXW_NT tiles for one wave");
+    constexpr int NW = D.n[W];
+    const swr_gemm_tn_args& a = kk.a;
+    const int i = lane & 31, s = lane >> 5;
+    f32x16 acc[NW > 0 ? NW : 1];
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const __bf16* lane_base = Lx + i * TX_PM + 8 * s;
+    __syncthreads();                                                       // stage 0 is in buffer 0
+    for (int sg = 0; sg < n_stages; ++sg) {
+        const __bf16* buf = lane_base + (sg & 1) * BUF;
+        bf16x8 bq[2][3], ap[2][3];
+        // fragments of tile 0, then inside the loop those of tile t + 1 before the products of tile t
+        if constexpr (NW > 0) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ap[0][pl] = *reinterpret_cast<const bf16x8*>(buf + (32 * D.p[W][0]) * TX_PM + pl * PLANE);
+#pragma unroll
+            for (int pl = 0; pl < (D.q[W][0] >= QE ? 1 : 3); ++pl)
+                bq[0][pl] = *reinterpret_cast<const bf16x8*>(buf + (ACOLS + 32 * D.q[W][0]) * TX_PM + pl * PLANE);
+        }
+        int bsel = 0;                                                      // (compile-time after unrolling)
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            const int bcur = bsel;
+            if (t + 1 < NW) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ap[(t + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(buf + (32 * D.p[W][t + 1]) * TX_PM + pl * PLANE);
+                if (D.q[W][t + 1] != D.q[W][t]) {
+                    bsel ^= 1;
+#pragma unroll
+                    for (int pl = 0; pl < (D.q[W][t + 1] >= QE ? 1 : 3); ++pl)
+                        bq[bsel][pl] = *reinterpret_cast<const bf16x8*>(buf + (ACOLS + 32 * D.q[W][t + 1]) * TX_PM + pl * PLANE);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 (&af)[3] = ap[t & 1];
+            bf16x8 (&b)[3] = bq[bcur];
+            f32x16 c_ = acc[t];
+            if (D.q[W][t] < QE) {
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
+            } else {
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
+            }
+            acc[t] = c_;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+        const int q = 32 * D.q[W][t] + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = 32 * D.p[W][t] + (r & 3) + 8 * (r >> 2) + 4 * s;
+            if (p < a.K1 && q < a.K2) P[static_cast<int64_t>(p) * kk.k2p + q] = acc[t][r];
+        }
+    }
+}
+
+template <int CT, int PT, int QT, int QE>
+__global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, const TnGather g) {
+    constexpr int COLS = CT * 32;
+    constexpr int PLANE = COLS * TX_PM, BUF = 3 * PLANE;
+    constexpr int ACOLS = PT * 32, UNITS = ACOLS + QT * 32;            // 2 row octs x (columns / 2)
+    static_assert(UNITS <= COLS && UNITS <= 512, "slab too narrow / more than two units per staging thread");
+    extern __shared__ __attribute__((aligned(16))) __bf16 Lx[];        // [2][3][COLS][TX_PM]
+    const swr_gemm_tn_args& a = kk.a;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int split = blockIdx.x;
+    const int64_t ms = min(static_cast<int64_t>(split) * kk.rows_per_split, a.M);
+    const int64_t me = min(ms + kk.rows_per_split, a.M);
+    const int n_stages = static_cast<int>((me - ms + TX_ROWS - 1) / TX_ROWS);
+    float* __restrict__ P = kk.part + static_cast<int64_t>(split) * a.K1 * kk.k2p;
+
+    if (wave < 4) {                                                      // multiplying waves: one code path each
+        if (wave == 0) wide_mul<CT, PT, QT, QE, 0>(kk, Lx, n_stages, lane, P);
+        else if (wave == 1) wide_mul<CT, PT, QT, QE, 1>(kk, Lx, n_stages, lane, P);
+        else if (wave == 2) wide_mul<CT, PT, QT, QE, 2>(kk, Lx, n_stages, lane, P);
+        else wide_mul<CT, PT, QT, QE, 3>(kk, Lx, n_stages, lane, P);
+        return;
+    }
+    // ====================================================================== staging waves
+    const int tid = threadIdx.x - 256;
+    struct Unit {
+        bool on, col_ok, isA, keyed, is_oh, oh_planes;
+        int ro, scol, gcol, bit;
+        const float* vbase;
+        const uint32_t* kwp;
+        uint32_t vstride, kmax;
+        float cs0, cs1;
+    } un[2];
+    typedef uint32_t kw_t[8];
+    float2 st[2][TXW_DEPTH][8];
+    uint32_t ob[2][TXW_DEPTH];
+    kw_t kw[2][2];                                                        // [unit][stage & 1]: keys / mask words, loaded two steps ahead
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        Unit& U = un[u];
+        const int uid = tid + 256 * u;
+        U.on = uid < UNITS;
+        U.ro = uid & 1;
+        const int cp = U.on ? (uid >> 1) : 0;
+        U.scol = 2 * cp;
+        U.isA = U.scol < ACOLS;
+        U.gcol = U.isA ? U.scol : U.scol - ACOLS;
+        U.col_ok = U.on && (U.isA ? U.gcol < a.K1 : U.gcol < a.K2);
+        // (units that load nothing read harmless addresses: A's first row, and A as "keys" -- M * 4 bytes into it and never used)
+        U.vbase = a.A; U.vstride = 0; U.kmax = 0; U.kwp = reinterpret_cast<const uint32_t*>(a.A);
+        U.keyed = false; U.is_oh = false; U.bit = 0; U.cs0 = 0.f; U.cs1 = 0.f;
+        if (U.isA) {
+            if (U.col_ok) { U.vbase = a.A + U.gcol; U.vstride = static_cast<uint32_t>(a.lda); }
+        } else if (U.col_ok) {
+            const TnGatherPiece Pc = g.piece[min(U.gcol >> 3, g.n_pieces - 1)];
+            const int e = U.gcol & 7;
+            if (Pc.kind == TNG_TABLE) { U.vbase = Pc.vbase + e; U.vstride = Pc.vstride; U.kwp = Pc.kwp; U.kmax = Pc.kmax; U.keyed = true; }
+            else if (Pc.kind == TNG_ROWIDX && e < Pc.n_valid) { U.vbase = Pc.vbase + e; U.vstride = Pc.vstride; }
+            else if (Pc.kind == TNG_ONEHOT) { U.kwp = Pc.kwp; U.keyed = true; U.is_oh = true; U.bit = Pc.bit0 + e; }
+            else U.col_ok = false;
+        }
+        U.oh_planes = U.is_oh && (U.gcol >> 5) < QE;                     // its tile is multiplied with all three planes
+    }
+    const uint32_t m_last = static_cast<uint32_t>(a.M - 1);
+    const int rows_total = static_cast<int>(me - ms);
+    auto kw_load = [&](const Unit& U, int stage, kw_t& dst) {             // unconditional: a fixed number of loads per step
+        const uint4* p = reinterpret_cast<const uint4*>(U.kwp + (static_cast<uint32_t>(ms) + 8u * U.ro + static_cast<uint32_t>(stage) * TX_ROWS));
+        const uint4 x = p[0], y = p[1];
+        dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w; dst[4] = y.x; dst[5] = y.y; dst[6] = y.z; dst[7] = y.w;
+    };
+    auto val_load = [&](const Unit& U, int stage, const kw_t& k8, float2 (&dst)[8], uint32_t& bits) {
+        const uint32_t rbase = static_cast<uint32_t>(ms) + 8u * U.ro + static_cast<uint32_t>(stage) * TX_ROWS;
+        uint32_t b2 = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t idx = U.keyed ? min(k8[r], U.kmax) : min(rbase + r, m_last);
+            dst[r] = *reinterpret_cast<const float2*>(U.vbase + static_cast<uint64_t>(idx) * U.vstride);
+            b2 |= ((k8[r] >> U.bit) & 3u) << (2 * r);
+        }
+        bits = b2;
+    };
+    auto stage_store = [&](Unit& U, int stage, const float2 (&raw)[8], uint32_t bits, __bf16* buf) {
+        if (!U.col_ok) return;
+        const int left = rows_total - stage * TX_ROWS - 8 * U.ro;
+        bf16x8 h0, m0_, l0, h1, m1, l1;
+        __bf16* d = buf + U.scol * TX_PM + 8 * U.ro;
+        if (U.is_oh) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool ok = r < left;
+                h0[r] = static_cast<__bf16>((ok && ((bits >> (2 * r)) & 1u)) ? 1.f : 0.f);
+                h1[r] = static_cast<__bf16>((ok && ((bits >> (2 * r + 1)) & 1u)) ? 1.f : 0.f);
+                m0_[r] = static_cast<__bf16>(0.f); l0[r] = m0_[r]; m1[r] = m0_[r]; l1[r] = m0_[r];
+            }
+            *reinterpret_cast<bf16x8*>(d) = h0;
+            *reinterpret_cast<bf16x8*>(d + TX_PM) = h1;
+            if (U.oh_planes) {
+                *reinterpret_cast<bf16x8*>(d + PLANE) = m0_;
+                *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l0;
+                *reinterpret_cast<bf16x8*>(d + TX_PM + PLANE) = m1;
+                *reinterpret_cast<bf16x8*>(d + TX_PM + 2 * PLANE) = l1;
+            }
+            return;
+        }
+        if (left >= 8) {
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                // (scalar splits: the packed-f32 subtractions of SPLIT3_PAIR run on the matrix pipe's side and cost the partner
+                // wave's MFMAs more than they save here)
+                SPLIT3_INTO(raw[r].x, h0, m0_, l0, r); SPLIT3_INTO(raw[r + 1].x, h0, m0_, l0, r + 1);
+                SPLIT3_INTO(raw[r].y, h1, m1, l1, r); SPLIT3_INTO(raw[r + 1].y, h1, m1, l1, r + 1);
+                U.cs0 += raw[r].x;
+                U.cs1 += raw[r].y;
+                U.cs0 += raw[r + 1].x;
+                U.cs1 += raw[r + 1].y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool ok = r < left;
+                const float vx = ok ? raw[r].x : 0.f, vy = ok ? raw[r].y : 0.f;
+                SPLIT3_INTO(vx, h0, m0_, l0, r);
+                SPLIT3_INTO(vy, h1, m1, l1, r);
+                U.cs0 += vx;
+                U.cs1 += vy;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(d) = h0;
+        *reinterpret_cast<bf16x8*>(d + PLANE) = m0_;
+        *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l0;
+        *reinterpret_cast<bf16x8*>(d + TX_PM) = h1;
+        *reinterpret_cast<bf16x8*>(d + TX_PM + PLANE) = m1;
+        *reinterpret_cast<bf16x8*>(d + TX_PM + 2 * PLANE) = l1;
+    };
+    static_assert(TXW_DEPTH == 3, "ring written for three stages in flight");
+    // prologue: keys of stages 0 .. DEPTH + 1, values of stages 0 .. DEPTH - 1 in flight, stage 0 into buffer 0, stage DEPTH takes its slot
+    {
+        kw_t kp[2][TXW_DEPTH];
+#pragma unroll
+        for (int d = 0; d < TXW_DEPTH; ++d)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) kw_load(un[u], d, kp[u][d]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { kw_load(un[u], TXW_DEPTH, kw[u][TXW_DEPTH & 1]); kw_load(un[u], TXW_DEPTH + 1, kw[u][(TXW_DEPTH + 1) & 1]); }
+#pragma unroll
+        for (int d = 0; d < TXW_DEPTH; ++d)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) val_load(un[u], d, kp[u][d], st[u][d], ob[u][d]);
+    }
+    // slab columns that are never staged (past K1 inside A's tiles, past K2, the tiles past QT): zero in both buffers, once
+    for (int c = tid; c < COLS; c += 256) {
+        const bool isa = c < ACOLS;
+        const int gc = isa ? c : c - ACOLS;
+        bool live = c < UNITS && (isa ? gc < a.K1 : gc < a.K2);
+        if (live && !isa) {
+            const TnGatherPiece Pc = g.piece[min(gc >> 3, g.n_pieces - 1)];
+            live = Pc.kind == TNG_TABLE || Pc.kind == TNG_ONEHOT || (Pc.kind == TNG_ROWIDX && (gc & 7) < Pc.n_valid);
+        }
+        if (!live) {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = static_cast<__bf16>(0.f);
+#pragma unroll
+            for (int bsel = 0; bsel < 2; ++bsel)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    __bf16* d = Lx + bsel * BUF + pl * PLANE + c * TX_PM;
+                    *reinterpret_cast<bf16x8*>(d) = z;
+                    *reinterpret_cast<bf16x8*>(d + 8) = z;
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) stage_store(un[u], 0, st[u][0], ob[u][0], Lx);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) val_load(un[u], TXW_DEPTH, kw[u][TXW_DEPTH & 1], st[u][0], ob[u][0]);
+    __syncthreads();
+    // step sg: stage sg + 1 (slot (sg + 1) % DEPTH) goes to the other buffer; the keys of stage sg + DEPTH + 2 are requested, THEN
+    // the values of stage sg + DEPTH + 1 through the keys requested a step ago
+    auto step = [&](int sg, auto slot_c, auto par_c) {
+        constexpr int NX = decltype(slot_c)::value;                       // (sg + 1) % DEPTH
+        constexpr int KS = decltype(par_c)::value;                        // (sg + DEPTH + 1) & 1
+#if TNW_EXP == 2 || TNW_EXP == 4
+        if (kk.n_tiles == 12345u)
+#endif
+        if (sg + 1 < n_stages) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) stage_store(un[u], sg + 1, st[u][NX], ob[u][NX], Lx + ((sg + 1) & 1) * BUF);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) kw_load(un[u], sg + TXW_DEPTH + 2, kw[u][KS ^ 1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) val_load(un[u], sg + TXW_DEPTH + 1, kw[u][KS], st[u][NX], ob[u][NX]);
+        __syncthreads();
+    };
+    int sg = 0;
+    // (unrolled by 6: three value slots, two key slots; stage sg + DEPTH + 1 = sg + 4 has the parity of sg)
+#define TXW_STEP(OFF) step(sg + OFF, std::integral_constant<int, (OFF + 1) % 3>{}, std::integral_constant<int, OFF & 1>{})
+    for (; sg + 6 <= n_stages; sg += 6) { TXW_STEP(0); TXW_STEP(1); TXW_STEP(2); TXW_STEP(3); TXW_STEP(4); TXW_STEP(5); }
+    if (sg < n_stages) { TXW_STEP(0); }
+    if (sg + 1 < n_stages) { TXW_STEP(1); }
+    if (sg + 2 < n_stages) { TXW_STEP(2); }
+    if (sg + 3 < n_stages) { TXW_STEP(3); }
+    if (sg + 4 < n_stages) { TXW_STEP(4); }
+#undef TXW_STEP
+    if (kk.part_cs) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float c0 = un[u].cs0, c1 = un[u].cs1;
+            c0 += __shfl_xor(c0, 1);
+            c1 += __shfl_xor(c1, 1);
+            if (un[u].col_ok && un[u].isA && un[u].ro == 0) {
+                kk.part_cs[static_cast<int64_t>(split) * a.K1 + un[u].gcol] = c0;
+                kk.part_cs[static_cast<int64_t>(split) * a.K1 + un[u].gcol + 1] = c1;
+            }
+        }
+    }
+}
+
 // fixed-order sum of the per-workgroup partial tiles.  A workgroup owns 256 / L consecutive output elements; thread
 // (sub, o) adds partials sub, sub + L, ... of element o in order (UNROLL loads in flight), so the 64 lanes of a wave read
 // 64 CONSECUTIVE floats of one partial matrix (coalesced; with the L lanes of an element adjacent, as before, every lane
@@ -1451,6 +1795,85 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
     }
 }
 
+// the same fixed-order sum for MANY partial matrices (the wide kernel writes one per CU: 256 x 184 KB at config 2): a thread
+// owns four consecutive outputs (16-byte loads), 16 threads share them and take partials sub, sub + 16, ... (8 loads in
+// flight), their sums are added in sub order through LDS.  tn_reduce_kernel<32> reads 32-byte runs: 27 us for the 47 MB.
+__global__ __launch_bounds__(256) void tn_reduce4_kernel(const TnK kk) {
+    constexpr int SUBS = 16, OUT4 = 256 / SUBS;      // 16 float4 columns = 64 outputs per workgroup
+    __shared__ float4 red[256];
+    const swr_gemm_tn_args& a = kk.a;
+    const int64_t n4 = static_cast<int64_t>(a.K1) * a.K2 / 4;
+    const int64_t np = static_cast<int64_t>(a.K1) * kk.k2p;
+    const int sub = threadIdx.x / OUT4, o = threadIdx.x % OUT4;
+    const int64_t j4 = static_cast<int64_t>(blockIdx.x) * OUT4 + o;
+    const int nparts = (kk.splits + GEMM_WAVES - 1) / GEMM_WAVES;
+    auto lane_sum = [&](const float* __restrict__ p, int64_t stride) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = sub;
+        for (; sp + 7 * SUBS < nparts; sp += 8 * SUBS) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (sp + u * SUBS) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+        }
+        for (; sp < nparts; sp += SUBS) {
+            const float4 v = *reinterpret_cast<const float4*>(p + sp * stride);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        return sum;
+    };
+    auto total = [&]() {
+        float4 t = red[o];
+#pragma unroll
+        for (int q = 1; q < SUBS; ++q) { const float4 v = red[q * OUT4 + o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        return t;
+    };
+    const int64_t j = 4 * j4;
+    const int64_t r = j / a.K2, c = j - r * a.K2;                          // (K2 % 4 == 0: the four outputs share a row)
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j4 < n4) sum = lane_sum(kk.part + r * kk.k2p + c, np);
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (sub == 0 && j4 < n4) {
+        const float4 t = total();
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (a.C2 && c + e >= a.c2_from) {
+                a.C2[r * a.ldc2 + (c + e - a.c2_from)] = tv[e];
+            } else {
+                float* dst = a.C + r * a.ldc + c + e;
+                *dst = a.accumulate ? *dst + tv[e] : tv[e];
+            }
+        }
+    }
+    __syncthreads();
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cs_on = kk.part_cs && j < a.K1;                             // (K1 % 4 == 0)
+    if (cs_on) cs = lane_sum(kk.part_cs + j, a.K1);
+    red[threadIdx.x] = cs;
+    __syncthreads();
+    if (cs_on && sub == 0) {
+        const float4 t = total();
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float* dst = a.colsum + j + e;
+            *dst = a.accumulate ? *dst + tv[e] : tv[e];
+        }
+    }
+}
+static bool tn_reduce4_ok(const TnK& kk) {
+    const swr_gemm_tn_args& a = kk.a;
+    return a.groups == 1 && kk.tail_rep == 0 && a.K2 % 4 == 0 && kk.k2p % 4 == 0 && a.K1 % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(kk.part) & 15u) == 0 && (!kk.part_cs || (reinterpret_cast<uintptr_t>(kk.part_cs) & 15u) == 0);
+}
+static void tn_reduce4(const TnK& kk, hipStream_t st) {
+    const int64_t n4 = static_cast<int64_t>(kk.a.K1) * kk.a.K2 / 4;
+    hipLaunchKernelGGL(tn_reduce4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n4, 16))), dim3(256), 0, st, kk);
+}
+
 static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps) {
     const int tiles1 = static_cast<int>(swr_ceil_div(a.K1, 32));
     const int pblk = static_cast<int>(swr_ceil_div(tiles1, TN_TA_MAX));
@@ -1478,14 +1901,55 @@ static bool tn_x6_tail(const swr_gemm_tn_args& a) {
     const int r = a.K2 % TX_QCOLS;
     return a.K2 > TX_QCOLS && r > 0 && r <= 32;
 }
+// the wide form (gemm_tn_x6w_kernel): every column tile of B in one workgroup's slab
+static bool tn_wide_shape(int pt, int qt);
+static bool tn_wide_ok(const swr_gemm_tn_args& a) {
+    const int pt = static_cast<int>(swr_ceil_div(a.K1, 32)), qt = static_cast<int>(swr_ceil_div(a.K2, 32));
+    return !use_bf16() && tn_wide_enabled() && tn_wide_shape(pt, qt) && a.K2 <= 8 * TNG_MAX_PIECES && a.M >= 256 * TX_ROWS;
+}
 static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
     constexpr int blocks_target = 256;   // one per CU
     const int qblk = tn_x6_tail(a) ? a.K2 / TX_QCOLS : static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
     const int pblk = static_cast<int>(swr_ceil_div(swr_ceil_div(a.K1, 32), TN_TA_MAX));
-    int64_t want = std::max<int64_t>(1, blocks_target / (qblk * pblk));
+    int64_t want = tn_wide_ok(a) ? blocks_target : std::max<int64_t>(1, blocks_target / (qblk * pblk));
     want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (8 * TX_ROWS)));
     rps = swr_ceil_div(swr_ceil_div(a.M, want), TX_ROWS) * TX_ROWS;
     n_splits = static_cast<int>(swr_ceil_div(a.M, rps));
+}
+
+// the instantiated shapes of the wide kernel: (column tiles of A, of A', first all-one-hot tile).  A gathered product whose
+// one-hot columns start later than QE takes the form with the next smaller QE (more six-product tiles than needed: exact).
+#define TNW_SHAPES(X) X(14, 5, 9, 5) X(14, 5, 9, 9)
+static const void* tn_wide_fn(int pt, int qt, int qe_have, unsigned& lds) {
+    const void* best = nullptr;
+    int best_qe = -1;
+#define X(CT, PT, QT, QE)                                                                                                  \
+    if (pt == PT && qt == QT && QE <= qe_have && QE > best_qe) {                                                           \
+        best = reinterpret_cast<const void*>(gemm_tn_x6w_kernel<CT, PT, QT, QE>); best_qe = QE;                            \
+        lds = static_cast<unsigned>(2 * 3 * CT * 32 * TX_PM * sizeof(__bf16));                                             \
+    }
+    TNW_SHAPES(X)
+#undef X
+    return best;
+}
+static bool tn_wide_shape(int pt, int qt) {
+#define X(CT, PT, QT, QE) if (pt == PT && qt == QT) return true;
+    TNW_SHAPES(X)
+#undef X
+    return false;
+}
+
+static int tn_wide_launch(const TnK& kk, const TnGather& g, int n_splits, hipStream_t st) {
+    unsigned lds = 0;
+    const int qt = static_cast<int>(swr_ceil_div(kk.a.K2, 32));
+    const void* fn = tn_wide_fn(static_cast<int>(swr_ceil_div(kk.a.K1, 32)), qt, std::min(qt, g.kp / 32), lds);
+    if (!fn) return SWR_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;
+    TnK k2 = kk;
+    TnGather gg = g;
+    void* kargs[] = {&k2, &gg};
+    if (hipLaunchKernel(fn, dim3(static_cast<unsigned>(n_splits)), dim3(TX_THREADS), kargs, lds, st) != hipSuccess) return SWR_ERR_LAUNCH;
+    return SWR_OK;
 }
 
 extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args);
@@ -1507,7 +1971,8 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     int n_splits;
     tn_x6_plan(a, n_splits, kk.rows_per_split);
     kk.splits = n_splits * GEMM_WAVES;
-    const bool tail = tn_x6_tail(a);
+    const bool wide = tn_wide_ok(a);
+    const bool tail = !wide && tn_x6_tail(a);
     kk.qblk = tail ? static_cast<unsigned>(a.K2 / TX_QCOLS) : static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
     kk.tail_q0 = tail ? static_cast<int>(kk.qblk) * TX_QCOLS : 0;
     kk.tail_rep = tail ? static_cast<int>(kk.qblk) : 0;
@@ -1517,6 +1982,10 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     const int pt_all = static_cast<int>(swr_ceil_div(a.K1, 32));
     kk.pblk = 1;
     kk.n_tiles = kk.qblk * static_cast<unsigned>(n_splits);
+    if (wide) {
+        const int rc = tn_wide_launch(kk, g, n_splits, st);
+        if (rc != SWR_OK) return rc;
+    } else {
     const dim3 grid((kk.n_tiles + 7) / 8 * 8);
     const unsigned lds = static_cast<unsigned>(2 * 3 * (pt_all * 32 + TX_QCOLS + (tail ? 32 : 0)) * TX_PM * sizeof(__bf16));
     const void* fn = nullptr;
@@ -1534,11 +2003,13 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     TnGather gg = g;
     void* kargs[] = {&kk, &gg};
     if (hipLaunchKernel(fn, grid, dim3(TX_THREADS), kargs, lds, st) != hipSuccess) return SWR_ERR_LAUNCH;
+    }
     const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
     const dim3 rblock(256);
 #define TN_RED(LV)                                                                                                      \
     hipLaunchKernelGGL(tn_reduce_kernel<LV>, dim3(static_cast<unsigned>(swr_ceil_div(n * LV, 256)), 1u), rblock, 0, st, kk)
-    if (n_splits > 128) TN_RED(32);
+    if (wide && tn_reduce4_ok(kk)) tn_reduce4(kk, st);
+    else if (n_splits > 128) TN_RED(32);
     else if (n_splits > 64) TN_RED(8);
     else TN_RED(4);
 #undef TN_RED
@@ -1554,7 +2025,7 @@ extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args) {
     else
         tn_plan(*args, ta, splits, rps);
     size_t k2p = args->K2;
-    if (tn_x6_ok(*args) && tn_x6_tail(*args)) k2p = static_cast<size_t>(args->K2 / TX_QCOLS) * (TX_QCOLS + 32);
+    if (tn_x6_ok(*args) && tn_x6_tail(*args) && !tn_wide_ok(*args)) k2p = static_cast<size_t>(args->K2 / TX_QCOLS) * (TX_QCOLS + 32);
     return static_cast<size_t>(args->groups) * splits * (static_cast<size_t>(args->K1) * k2p + args->K1) * 4 + 256;
 }
 
@@ -1591,7 +2062,8 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         int n_splits;
         tn_x6_plan(a, n_splits, kk.rows_per_split);
         kk.splits = n_splits * GEMM_WAVES;                      // tn_reduce_kernel counts partial tiles as splits / 4
-        const bool tail = tn_x6_tail(a);
+        const bool wide = tn_wide_ok(a);
+        const bool tail = !wide && tn_x6_tail(a);
         kk.qblk = tail ? static_cast<unsigned>(a.K2 / TX_QCOLS) : static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
         kk.tail_q0 = tail ? static_cast<int>(kk.qblk) * TX_QCOLS : 0;
         kk.tail_rep = tail ? static_cast<int>(kk.qblk) : 0;
@@ -1602,6 +2074,20 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
         kk.pblk = static_cast<unsigned>(swr_ceil_div(pt_all, TN_TA_MAX));          // A column blocks of <= 5 tiles
         kk.n_tiles = kk.qblk * kk.pblk * static_cast<unsigned>(n_splits);
         const int pt = static_cast<int>(swr_ceil_div(pt_all, kk.pblk));
+        if (wide) {
+            // B as plain 8-column pieces of the gathered form: the same kernel, plan and summation order as the fused lookup's
+            // product (tests/test_ops_gpu.py compares the two bit for bit)
+            TnGather g;
+            g.n_pieces = static_cast<int>(swr_ceil_div(a.K2, 8));
+            g.kp = 32 * 16;                                           // no one-hot columns
+            for (int c = 0; c < g.n_pieces; ++c) {
+                TnGatherPiece& P = g.piece[c];
+                P.vbase = a.B + 8 * c; P.kwp = nullptr; P.vstride = static_cast<uint32_t>(a.ldb); P.kmax = 0;
+                P.kind = TNG_ROWIDX; P.bit0 = 0; P.n_valid = static_cast<int16_t>(std::min<int64_t>(8, a.K2 - 8 * c)); P.pad = 0;
+            }
+            const int rc = tn_wide_launch(kk, g, n_splits, st);
+            if (rc != SWR_OK) return rc;
+        } else {
         const dim3 grid((kk.n_tiles + 7) / 8 * 8);
         const unsigned lds = static_cast<unsigned>(2 * 3 * (pt * 32 + TX_QCOLS + (tail ? 32 : 0)) * TX_PM * sizeof(__bf16));
         const void* fn = nullptr;
@@ -1620,11 +2106,13 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
             return SWR_ERR_LAUNCH;
         void* kargs[] = {&kk};
         if (hipLaunchKernel(fn, grid, dim3(TX_THREADS), kargs, lds, st) != hipSuccess) return SWR_ERR_LAUNCH;
+        }
         const int64_t n = static_cast<int64_t>(a.K1) * a.K2;
         const dim3 rblock(256);
 #define TN_RED(LV)                                                                                                      \
     hipLaunchKernelGGL(tn_reduce_kernel<LV>, dim3(static_cast<unsigned>(swr_ceil_div(n * LV, 256)), 1u), rblock, 0, st, kk)
-        if (n_splits > 128) TN_RED(32);
+        if (wide && tn_reduce4_ok(kk)) tn_reduce4(kk, st);
+        else if (n_splits > 128) TN_RED(32);
         else if (n_splits > 64) TN_RED(8);
         else TN_RED(4);
 #undef TN_RED

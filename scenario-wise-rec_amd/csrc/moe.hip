@@ -973,6 +973,16 @@ extern "C" int swr_spin_us(int us, void* stream) {
     return swr_launch_status();
 }
 
+// Schedule instrument (SWR_STAMPS, ops._stamp): one lane writes the 100 MHz wall clock where its stream has got to.  A kernel
+// trace under rocprofv3 intercepts the queues and moves the branches of a replayed graph against each other; this does not.
+__global__ void swr_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int swr_stamp(unsigned long long* slot, void* stream) {
+    SWR_REQUIRE(slot != nullptr, SWR_ERR_ARG);
+    hipLaunchKernelGGL(swr_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
+    return swr_launch_status();
+}
+
 extern "C" int swr_abi_version(void) { return SWR_ABI_VERSION; }
 
 extern "C" const char* swr_status_str(int status) {

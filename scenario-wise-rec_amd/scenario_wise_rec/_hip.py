@@ -200,6 +200,7 @@ _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _SIGS = {
     "swr_abi_version": (C.c_int, []),
     "swr_spin_us": (C.c_int, [C.c_int, _P]),
+    "swr_stamp": (C.c_int, [_P, _P]),
     "swr_zero": (C.c_int, [_P, _Z, _P]),
     "swr_status_str": (C.c_char_p, [_I]),
     "swr_device_available": (C.c_int, []),

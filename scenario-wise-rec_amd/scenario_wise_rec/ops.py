@@ -190,6 +190,30 @@ def set_skew(seed):
     _SKEW["seed"], _SKEW["n"] = (None if seed is None else int(seed)), 0
 
 
+# ---- schedule stamps (measurement aid): SWR_STAMPS=all or a comma list of point names.  `_stamp(name)` enqueues a one-lane kernel
+# on the CURRENT stream that writes the device wall clock; `read_stamps()` -> {name: us since the earliest stamp} of the last pass.
+_STAMPS = {"on": os.environ.get("SWR_STAMPS", ""), "buf": None, "slot": {}}
+
+
+def _stamp(name):
+    want = _STAMPS["on"]
+    if not want or (want != "all" and name not in want.split(",")):
+        return
+    if _STAMPS["buf"] is None:
+        _STAMPS["buf"] = torch.zeros(64, dtype=torch.int64, device="cuda")
+    slot = _STAMPS["slot"].setdefault(name, len(_STAMPS["slot"]))
+    H.check(lib.swr_stamp(_STAMPS["buf"].data_ptr() + 8 * slot, H.stream()), "swr_stamp")
+
+
+def read_stamps():
+    if _STAMPS["buf"] is None:
+        return {}
+    v = _STAMPS["buf"].cpu().tolist()
+    t = {n: v[i] for n, i in _STAMPS["slot"].items() if v[i]}
+    t0 = min(t.values()) if t else 0
+    return {n: (x - t0) / 100.0 for n, x in sorted(t.items(), key=lambda kv: kv[1])}
+
+
 def _skew(point):
     if _SKEW["seed"] is None:
         return
@@ -348,8 +372,11 @@ def _fork_dw(dev, fn, keep):
     st.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(st):
         _skew(3)
+        _stamp("d_begin")
         fn()
+        _stamp("d_dw_end")
         _run_dw_riders()
+        _stamp("d_end")
     _skew(4)
     _dw["pending"] += 1
     _side["keep"].append(keep)
@@ -360,6 +387,7 @@ def _fork_dw(dev, fn, keep):
 
 def _join_side():
     _side["queued"] = False
+    _stamp("m_autograd_end")
     _run_dw_riders()              # (no weight-gradient branch was forked in this backward: they run here)
     join_side_streams()
 
@@ -450,6 +478,7 @@ FOLD = os.environ.get("SWR_FOLD", "1") != "0"       # the lookup writes [E_big |
 # fused lookup + first layer (csrc/first_layer.hip): the lookup writes NOTHING but keys / one-hot bits / piece offsets; the
 # consuming layer's products fetch table rows through the keys ("0": the folded layout is written as before)
 FUSED_LOOKUP = os.environ.get("SWR_FUSED_LOOKUP", "1") != "0"
+_SORT_DELAY_US = int(os.environ.get("SWR_SORT_DELAY_US", "0"))   # measurement aid: is the forward-time sort on the step's critical path?
 
 
 class OneHotInfo(object):
@@ -693,10 +722,15 @@ class EmbedGather(Function):
                     # would otherwise wait for LAST (measured: 30 us of join stall at config 2 with the jobs behind the sort)
                     # (the sort on a branch of its own -- so that nothing that joins the one-shot jobs queues behind it -- was
                     # measured: 0.487 vs 0.463 ms per step, the runtime then starts it in the middle of the backward pass)
+                    _stamp("s_begin")
                     _fork_extras()
+                    _stamp("s_extras_end")
+                    if _SORT_DELAY_US:
+                        H.check(lib.swr_spin_us(_SORT_DELAY_US, H.stream()), "swr_spin_us")
                     box["ws"] = torch.empty(box["nbytes"], dtype=torch.uint8, device=dev)
                     H.check(lib.swr_embed_bwd_sort(proto, n, H.ptr(keys), B, H.ptr(box["ws"]), box["nbytes"], H.stream()),
                             "swr_embed_bwd_sort")
+                    _stamp("s_sort_end")
                 _defer_side(dev, sort_now)
                 ctx.presorted = box
         return out[:, :plan.width] if plan.width != plan.ld else out
@@ -768,6 +802,7 @@ class EmbedGather(Function):
             raise H.SwrError("swr_embed_bwd: unsupported lookup shape (more than 40 lookup slots)")
         if ctx.presorted is not None and ctx.presorted["nbytes"] == nbytes:
             join_side_streams(dw=False)                               # the sort forked in forward() (no-op if joined)
+            _stamp("m_embed_bwd_begin")
             ws = ctx.presorted["ws"]
             all_direct = all(g is None or isinstance(g, tuple) for g in grads)      # dense gradients go to the arena
             if _late["on"] and sparse_out and all_direct:
@@ -1182,6 +1217,7 @@ class LinearBNAct(Function):
                     H.check(lib.swr_bn_bwd_dx(C.byref(oh.fl["plan"]), H.ptr(oh.fl["ws"]), H.ptr(dYb), dYb.stride(0), H.ptr(Z), ldp,
                                               H.ptr(ca_), H.ptr(cb_), H.ptr(cc_), H.ptr(mean), oh.n_sel, H.ptr(dZ), ldp, H.ptr(dsel),
                                               lds_, H.stream()), "swr_bn_bwd_dx")
+                    _stamp("m_dx_end")
                     if _side["deferred"]:
                         _flush_deferred()
                 else:
@@ -1383,7 +1419,10 @@ def _tower_backward(ctx, saved, dV=None, sel=None):
         gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
                 ldc=K)
     if direct_w and SIDE_STREAM and not _late["on"] and _in_backward():
-        _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
+        if TOWER_DW_SIDE:
+            _on_side_stream(dev, launch_dw1, (dZ1, x, dW1, db1))
+        else:
+            _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
     elif direct_w and _late["on"]:
         # split backward (data-parallel step): nothing but the optimizer reads it -- with the other weight-gradient work,
         # behind the row lists (it sat on the critical path in front of the expert level's backward: 25 us at config 2)
@@ -1494,6 +1533,7 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
 
 
 TOWER_SELECT = os.environ.get("SWR_TOWER_SELECT", "1") != "0"
+TOWER_DW_SIDE = os.environ.get("SWR_TOWER_DW_SIDE", "0") != "0"
 
 
 def tower_head_select(x, W1s, b1s, bn, w2s, b2s, domain):

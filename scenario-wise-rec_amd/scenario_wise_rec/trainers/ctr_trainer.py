@@ -117,6 +117,7 @@ class CTRTrainer(object):
         """forward -> criterion -> zero_grad -> backward (`ctr_trainer.py:69-72`); returns the loss tensor."""
         # zero_grad rides the forward pass's side-stream fork (its fill is pure launch latency on the main stream);
         # if the model forks nothing it runs right after the forward, where the reference has it
+        ops._stamp("m_begin")
         ops.add_side_job(self.model.zero_grad)
         if isinstance(self.criterion, BCELoss):
             # the model's final domain select and the criterion in one launch when the model output IS the selected
@@ -130,9 +131,12 @@ class CTRTrainer(object):
             y_pred = self.model(x_dict)
             loss = self.criterion(y_pred, y)
         ops.run_side_jobs()          # zero_grad, unless the fork already ran it
+        ops._stamp("m_fwd_end")
         ops.join_side_extras()       # zero_grad / W^T copies forked during the forward pass: needed from the first backward
         loss.backward(gradient=self._one(loss))     # kernel on; the sort behind them is joined by the embedding backward
+        ops._stamp("m_bwd_end")
         ops.join_side_streams()      # (no-op unless no embedding backward ran: nothing forked outlives the step)
+        ops._stamp("m_joined")
         return loss
 
     def train_step(self, x_dict, y):
@@ -149,6 +153,7 @@ class CTRTrainer(object):
             ops.add_side_job(self.optimizer.advance_early, backward_needs=False)      # the step-counter launch leaves the critical path too
         loss = self.forward_backward(x_dict, y)
         self.optimizer.step()
+        ops._stamp("m_end")
         return loss
 
     def _one(self, loss):
