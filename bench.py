@@ -439,7 +439,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
     bf16 MFMA products (3-way operand split, fp32 accumulate: the 1e-4 logit bar rules plain bf16 out; three for the
     bf16-exact one-hot columns), so the matrix pipes issue up to 6 x the executed flops: `mfma_issue_util`.  `hbm_frac`
     prices the launch's executed bytes against the 8 TB/s HBM peak.
-    Primary entry = the longest kernel of the step, the weight-gradient product (`gemm_tn_x6g_kernel` + its fixed-order
+    Primary entry = the longest kernel of the step, the weight-gradient product (`gemm_tn_x6w_kernel` + its fixed-order
     partial-tile reduction).  Timed live with HIP events on the launch stream over graph-captured launches; four
     operand sets are rotated.  With SWR_FUSED_LOOKUP=0 (or SWR_GEMM != default) the written-block launches are timed
     instead (`gemm_tn_x6_kernel`, `gemm_rows_x6_kernel`, `embed_gather_kernel`)."""
@@ -553,10 +553,14 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         # gradient = the dZ row (read once per 128-column block), keys / mask words, 4 B per real column of A'
         nr = info.Kp // 16
         fwd_bytes = float(B) * (nr * 8 + 16 + 2 * nr * 48 + 4 * n1)
-        n_qblk = max(1, kf // 128)
+        # the wide kernel (one workgroup stages dZ and every column of A') where its shape is instantiated and SWR_TN_WIDE != 0,
+        # else the blocked one (dZ read once per 128-column block of A')
+        wide = os.environ.get("SWR_TN_WIDE", "1") != "0" and (n1 + 31) // 32 == 5 and (kf + 31) // 32 == 9
+        n_qblk = 1 if wide else max(1, kf // 128)
         dw_bytes = float(B) * (n_qblk * 4 * n1 + 4 * info.Kp + 4 * (info.Kp // 16) + 16)
-        roof = entry("gemm_tn_x6g_kernel (+tn_reduce_kernel): dWp = dZ^T A', A' gathered through the row keys", f_tn,
-                     "void gemm_tn_x6g_kernel<", kf, alg_flops, k3=k_half, nbytes=dw_bytes)
+        dw_name = "gemm_tn_x6w_kernel" if wide else "gemm_tn_x6g_kernel"
+        roof = entry(dw_name + " (+tn_reduce): dWp = dZ^T A', A' gathered through the row keys", f_tn,
+                     "void %s<" % dw_name, kf, alg_flops, k3=k_half, nbytes=dw_bytes)
         fwd_ent = entry("fl_fwd_kernel (forward Z = A' Wf^T, lookup fused as the A-operand producer, BN partials in the epilogue)", f_fwd,
                         "void fl_fwd_kernel<", kf, alg_flops, k3=k_half, nbytes=fwd_bytes)
     else:

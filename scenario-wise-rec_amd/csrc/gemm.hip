@@ -1142,7 +1142,9 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, c
     bool col_ok = unit_on && (isA ? gcol < a.K1 : gcol < a.K2);
     const float* __restrict__ vbase = a.A;      // (a harmless address for the units that load nothing)
     uint32_t vstride = 0, kmax = 0;
-    const uint32_t* __restrict__ kwp = g.piece[0].kwp;
+    // (units without keys read A as "keys": M * 4 bytes into it and never used -- the key loads are unconditional so that every
+    // step issues a fixed number of loads and the waits are counted; with `if (keyed)` hipcc waited for vmcnt(0) every stage)
+    const uint32_t* __restrict__ kwp = reinterpret_cast<const uint32_t*>(a.A);
     bool keyed = false, is_oh = false;
     int bit = 0;
     if (isA) {
@@ -1167,11 +1169,9 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, c
     const uint32_t row0 = static_cast<uint32_t>(ms) + 8u * ro;
     auto kw_load = [&](int stage, kw_t& dst) {
         // 8 consecutive rows' words (read past row M - 1 at the very end: still inside the workspace, see TnGatherPiece)
-        if (keyed) {
-            const uint4* p = reinterpret_cast<const uint4*>(kwp + (row0 + static_cast<uint32_t>(stage) * TX_ROWS));
-            const uint4 x = p[0], y = p[1];
-            dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w; dst[4] = y.x; dst[5] = y.y; dst[6] = y.z; dst[7] = y.w;
-        }
+        const uint4* p = reinterpret_cast<const uint4*>(kwp + (row0 + static_cast<uint32_t>(stage) * TX_ROWS));
+        const uint4 x = p[0], y = p[1];
+        dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w; dst[4] = y.x; dst[5] = y.y; dst[6] = y.z; dst[7] = y.w;
     };
     auto val_load = [&](int stage, const kw_t& k8, float2 (&dst)[8], uint32_t& bits) {
         const uint32_t rbase = row0 + static_cast<uint32_t>(stage) * TX_ROWS;
@@ -1694,9 +1694,6 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
     auto step = [&](int sg, auto slot_c, auto par_c) {
         constexpr int NX = decltype(slot_c)::value;                       // (sg + 1) % DEPTH
         constexpr int KS = decltype(par_c)::value;                        // (sg + DEPTH + 1) & 1
-#if TNW_EXP == 2 || TNW_EXP == 4
-        if (kk.n_tiles == 12345u)
-#endif
         if (sg + 1 < n_stages) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) stage_store(un[u], sg + 1, st[u][NX], ob[u][NX], Lx + ((sg + 1) & 1) * BUF);
