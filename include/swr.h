@@ -527,6 +527,13 @@ int swr_tower_fwd_linear(const swr_tower_args* args_host, void* stream);
 int swr_tower_fwd_head(const swr_tower_args* args_host, void* stream);
 size_t swr_tower_bwd_workspace_bytes(int64_t M, int G, int H);
 int swr_tower_bwd(const swr_tower_args* args_host, void* workspace, size_t workspace_bytes, void* stream);
+/* First-layer weight gradients of the G towers in one pass: dW1 [G][H][K] (+)= dZ1_g^T X_g, db1 [G][H] (+)= column sums of dZ1
+ * (the `towers` of mmoe.py:38-41, the autograd of their first nn.Linear) -- replaces the grouped swr_gemm_tn on (dZ1, X).
+ * dZ1 [M][ldz >= G*H], X [M][ldx >= G*K], 16-byte aligned rows; db1 may be NULL; workspace: swr_tower_dw_workspace_bytes. */
+int swr_tower_dw_supported(int K, int H, int G);
+size_t swr_tower_dw_workspace_bytes(int64_t M, int K, int H, int G);
+int swr_tower_dw(const float* dZ1, int64_t ldz, const float* X, int64_t ldx, int64_t M, int K, int H, int G, float* dW1, float* db1,
+                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------- domain select + loss ------
  * final = 0; for d: final = where(domain_id == d, y_d, final)

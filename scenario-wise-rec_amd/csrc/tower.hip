@@ -422,6 +422,177 @@ static bool tower_shape_ok(int K, int H) {
     return (K == 8 || K == 16 || K == 32) && (H == 4 || H == 8 || H == 16 || H == 32);   // K = 64 would need > 64 KB of LDS
 }
 
+// ---------------------------------------------------------------------------- backward, first-layer weights
+// dW1_g = dZ1_g^T X_g, db1_g = column sums of dZ1_g for all G towers in ONE pass over dZ1 and X (63 MB at the KuaiRand shape): the
+// generic grouped weight-gradient product (gemm_tn_kernel<1> + its reduce, 24 + 5 us) multiplies 5 slivers of 16 x 32 outputs
+// through a kernel built for wide outputs.  Here a workgroup walks 64-row tiles (coalesced 16-byte loads into LDS, the next
+// tile's loads in flight in registers), wave w owns rows 16 w .. 16 w + 15 of every tile and keeps all G * H/16 * K/16 output
+// tiles (+ the column sums, as a product with ones) in v_mfma_f32_16x16x4_f32 accumulators: exact fp32 products.  The four
+// waves' sums are added in a fixed tree, the workgroups' partials by tower_dw_reduce_kernel in a fixed order: deterministic.
+#define TDW_ROWS 64
+template <int K, int H, int G>
+__global__ __launch_bounds__(TW_THREADS) void tower_dw_kernel(const float* __restrict__ dZ1, int64_t ldz, const float* __restrict__ X,
+                                                              int64_t ldx, int64_t M, float* __restrict__ part) {
+    constexpr int WX = G * K, WZ = G * H, PX = WX + 4, PZ = WZ + 4;
+    constexpr int QX = WX / 4, QZ = WZ / 4;                        // 16-byte pieces per row
+    constexpr int NX = (TDW_ROWS * QX + TW_THREADS - 1) / TW_THREADS, NZ = (TDW_ROWS * QZ + TW_THREADS - 1) / TW_THREADS;
+    constexpr int CT = H / 16, KT = K / 16;
+    constexpr int OUT = G * H * K + G * H;                         // floats of one partial: dW1 [G][H][K], then db1 [G][H]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lx = lds;                                               // [64][PX]
+    float* lz = lds + TDW_ROWS * PX;                               // [64][PZ]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int64_t n_tiles = (M + TDW_ROWS - 1) / TDW_ROWS;
+    f32x4 acc[G][CT][KT], accb[G][CT];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            accb[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[g][ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    float4 rx[NX], rz[NZ];
+    auto tile_fetch = [&](int64_t tile) {                           // rows past the end: zeros (they add nothing)
+        const int64_t m0 = tile * TDW_ROWS;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int idx = threadIdx.x + u * TW_THREADS, r = idx / QX, c = idx - r * QX;
+            rx[u] = (idx < TDW_ROWS * QX && m0 + r < M) ? *reinterpret_cast<const float4*>(X + (m0 + r) * ldx + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int idx = threadIdx.x + u * TW_THREADS, r = idx / QZ, c = idx - r * QZ;
+            rz[u] = (idx < TDW_ROWS * QZ && m0 + r < M) ? *reinterpret_cast<const float4*>(dZ1 + (m0 + r) * ldz + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto tile_put = [&]() {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int idx = threadIdx.x + u * TW_THREADS, r = idx / QX, c = idx - r * QX;
+            if (idx < TDW_ROWS * QX) *reinterpret_cast<float4*>(lx + r * PX + 4 * c) = rx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int idx = threadIdx.x + u * TW_THREADS, r = idx / QZ, c = idx - r * QZ;
+            if (idx < TDW_ROWS * QZ) *reinterpret_cast<float4*>(lz + r * PZ + 4 * c) = rz[u];
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) tile_fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                            // the previous tile's fragments have been read
+        tile_put();
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) tile_fetch(tile + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int r = 16 * wave + 4 * ks + kq;                  // this lane's row (k index) of the step
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float bf[KT];
+#pragma unroll
+                for (int t = 0; t < KT; ++t) bf[t] = lx[r * PX + g * K + 16 * t + n];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float af = lz[r * PZ + g * H + 16 * ct + n];
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) acc[g][ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[t], acc[g][ct][t], 0, 0, 0);
+                    accb[g][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, 1.f, accb[g][ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- the four waves' tiles -> one partial per workgroup: ((w0 + w1) + (w2 + w3)) through LDS
+    __syncthreads();
+    float* red = lds;                                               // [4][OUT]
+    static_assert(4 * OUT <= TDW_ROWS * (PX + PZ), "reduction buffer larger than the tiles");
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)          // D[row 4 kq + r][column n]: dW1[g][16 ct + 4 kq + r][16 t + n]
+                    red[wave * OUT + (g * H + 16 * ct + 4 * kq + r) * K + 16 * t + n] = acc[g][ct][t][r];
+            if (n == 0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * OUT + G * H * K + g * H + 16 * ct + 4 * kq + r] = accb[g][ct][r];
+        }
+    __syncthreads();
+    float* P = part + static_cast<int64_t>(blockIdx.x) * OUT;
+    for (int j = threadIdx.x; j < OUT; j += TW_THREADS) P[j] = (red[j] + red[OUT + j]) + (red[2 * OUT + j] + red[3 * OUT + j]);
+}
+
+// out[j] (+)= sum over the workgroups' partials, in order: 16 threads share four consecutive outputs and take partials sub, sub + 16,
+// ...; their sums are added in sub order through LDS
+__global__ __launch_bounds__(256) void tower_dw_reduce_kernel(const float* __restrict__ part, int n_part, int out, int n_w, float* dW1,
+                                                              float* db1, int accumulate) {
+    __shared__ float4 red[256];
+    const int sub = threadIdx.x / 16, o = threadIdx.x % 16;
+    const int j = 4 * (blockIdx.x * 16 + o);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < out) {
+        int sp = sub;
+        for (; sp + 3 * 16 < n_part; sp += 4 * 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + static_cast<int64_t>(sp + 16 * u) * out + j);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+        }
+        for (; sp < n_part; sp += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(part + static_cast<int64_t>(sp) * out + j);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (sub != 0 || j >= out) return;
+    float4 t = red[o];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) { const float4 v = red[q * 16 + o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float* dst = j + e < n_w ? dW1 + j + e : db1 + (j + e - n_w);
+        if (j + e < n_w || db1) *dst = accumulate ? *dst + tv[e] : tv[e];
+    }
+}
+
+static int tower_dw_blocks(int64_t M) { return static_cast<int>(std::min<int64_t>(512, (M + TDW_ROWS - 1) / TDW_ROWS)); }
+extern "C" int swr_tower_dw_supported(int K, int H, int G) { return (K == 32 && H == 16 && G >= 1 && G <= 6) ? 1 : 0; }
+extern "C" size_t swr_tower_dw_workspace_bytes(int64_t M, int K, int H, int G) {
+    if (!swr_tower_dw_supported(K, H, G) || M <= 0) return 0;
+    return static_cast<size_t>(tower_dw_blocks(M)) * (static_cast<size_t>(G) * H * K + G * H) * sizeof(float) + 256;
+}
+extern "C" int swr_tower_dw(const float* dZ1, int64_t ldz, const float* X, int64_t ldx, int64_t M, int K, int H, int G, float* dW1,
+                            float* db1, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    SWR_REQUIRE(dZ1 && X && dW1 && M > 0 && ldz >= G * H && ldx >= G * K, SWR_ERR_ARG);
+    SWR_REQUIRE(swr_tower_dw_supported(K, H, G), SWR_ERR_UNSUPPORTED);
+    SWR_REQUIRE(ldz % 4 == 0 && ldx % 4 == 0 && swr_aligned16(dZ1) && swr_aligned16(X), SWR_ERR_ALIGN);
+    SWR_REQUIRE(workspace && workspace_bytes >= swr_tower_dw_workspace_bytes(M, K, H, G) && swr_aligned16(workspace), SWR_ERR_WORKSPACE);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = tower_dw_blocks(M);
+    float* part = static_cast<float*>(workspace);
+    const int out = G * H * K + G * H;
+#define TDW(GV)                                                                                                            \
+    case GV: {                                                                                                             \
+        const size_t lds = static_cast<size_t>(TDW_ROWS) * (GV * 32 + 4 + GV * 16 + 4) * sizeof(float);                    \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dw_kernel<32, 16, GV>),             \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)   \
+            return SWR_ERR_LAUNCH;                                                                                         \
+        hipLaunchKernelGGL((tower_dw_kernel<32, 16, GV>), dim3(nb), dim3(TW_THREADS), lds, st, dZ1, ldz, X, ldx, M, part); \
+        break;                                                                                                             \
+    }
+    switch (G) { TDW(1) TDW(2) TDW(3) TDW(4) TDW(5) TDW(6) default: return SWR_ERR_UNSUPPORTED; }
+#undef TDW
+    hipLaunchKernelGGL(tower_dw_reduce_kernel, dim3((out / 4 + 15) / 16), dim3(256), 0, st, part, nb, out, G * H * K, dW1, db1, accumulate);
+    return swr_launch_status();
+}
+
 extern "C" int swr_tower_supported(int K, int H) { return tower_shape_ok(K, H) ? 1 : 0; }
 
 #define TW_DISPATCH_KH(FN, K, H, ...)                                   \

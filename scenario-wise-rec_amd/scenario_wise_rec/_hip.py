@@ -201,6 +201,9 @@ _SIGS = {
     "swr_abi_version": (C.c_int, []),
     "swr_spin_us": (C.c_int, [C.c_int, _P]),
     "swr_stamp": (C.c_int, [_P, _P]),
+    "swr_tower_dw_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "swr_tower_dw_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "swr_tower_dw": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "swr_zero": (C.c_int, [_P, _Z, _P]),
     "swr_status_str": (C.c_char_p, [_I]),
     "swr_device_available": (C.c_int, []),

@@ -374,6 +374,8 @@ def _fork_dw(dev, fn, keep):
         _skew(3)
         _stamp("d_begin")
         fn()
+        if _DELAY_DW_US:
+            H.check(lib.swr_spin_us(_DELAY_DW_US, H.stream()), "swr_spin_us")
         _stamp("d_dw_end")
         _run_dw_riders()
         _stamp("d_end")
@@ -478,6 +480,8 @@ FOLD = os.environ.get("SWR_FOLD", "1") != "0"       # the lookup writes [E_big |
 # fused lookup + first layer (csrc/first_layer.hip): the lookup writes NOTHING but keys / one-hot bits / piece offsets; the
 # consuming layer's products fetch table rows through the keys ("0": the folded layout is written as before)
 FUSED_LOOKUP = os.environ.get("SWR_FUSED_LOOKUP", "1") != "0"
+_DELAY_DW_US = int(os.environ.get("SWR_DELAY_DW_US", "0"))         # measurement aids: which branch behind dX is the critical one?
+_DELAY_EMBED_US = int(os.environ.get("SWR_DELAY_EMBED_US", "0"))
 _SORT_DELAY_US = int(os.environ.get("SWR_SORT_DELAY_US", "0"))   # measurement aid: is the forward-time sort on the step's critical path?
 
 
@@ -803,6 +807,8 @@ class EmbedGather(Function):
         if ctx.presorted is not None and ctx.presorted["nbytes"] == nbytes:
             join_side_streams(dw=False)                               # the sort forked in forward() (no-op if joined)
             _stamp("m_embed_bwd_begin")
+            if _DELAY_EMBED_US:
+                H.check(lib.swr_spin_us(_DELAY_EMBED_US, H.stream()), "swr_spin_us")
             ws = ctx.presorted["ws"]
             all_direct = all(g is None or isinstance(g, tuple) for g in grads)      # dense gradients go to the arena
             if _late["on"] and sparse_out and all_direct:
@@ -1415,14 +1421,20 @@ def _tower_backward(ctx, saved, dV=None, sel=None):
     if not direct_w:
         dW1 = torch.empty((N, K), dtype=torch.float32, device=dev)
         db1 = torch.empty(N, dtype=torch.float32, device=dev)
+    # one pass over dZ1 and x for all towers (csrc/tower.hip tower_dw_kernel) where the shape is built, else the grouped product
+    one_pass = (TOWER_DW and lib.swr_tower_dw_supported(K, Hd, G) and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0 and dW1.is_contiguous() and db1.is_contiguous())
     def launch_dw1():
+        if one_pass:
+            nb = lib.swr_tower_dw_workspace_bytes(M, K, Hd, G)
+            wsd = torch.empty(nb, dtype=torch.uint8, device=dev)
+            H.check(lib.swr_tower_dw(H.ptr(dZ1), N, H.ptr(x), x.stride(0), M, K, Hd, G, H.ptr(dW1), H.ptr(db1), int(direct_w),
+                                     H.ptr(wsd), nb, H.stream()), "swr_tower_dw")
+            return
         gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
                 ldc=K)
     if direct_w and SIDE_STREAM and not _late["on"] and _in_backward():
-        if TOWER_DW_SIDE:
-            _on_side_stream(dev, launch_dw1, (dZ1, x, dW1, db1))
-        else:
-            _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
+        _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
     elif direct_w and _late["on"]:
         # split backward (data-parallel step): nothing but the optimizer reads it -- with the other weight-gradient work,
         # behind the row lists (it sat on the critical path in front of the expert level's backward: 25 us at config 2)
@@ -1533,7 +1545,7 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
 
 
 TOWER_SELECT = os.environ.get("SWR_TOWER_SELECT", "1") != "0"
-TOWER_DW_SIDE = os.environ.get("SWR_TOWER_DW_SIDE", "0") != "0"
+TOWER_DW = os.environ.get("SWR_TOWER_DW", "1") != "0"         # the towers' first-layer weight gradients in one pass (swr_tower_dw)
 
 
 def tower_head_select(x, W1s, b1s, bn, w2s, b2s, domain):

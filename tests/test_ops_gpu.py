@@ -1390,3 +1390,36 @@ def test_fused_lookup_step_against_the_oracle():
         else:
             got = grads[k]
         np.testing.assert_allclose(got, g, rtol=0, atol=2e-4 * max(1e-6, float(np.abs(g).max())) + 3e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("M,G", [(1000, 5), (64, 1), (4099, 3), (65536, 5), (33000, 6)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_tower_weight_gradients_in_one_pass(M, G, accumulate):
+    """swr_tower_dw (csrc/tower.hip): dW1_g = dZ1_g^T X_g and db1_g = column sums of dZ1_g for all towers in one pass, against
+    fp64 torch; twice the same bits (fixed-order partial sums); rows that do not fill the last 64-row tile."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec._hip import lib
+    K, Hd = 32, 16
+    assert lib.swr_tower_dw_supported(K, Hd, G) == 1 and lib.swr_tower_dw_supported(8, 4, G) == 0
+    g = torch.Generator(device="cuda").manual_seed(M + G)
+    dZ = torch.randn(M, G * Hd, device="cuda", generator=g)
+    xw = torch.randn(M, G * K + 8, device="cuda", generator=g)
+    x = xw[:, :G * K]                                          # a view with a row pitch of its own
+    init_w = torch.randn(G * Hd, K, device="cuda", generator=g)
+    init_b = torch.randn(G * Hd, device="cuda", generator=g)
+    nb = lib.swr_tower_dw_workspace_bytes(M, K, Hd, G)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        dW, db = init_w.clone(), init_b.clone()
+        H.check(lib.swr_tower_dw(H.ptr(dZ), dZ.stride(0), H.ptr(x), x.stride(0), M, K, Hd, G, H.ptr(dW), H.ptr(db), accumulate,
+                                 H.ptr(ws), nb, H.stream()), "swr_tower_dw")
+        outs.append((dW, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref_w = torch.stack([dZ[:, t * Hd:(t + 1) * Hd].double().t() @ x[:, t * K:(t + 1) * K].double() for t in range(G)]).reshape(G * Hd, K)
+    ref_b = dZ.double().sum(0)
+    if accumulate:
+        ref_w, ref_b = ref_w + init_w.double(), ref_b + init_b.double()
+    scale = float(M) ** 0.5
+    torch.testing.assert_close(outs[0][0].double(), ref_w, rtol=0, atol=2e-6 * scale * 4)
+    torch.testing.assert_close(outs[0][1].double(), ref_b, rtol=0, atol=2e-6 * scale * 4)
