@@ -161,6 +161,13 @@ int swr_fold_first_layer_fwd(const float* W, int64_t ldw, int N, int K, int Kp, 
 int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const float* dbp /* nullable */, int N, int K, int Kp, int ohw,
                              const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables_host,
                              int n_tables, float* dW, int64_t lddw, float* db /* nullable */, int accumulate, void* stream);
+/* swr_fold_first_layer_bwd and swr_onehot_table_grads(S = dWp, ...) in ONE launch: both read the reduced dWp and nothing of each
+ * other.  `tables` carry the table VALUES (the unfolding multiplies with them), `grad_tables` the gradient destinations with
+ * oh_off counted from column 0 of dWp (Kp + the table's offset in the one-hot block); W [N][ldw] is the layer's weight. */
+int swr_fold_first_layer_bwd_tables(const float* dWp, int64_t lddwp, const float* dbp, int N, int K, int Kp, int ohw,
+                                    const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables, int n_tables,
+                                    float* dW, int64_t lddw, float* db, int accumulate, const float* W, int64_t ldw,
+                                    const swr_onehot_table* grad_tables, int n_grad_tables, void* stream);
 
 /* ---- fused lookup + first layer ("fl"; training; no reference counterpart: `embedding -> Linear`,
  * basic/layers.py:64-105 + 253-258, with the lookup as the A-operand producer of the layer's products).  The [B, K0]

@@ -275,8 +275,8 @@ struct OhtK {
 // one output element per 16 consecutive lanes: lane j of the group takes n = j, j + 16, ... (independent loads in flight,
 // fused multiply-adds in ascending n), then a fixed butterfly over the 16 partials -- deterministic
 #define OHT_LANES 16
-__global__ __launch_bounds__(GATHER_THREADS) void onehot_table_grads_kernel(const OhtK k) {
-    const int gidx = (blockIdx.x * GATHER_THREADS + threadIdx.x) / OHT_LANES;
+__device__ __forceinline__ void onehot_table_grads_body(const OhtK& k, unsigned block) {
+    const int gidx = (block * GATHER_THREADS + threadIdx.x) / OHT_LANES;
     const int j0 = threadIdx.x % OHT_LANES;
     const int total = k.first[k.n_tables];
     const bool live = gidx < total;
@@ -296,6 +296,22 @@ __global__ __launch_bounds__(GATHER_THREADS) void onehot_table_grads_kernel(cons
         float* dst = T.grad + static_cast<int64_t>(v) * T.dim + e;
         *dst = k.accumulate ? *dst + acc : acc;
     }
+}
+__global__ __launch_bounds__(GATHER_THREADS) void onehot_table_grads_kernel(const OhtK k) { onehot_table_grads_body(k, blockIdx.x); }
+
+static int oht_fill(OhtK& k, const float* S, int64_t lds, const float* W, int64_t ldw, int N, const swr_onehot_table* tables, int n_tables,
+                    int accumulate) {
+    k.n_tables = n_tables; k.N = N; k.accumulate = accumulate; k.S = S; k.lds = lds; k.W = W; k.ldw = ldw;
+    int pos = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        const swr_onehot_table& T = tables[t];
+        SWR_REQUIRE(T.grad && T.vocab > 0 && T.dim > 0 && T.oh_off >= 0 && T.w_col >= 0, SWR_ERR_ARG);
+        k.tab[t] = T;
+        k.first[t] = pos;
+        pos += T.vocab * T.dim;
+    }
+    k.first[n_tables] = pos;
+    return SWR_OK;
 }
 
 extern "C" int swr_onehot_table_grads(const float* S, int64_t lds, const float* W, int64_t ldw, int N,
@@ -384,8 +400,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void fold_fwd_kernel(const FoldK k,
 
 // dW[n, c] (+)= dWp[n, inv_col[c]]  or, for a column of small table t,  sum_v dWp[n, Kp + off_t + v] emb_t[v, c - col_t];
 // db (+)= dbp
-__global__ __launch_bounds__(GATHER_THREADS) void fold_bwd_kernel(const FoldK k) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x;
+__device__ __forceinline__ void fold_bwd_body(const FoldK& k, unsigned block) {
+    const int64_t i = static_cast<int64_t>(block) * GATHER_THREADS + threadIdx.x;
     if (i < k.N && k.db && k.dbp) k.db[i] = k.accumulate ? k.db[i] + k.dbp[i] : k.dbp[i];
     if (i >= static_cast<int64_t>(k.N) * k.K) return;
     const int n = static_cast<int>(i / k.K), c = static_cast<int>(i - static_cast<int64_t>(n) * k.K);
@@ -401,6 +417,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void fold_bwd_kernel(const FoldK k)
     }
     float* dst = k.dW + n * k.lddw + c;
     *dst = k.accumulate ? *dst + v : v;
+}
+__global__ __launch_bounds__(GATHER_THREADS) void fold_bwd_kernel(const FoldK k) { fold_bwd_body(k, blockIdx.x); }
+// the unfolding and the small tables' gradients read the same reduced dWp and nothing of each other: one launch, the first
+// `nb_fold` workgroups unfold
+__global__ __launch_bounds__(GATHER_THREADS) void fold_bwd_tables_kernel(const FoldK k, const OhtK o, unsigned nb_fold) {
+    if (blockIdx.x < nb_fold) fold_bwd_body(k, blockIdx.x);
+    else onehot_table_grads_body(o, blockIdx.x - nb_fold);
 }
 
 static int fold_fill(FoldK& k, const swr_onehot_table* tables, int n_tables, int N, int K, int Kp, int ohw, const int32_t* src_col,
@@ -445,5 +468,24 @@ extern "C" int swr_fold_first_layer_bwd(const float* dWp, int64_t lddwp, const f
     const int64_t total = static_cast<int64_t>(N) * K;
     hipLaunchKernelGGL(fold_bwd_kernel, dim3(static_cast<unsigned>(swr_ceil_div(total, GATHER_THREADS))), dim3(GATHER_THREADS), 0,
                        static_cast<hipStream_t>(stream), k);
+    return swr_launch_status();
+}
+
+extern "C" int swr_fold_first_layer_bwd_tables(const float* dWp, int64_t lddwp, const float* dbp, int N, int K, int Kp, int ohw,
+                                               const int32_t* src_col, const int32_t* inv_col, const swr_onehot_table* tables,
+                                               int n_tables, float* dW, int64_t lddw, float* db, int accumulate, const float* W,
+                                               int64_t ldw, const swr_onehot_table* grad_tables, int n_grad_tables, void* stream) {
+    FoldK k;
+    int rc = fold_fill(k, tables, n_tables, N, K, Kp, ohw, src_col, inv_col, nullptr, 0);
+    if (rc != SWR_OK) return rc;
+    SWR_REQUIRE(dWp && dW && W && grad_tables && lddwp >= Kp + ohw && lddw >= K && ldw > 0 && n_grad_tables > 0 && n_grad_tables <= OHT_MAX,
+                SWR_ERR_ARG);
+    k.dWp = dWp; k.lddwp = lddwp; k.dbp = dbp; k.dW = dW; k.lddw = lddw; k.db = db; k.accumulate = accumulate;
+    OhtK o;
+    rc = oht_fill(o, dWp, lddwp, W, ldw, N, grad_tables, n_grad_tables, accumulate);
+    if (rc != SWR_OK) return rc;
+    const unsigned nb_fold = static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(N) * K, GATHER_THREADS));
+    const unsigned nb_oh = static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(o.first[n_grad_tables]) * OHT_LANES, GATHER_THREADS));
+    hipLaunchKernelGGL(fold_bwd_tables_kernel, dim3(nb_fold + nb_oh), dim3(GATHER_THREADS), 0, static_cast<hipStream_t>(stream), k, o, nb_fold);
     return swr_launch_status();
 }

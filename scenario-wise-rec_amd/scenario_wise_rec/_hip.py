@@ -211,6 +211,7 @@ _SIGS = {
     "swr_embed_gather_fwd_onehot": (C.c_int, [_P, _I, _P, _I, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P]),
     "swr_fold_first_layer_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P]),
     "swr_fold_first_layer_bwd": (C.c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P, _I, _P]),
+    "swr_fold_first_layer_bwd_tables": (C.c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P, _I, _P]),
     "swr_onehot_table_grads": (C.c_int, [_P, _L, _P, _L, _I, _P, _I, _I, _P]),
     "swr_fl_layout": (C.c_int, [_P, _P]),
     "swr_fl_workspace_bytes": (_Z, [_P]),

@@ -1180,6 +1180,12 @@ class LinearBNAct(Function):
                 for j, ((p_t, vocab, dim, off, col), (g_t, *_r)) in enumerate(zip(oh.tables_p, oh.tables)):
                     tw[j] = H.OnehotTable(p_t.data_ptr(), vocab, dim, off, col)
                     tg[j] = H.OnehotTable(g_t.data_ptr(), vocab, dim, oh.Kp + off, col)
+                if FOLD_BWD_ONE_LAUNCH and 0 < len(oh.tables) <= 64:
+                    H.check(lib.swr_fold_first_layer_bwd_tables(H.ptr(dWp), Kf, H.ptr(dbp), Ntot, K, oh.Kp, oh.oh_width, H.ptr(oh.src),
+                                                                H.ptr(oh.inv), tw, len(oh.tables_p), H.ptr(dW), K, H.ptr(db), 1,
+                                                                H.ptr(W), W.stride(0), tg, len(oh.tables), H.stream()),
+                            "swr_fold_first_layer_bwd_tables")
+                    return
                 H.check(lib.swr_fold_first_layer_bwd(H.ptr(dWp), Kf, H.ptr(dbp), Ntot, K, oh.Kp, oh.oh_width, H.ptr(oh.src),
                                                      H.ptr(oh.inv), tw, len(oh.tables_p), H.ptr(dW), K, H.ptr(db), 1, H.stream()),
                         "swr_fold_first_layer_bwd")
@@ -1545,6 +1551,7 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
 
 
 TOWER_SELECT = os.environ.get("SWR_TOWER_SELECT", "1") != "0"
+FOLD_BWD_ONE_LAUNCH = os.environ.get("SWR_FOLD_BWD_ONE_LAUNCH", "1") != "0"   # unfolding of dWp + the small tables' gradients in one launch
 TOWER_DW = os.environ.get("SWR_TOWER_DW", "1") != "0"         # the towers' first-layer weight gradients in one pass (swr_tower_dw)
 
 
