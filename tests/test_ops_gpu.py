@@ -265,7 +265,11 @@ def test_embedding_backward_mfma_flags_non_finite_gradients_without_spreading_th
 
 @pytest.mark.parametrize("M,N,K", [(250, 148, 516), (64, 1, 16), (1000, 33, 7), (31, 300, 52), (4096, 256, 376),
                                    (5003, 148, 516), (4100, 64, 36), (8192, 20, 132), (4500, 96, 288), (5000, 300, 132), (4200, 512, 64), (4100, 2048, 36),
-                                   (6000, 160, 300)])     # tn on the bf16-split kernel (516, 132, 288: ragged last tile folded into the full blocks)
+                                   (6000, 160, 300),
+                                   # tn through the WIDE kernel (5 x 9 tiles of 32): whole, ragged rows + columns, a K not a multiple of 4
+                                   # (the 16-byte reduce does not apply), more rows than one stage ring per split
+                                   (4096, 160, 288), (5003, 148, 288), (70000, 160, 264), (4133, 130, 258)])
+# (tn on the bf16-split kernel -- 516, 132, 288: ragged last tile folded into the full blocks)
 def test_gemm_forms(M, N, K):
     """nt / nn / tn on the f32 MFMA pipe against fp64 matmul: exact-fp32 fma chains, so the error is
     fp32 summation roundoff, bounded here by 2e-6 * sum|a||b| per output."""
