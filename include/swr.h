@@ -235,6 +235,7 @@ int swr_fl_fwd(const swr_fl_plan* plan_host, const void* workspace, const float*
  * fragment of the product dX[B, n_out] = dZ W[:, sel] (weights: the B3X image swr_fl_prep wrote for `sel`) and written out
  * for the weight-gradient product.  K = plan->N <= 160, n_out = n_sel <= 160. */
 int swr_bn_bwd_dx_supported(int K, int n_out);
+/* (dZ may be NULL: nothing is written -- for a weight-gradient product that recomputes it, swr_fl_dw_bn) */
 int swr_bn_bwd_dx(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dY, int64_t lddy, const float* Z, int64_t ldz,
                   const float* ca, const float* cb, const float* cc, const float* mean, int n_out,
                   float* dZ, int64_t lddz, float* dX, int64_t lddx, void* stream);
@@ -242,6 +243,14 @@ int swr_fl_dw_supported(const swr_fl_plan* plan_host, int64_t lddz);
 size_t swr_fl_dw_workspace_bytes(const swr_fl_plan* plan_host);
 int swr_fl_dw(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,
               float* colsum /* nullable */, void* workspace, size_t workspace_bytes, void* stream);
+/* swr_fl_dw with dZ RECOMPUTED while it is staged: dZ[b, n] = ca[n] dY[b, n] + cb[n] (Z[b, n] - mean[n]) + cc[n], the BatchNorm
+ * backward of swr_act_bwd_apply / swr_bn_bwd_dx in its operation order (`layers.py:254-256` under autograd): together with
+ * swr_bn_bwd_dx(dZ = NULL) the [B, N] gradient of the pre-activations is never written or read back.  Supported where the wide
+ * weight-gradient kernel takes the product (swr_fl_dw_bn_supported); same workspace as swr_fl_dw. */
+int swr_fl_dw_bn_supported(const swr_fl_plan* plan_host, int64_t lddy, int64_t ldz);
+int swr_fl_dw_bn(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dY, int64_t lddy, const float* Z, int64_t ldz,
+                 const float* ca, const float* cb, const float* cc, const float* mean, float* dWp, int64_t lddwp, float* colsum,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K3 ----
  * Backward of the lookup: replaces aten::embedding_dense_backward (32 calls

@@ -898,8 +898,9 @@ extern "C" size_t swr_fl_dw_workspace_bytes(const swr_fl_plan* plan) {
     return swr_gemm_tn_workspace_bytes(&a);
 }
 
-extern "C" int swr_fl_dw(const swr_fl_plan* plan, const void* fl_workspace, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,
-                         float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+struct FlDwBn { const float* Z; int64_t ldz; const float* ca; const float* cb; const float* cc; const float* mean; };
+static int fl_dw_launch(const swr_fl_plan* plan, const void* fl_workspace, const float* dZ, int64_t lddz, const FlDwBn* bn, float* dWp,
+                        int64_t lddwp, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
     FlHost h;
     int rc = fl_build(plan, h);
     if (rc != SWR_OK) return rc;
@@ -943,7 +944,32 @@ extern "C" int swr_fl_dw(const swr_fl_plan* plan, const void* fl_workspace, cons
         P.kwp = mask_t + static_cast<int64_t>((8 * o8) / 32) * plan->B;
         P.bit0 = static_cast<int16_t>((8 * o8) % 32);
     }
+    if (bn) {
+        SWR_REQUIRE(bn->Z && bn->ca && bn->cb && bn->cc && bn->mean && tn_x6_gather_wide(a, g.kp), SWR_ERR_UNSUPPORTED);
+        g.a_z = bn->Z; g.a_ldz = bn->ldz; g.a_ca = bn->ca; g.a_cb = bn->cb; g.a_cc = bn->cc; g.a_mean = bn->mean;
+    }
     return tn_x6_gather(a, g, workspace, workspace_bytes, stream);
+}
+
+extern "C" int swr_fl_dw(const swr_fl_plan* plan, const void* fl_workspace, const float* dZ, int64_t lddz, float* dWp, int64_t lddwp,
+                         float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+    return fl_dw_launch(plan, fl_workspace, dZ, lddz, nullptr, dWp, lddwp, colsum, workspace, workspace_bytes, stream);
+}
+
+// the same product with dZ = ca dY + cb (Z - mean) + cc recomputed by the staging threads (the operations of swr_bn_bwd_dx, in
+// their order): dZ is never written -- swr_bn_bwd_dx(dZ = NULL) then moves 122 MB instead of 164
+extern "C" int swr_fl_dw_bn_supported(const swr_fl_plan* plan, int64_t lddy, int64_t ldz) {
+    FlHost h;
+    if (!plan || fl_build(plan, h) != SWR_OK || plan->N < 1 || lddy < plan->N || ldz < plan->N || lddy % 2 || ldz % 2) return 0;
+    swr_gemm_tn_args a;
+    fl_dw_args(plan, h, reinterpret_cast<const float*>(256), lddy, reinterpret_cast<float*>(256), 16 * h.NR + plan->oh_width, nullptr, a);
+    return (tn_x6_gather_wide(a, 16 * h.NR) && plan->B * ldz < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int swr_fl_dw_bn(const swr_fl_plan* plan, const void* fl_workspace, const float* dY, int64_t lddy, const float* Z, int64_t ldz,
+                            const float* ca, const float* cb, const float* cc, const float* mean, float* dWp, int64_t lddwp, float* colsum,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    const FlDwBn bn = {Z, ldz, ca, cb, cc, mean};
+    return fl_dw_launch(plan, fl_workspace, dY, lddy, &bn, dWp, lddwp, colsum, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward + dX
@@ -1049,7 +1075,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
     __syncthreads();                     // (the coefficients too)
     __builtin_amdgcn_sched_barrier(0);
 
-    float* __restrict__ dzrow = k.dZ + row * k.lddz;
+    float* __restrict__ dzrow = k.dZ ? k.dZ + row * k.lddz : nullptr;      // null: the weight-gradient product recomputes dZ (swr_fl_dw_bn)
     // dZ of the lane's 8 columns of group g (the operations of act_bwd_apply_v4_kernel, bn.hip, in its order), written out,
     // and its three bf16 terms
     auto make_frag = [&](int g, const fl_u32x4 (&raw)[4], bf16x8& ah, bf16x8& am, bf16x8& al) {
@@ -1066,7 +1092,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
             q4.z = fmaf(b4.z, z.z - mu.z, q4.z) + c4.z; q4.w = fmaf(b4.w, z.w - mu.w, q4.w) + c4.w;
             const bool ok = 16 * g + 8 * s + 4 * hh < K;          // (only the last group can be cut)
             if (!ok) q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && row_ok) *reinterpret_cast<float4*>(dzrow + 16 * g + 8 * s + 4 * hh) = q4;
+            if (ok && row_ok && dzrow) *reinterpret_cast<float4*>(dzrow + 16 * g + 8 * s + 4 * hh) = q4;
             v[4 * hh] = q4.x; v[4 * hh + 1] = q4.y; v[4 * hh + 2] = q4.z; v[4 * hh + 3] = q4.w;
         }
         fl_split8(v, ah, am, al);
@@ -1154,9 +1180,9 @@ extern "C" int swr_bn_bwd_dx(const swr_fl_plan* plan, const void* fl_workspace, 
     int rc = fl_build(plan, h);
     if (rc != SWR_OK) return rc;
     const int K = plan->N;
-    SWR_REQUIRE(fl_workspace && dY && Z && ca && cb && cc && mean && dZ && dX, SWR_ERR_ARG);
-    SWR_REQUIRE(swr_bn_bwd_dx_supported(K, n_out) && lddy >= K && ldz >= K && lddz >= K && lddx >= n_out, SWR_ERR_UNSUPPORTED);
-    SWR_REQUIRE(lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 && swr_aligned16(dY) && swr_aligned16(Z) && swr_aligned16(dZ) &&
+    SWR_REQUIRE(fl_workspace && dY && Z && ca && cb && cc && mean && dX, SWR_ERR_ARG);      // dZ may be NULL (swr.h)
+    SWR_REQUIRE(swr_bn_bwd_dx_supported(K, n_out) && lddy >= K && ldz >= K && (!dZ || lddz >= K) && lddx >= n_out, SWR_ERR_UNSUPPORTED);
+    SWR_REQUIRE(lddy % 4 == 0 && ldz % 4 == 0 && (!dZ || (lddz % 4 == 0 && swr_aligned16(dZ))) && swr_aligned16(dY) && swr_aligned16(Z) &&
                     plan->B * lddy * 4 < (1ll << 32) && plan->B * ldz * 4 < (1ll << 32), SWR_ERR_ALIGN);
     if (plan->B == 0) return SWR_OK;
     FlDxK k;

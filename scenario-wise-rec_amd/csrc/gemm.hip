@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, c
 // key loads hipcc waits for vmcnt(0) -- a full memory round trip per 16-row stage, which is what bounds gemm_tn_x6g_kernel
 // (removing its MFMAs, splits or loads alone gains 12 / 4 / 7 of 63 us).
 #define TXW_NT 12                        // output tiles per multiplying wave
-#define TXW_DEPTH 3                      // stages in flight in the staging waves' registers
+#define TXW_DEPTH 2                      // stages in flight in the staging waves' registers
 struct WideDeal {
     int n[4];
     int p[4][TXW_NT + 4], q[4][TXW_NT + 4];
@@ -1545,6 +1545,11 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
         uint32_t vstride, kmax;
         float cs0, cs1;
     } un[2];
+    // unit 0 of an A column pair when A is recomputed (TnGather.a_z): Z's column pair and the pair's coefficients
+    const bool bnA = g.a_z != nullptr;
+    const float* zbase = a.A;
+    float2 qa = {0.f, 0.f}, qb = {0.f, 0.f}, qc = {0.f, 0.f}, qm = {0.f, 0.f};
+    float2 sz[TXW_DEPTH][8];
     typedef uint32_t kw_t[8];
     float2 st[2][TXW_DEPTH][8];
     uint32_t ob[2][TXW_DEPTH];
@@ -1565,6 +1570,11 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
         U.keyed = false; U.is_oh = false; U.bit = 0; U.cs0 = 0.f; U.cs1 = 0.f;
         if (U.isA) {
             if (U.col_ok) { U.vbase = a.A + U.gcol; U.vstride = static_cast<uint32_t>(a.lda); }
+            if (U.col_ok && bnA && u == 0) {
+                zbase = g.a_z + U.gcol;
+                qa = *reinterpret_cast<const float2*>(g.a_ca + U.gcol); qb = *reinterpret_cast<const float2*>(g.a_cb + U.gcol);
+                qc = *reinterpret_cast<const float2*>(g.a_cc + U.gcol); qm = *reinterpret_cast<const float2*>(g.a_mean + U.gcol);
+            }
         } else if (U.col_ok) {
             const TnGatherPiece Pc = g.piece[min(U.gcol >> 3, g.n_pieces - 1)];
             const int e = U.gcol & 7;
@@ -1592,6 +1602,20 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
             b2 |= ((k8[r] >> U.bit) & 3u) << (2 * r);
         }
         bits = b2;
+    };
+    const uint32_t zstride = bnA && un[0].isA && un[0].col_ok ? static_cast<uint32_t>(g.a_ldz) : 0u;
+    auto z_load = [&](int stage, float2 (&dst)[8]) {                    // unit 0's rows of Z (a harmless address when A is A)
+        const uint32_t rbase = static_cast<uint32_t>(ms) + 8u * un[0].ro + static_cast<uint32_t>(stage) * TX_ROWS;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r] = *reinterpret_cast<const float2*>(zbase + static_cast<uint64_t>(min(rbase + r, m_last)) * zstride);
+    };
+    // dZ of a column pair from dY and Z: the operations of act_bwd_apply_v4_kernel (bn.hip) / fl_dx_kernel in their order
+    auto bn_apply = [&](float2 (&raw)[8], const float2 (&z)[8]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            raw[r].x = fmaf(qb.x, z[r].x - qm.x, raw[r].x * qa.x) + qc.x;
+            raw[r].y = fmaf(qb.y, z[r].y - qm.y, raw[r].y * qa.y) + qc.y;
+        }
     };
     auto stage_store = [&](Unit& U, int stage, const float2 (&raw)[8], uint32_t bits, __bf16* buf) {
         if (!U.col_ok) return;
@@ -1646,7 +1670,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
         *reinterpret_cast<bf16x8*>(d + TX_PM + PLANE) = m1;
         *reinterpret_cast<bf16x8*>(d + TX_PM + 2 * PLANE) = l1;
     };
-    static_assert(TXW_DEPTH == 3, "ring written for three stages in flight");
+    static_assert(TXW_DEPTH == 2 || TXW_DEPTH == 3, "step sequence written for two or three stages in flight");
     // prologue: keys of stages 0 .. DEPTH + 1, values of stages 0 .. DEPTH - 1 in flight, stage 0 into buffer 0, stage DEPTH takes its slot
     {
         kw_t kp[2][TXW_DEPTH];
@@ -1657,10 +1681,13 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
 #pragma unroll
         for (int u = 0; u < 2; ++u) { kw_load(un[u], TXW_DEPTH, kw[u][TXW_DEPTH & 1]); kw_load(un[u], TXW_DEPTH + 1, kw[u][(TXW_DEPTH + 1) & 1]); }
 #pragma unroll
-        for (int d = 0; d < TXW_DEPTH; ++d)
+        for (int d = 0; d < TXW_DEPTH; ++d) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) val_load(un[u], d, kp[u][d], st[u][d], ob[u][d]);
+            z_load(d, sz[d]);
+        }
     }
+    const bool applyA = bnA && un[0].isA && un[0].col_ok;
     // slab columns that are never staged (past K1 inside A's tiles, past K2, the tiles past QT): zero in both buffers, once
     for (int c = tid; c < COLS; c += 256) {
         const bool isa = c < ACOLS;
@@ -1684,10 +1711,12 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
                 }
         }
     }
+    if (applyA) bn_apply(st[0][0], sz[0]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) stage_store(un[u], 0, st[u][0], ob[u][0], Lx);
 #pragma unroll
     for (int u = 0; u < 2; ++u) val_load(un[u], TXW_DEPTH, kw[u][TXW_DEPTH & 1], st[u][0], ob[u][0]);
+    z_load(TXW_DEPTH, sz[0]);
     __syncthreads();
     // step sg: stage sg + 1 (slot (sg + 1) % DEPTH) goes to the other buffer; the keys of stage sg + DEPTH + 2 are requested, THEN
     // the values of stage sg + DEPTH + 1 through the keys requested a step ago
@@ -1695,6 +1724,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
         constexpr int NX = decltype(slot_c)::value;                       // (sg + 1) % DEPTH
         constexpr int KS = decltype(par_c)::value;                        // (sg + DEPTH + 1) & 1
         if (sg + 1 < n_stages) {
+            if (applyA) bn_apply(st[0][NX], sz[NX]);
 #pragma unroll
             for (int u = 0; u < 2; ++u) stage_store(un[u], sg + 1, st[u][NX], ob[u][NX], Lx + ((sg + 1) & 1) * BUF);
         }
@@ -1702,11 +1732,12 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6w_kernel(const TnK kk, c
         for (int u = 0; u < 2; ++u) kw_load(un[u], sg + TXW_DEPTH + 2, kw[u][KS ^ 1]);
 #pragma unroll
         for (int u = 0; u < 2; ++u) val_load(un[u], sg + TXW_DEPTH + 1, kw[u][KS], st[u][NX], ob[u][NX]);
+        z_load(sg + TXW_DEPTH + 1, sz[NX]);
         __syncthreads();
     };
     int sg = 0;
-    // (unrolled by 6: three value slots, two key slots; stage sg + DEPTH + 1 = sg + 4 has the parity of sg)
-#define TXW_STEP(OFF) step(sg + OFF, std::integral_constant<int, (OFF + 1) % 3>{}, std::integral_constant<int, OFF & 1>{})
+    // (unrolled by 6 = lcm(value slots, key slots); the key slot is the parity of stage sg + DEPTH + 1)
+#define TXW_STEP(OFF) step(sg + OFF, std::integral_constant<int, (OFF + 1) % TXW_DEPTH>{}, std::integral_constant<int, (OFF + TXW_DEPTH + 1) & 1>{})
     for (; sg + 6 <= n_stages; sg += 6) { TXW_STEP(0); TXW_STEP(1); TXW_STEP(2); TXW_STEP(3); TXW_STEP(4); TXW_STEP(5); }
     if (sg < n_stages) { TXW_STEP(0); }
     if (sg + 1 < n_stages) { TXW_STEP(1); }
@@ -1956,8 +1987,16 @@ bool tn_x6_gather_ok(const swr_gemm_tn_args& a) {
            (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0 && a.M >= 4096 && a.M * a.lda < (1ll << 31) && !a.C2 && a.K2 <= 8 * TNG_MAX_PIECES;
 }
 
+bool tn_x6_gather_wide(const swr_gemm_tn_args& a, int kp) {
+    unsigned lds = 0;
+    const int qt = static_cast<int>(swr_ceil_div(a.K2, 32));
+    return tn_x6_gather_ok(a) && tn_wide_ok(a) && tn_wide_fn(static_cast<int>(swr_ceil_div(a.K1, 32)), qt, std::min(qt, kp / 32), lds) != nullptr;
+}
+
 int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, size_t workspace_bytes, void* stream) {
     SWR_REQUIRE(tn_x6_gather_ok(a) && a.A && a.C && a.lda >= a.K1 && a.ldc >= a.K2 && g.n_pieces * 8 >= a.K2 && g.kp % 16 == 0, SWR_ERR_ARG);
+    SWR_REQUIRE(g.a_z == nullptr || (tn_x6_gather_wide(a, g.kp) && g.a_ca && g.a_cb && g.a_cc && g.a_mean && g.a_ldz >= a.K1 && g.a_ldz % 2 == 0 &&
+                                     (reinterpret_cast<uintptr_t>(g.a_z) & 7u) == 0 && a.M * g.a_ldz < (1ll << 31)), SWR_ERR_UNSUPPORTED);
     swr_gemm_tn_args sized = a;
     sized.B = a.A; sized.ldb = a.K2;                               // (workspace size: B is only looked at for alignment)
     const size_t need = swr_gemm_tn_workspace_bytes(&sized);
@@ -2075,6 +2114,7 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
             // B as plain 8-column pieces of the gathered form: the same kernel, plan and summation order as the fused lookup's
             // product (tests/test_ops_gpu.py compares the two bit for bit)
             TnGather g;
+            g.a_z = nullptr; g.a_ldz = 0; g.a_ca = g.a_cb = g.a_cc = g.a_mean = nullptr;
             g.n_pieces = static_cast<int>(swr_ceil_div(a.K2, 8));
             g.kp = 32 * 16;                                           // no one-hot columns
             for (int c = 0; c < g.n_pieces; ++c) {

@@ -22,8 +22,15 @@ struct TnGather {
     TnGatherPiece piece[TNG_MAX_PIECES];
     int n_pieces;
     int kp;                   // first one-hot column (a multiple of 16)
+    // A recomputed while it is staged (wide kernel only): the product's A pointer is dY and
+    //   A[b, n] = ca[n] dY[b, n] + cb[n] (Z[b, n] - mean[n]) + cc[n]
+    // -- the BatchNorm backward of swr_act_bwd_apply / swr_bn_bwd_dx in its operation order, so dZ is never written.  a_z = null: A is A.
+    const float* a_z;
+    int64_t a_ldz;
+    const float* a_ca; const float* a_cb; const float* a_cc; const float* a_mean;
 };
 
 // a = the product's description with B ignored (K2 = columns of A'); same workspace size as swr_gemm_tn_workspace_bytes
 int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, size_t workspace_bytes, void* stream);
 bool tn_x6_gather_ok(const swr_gemm_tn_args& a);
+bool tn_x6_gather_wide(const swr_gemm_tn_args& a, int kp);      // the wide kernel takes this product (a recomputed A needs it)

@@ -223,6 +223,8 @@ _SIGS = {
     "swr_fl_dw_supported": (C.c_int, [_P, _L]),
     "swr_fl_dw_workspace_bytes": (_Z, [_P]),
     "swr_fl_dw": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _Z, _P]),
+    "swr_fl_dw_bn_supported": (C.c_int, [_P, _L, _L]),
+    "swr_fl_dw_bn": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _Z, _P]),
     "swr_adam_catchup_multi": (C.c_int, [_P, _I, _P, _P, _P]),
     "swr_adam_rows_multi": (C.c_int, [_P, _I, _P, _P]),
     "swr_embed_bag_fwd": (C.c_int, [_P, _L, _I, _P, _I, _L, _I, _I, _I, _L, C.c_uint32, _P, _L, _I, _P, _P, _P, _P]),

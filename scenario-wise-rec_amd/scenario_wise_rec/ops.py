@@ -1157,13 +1157,27 @@ class LinearBNAct(Function):
             raise H.SwrError("folded first layer: the layer's and the small tables' gradients must live in the gradient arena "
                              "(SwrModule.build_arena) and the lookup must take a gradient")
 
+        # dZ of a fused BN-backward + dX launch is read by ONE consumer, the weight-gradient product: where that product can
+        # recompute it from dY and Z while staging (swr_fl_dw_bn) it is never written -- the dX launch moves 122 MB instead of 164
+        dz_free = bool(DZ_FREE and bn_dx is not None and oh is not None and oh.fold and ctx.fl_fused
+                       and lib.swr_fl_dw_supported(C.byref(oh.fl["plan"]), dZ.stride(0))
+                       and lib.swr_fl_dw_bn_supported(C.byref(oh.fl["plan"]), bn_dx[0].stride(0), ldp))
+
         def launch_dw():
             if oh is not None and oh.fold:
                 # dWp = dZ^T [E_big | dense | one-hot]; unfolded into dW / db (arena), the small tables' gradients from S
                 Kf = oh.Kp + oh.oh_width
                 dWp = torch.empty((Ntot, Kf), dtype=torch.float32, device=dev)
                 dbp = torch.empty(Ntot, dtype=torch.float32, device=dev) if cfg["has_bias"] else None
-                if ctx.fl_fused and lib.swr_fl_dw_supported(C.byref(oh.fl["plan"]), dZ.stride(0)):
+                if dz_free:
+                    f = oh.fl
+                    dYb, ca_, cb_, cc_ = bn_dx
+                    nb = lib.swr_fl_dw_workspace_bytes(C.byref(f["plan"]))
+                    wsd = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+                    H.check(lib.swr_fl_dw_bn(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(dYb), dYb.stride(0), H.ptr(Z), ldp, H.ptr(ca_),
+                                             H.ptr(cb_), H.ptr(cc_), H.ptr(mean), H.ptr(dWp), Kf, H.ptr(dbp), H.ptr(wsd), nb, H.stream()),
+                            "swr_fl_dw_bn")
+                elif ctx.fl_fused and lib.swr_fl_dw_supported(C.byref(oh.fl["plan"]), dZ.stride(0)):
                     # the product's staging threads fetch the table rows through the keys: A' is never written
                     f = oh.fl
                     nb = lib.swr_fl_dw_workspace_bytes(C.byref(f["plan"]))
@@ -1227,8 +1241,8 @@ class LinearBNAct(Function):
                 if bn_dx is not None:
                     dYb, ca_, cb_, cc_ = bn_dx
                     H.check(lib.swr_bn_bwd_dx(C.byref(oh.fl["plan"]), H.ptr(oh.fl["ws"]), H.ptr(dYb), dYb.stride(0), H.ptr(Z), ldp,
-                                              H.ptr(ca_), H.ptr(cb_), H.ptr(cc_), H.ptr(mean), oh.n_sel, H.ptr(dZ), ldp, H.ptr(dsel),
-                                              lds_, H.stream()), "swr_bn_bwd_dx")
+                                              H.ptr(ca_), H.ptr(cb_), H.ptr(cc_), H.ptr(mean), oh.n_sel, None if dz_free else H.ptr(dZ), ldp,
+                                              H.ptr(dsel), lds_, H.stream()), "swr_bn_bwd_dx")
                     _stamp("m_dx_end")
                     if _side["deferred"]:
                         _flush_deferred()
@@ -1268,7 +1282,7 @@ class LinearBNAct(Function):
             # with dW; dW then overlaps whatever the main stream does next (the embedding backward, lower layers).
             # (Measured, config 2: forking BEFORE dX instead -- dW next to dX and K3 -- 0.523 vs 0.520 ms: that stretch of
             # the step is throughput-bound, not dependency-bound.)
-            _fork_dw(dev, launch_dw, (dZ, x, dW, db))
+            _fork_dw(dev, launch_dw, (dZ, x, dW, db) + ((tuple(bn_dx) + (Z, mean)) if dz_free else ()))
         if direct_w:
             _mark_touched(p_W + tuple(p_b))
             grads = [None] * (nw * (2 if cfg["has_bias"] else 1))
@@ -1551,6 +1565,7 @@ def tower_head(x, W1s, b1s, bn, w2s, b2s):
 
 
 TOWER_SELECT = os.environ.get("SWR_TOWER_SELECT", "1") != "0"
+DZ_FREE = os.environ.get("SWR_DZ_FREE", "1") != "0"      # dZ recomputed inside the weight-gradient product (swr_fl_dw_bn): never written
 FOLD_BWD_ONE_LAUNCH = os.environ.get("SWR_FOLD_BWD_ONE_LAUNCH", "1") != "0"   # unfolding of dWp + the small tables' gradients in one launch
 TOWER_DW = os.environ.get("SWR_TOWER_DW", "1") != "0"         # the towers' first-layer weight gradients in one pass (swr_tower_dw)
 
