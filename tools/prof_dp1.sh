@@ -11,5 +11,5 @@ rm -rf $O/prof_${T}_dp1
 python -c "
 import json
 for n in ('dp1','n1'):
-    d=json.loads(open('$O/${T}_'+n+'_bench.json').read().strip().splitlines()[-1]); print(n, d['ms_per_step'], d['value'])
+    d=json.loads([l for l in open('$O/${T}_'+n+'_bench.json') if l.startswith('{')][-1]); print(n, d['ms_per_step'], d['value'])
 "
