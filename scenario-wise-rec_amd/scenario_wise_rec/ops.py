@@ -1455,7 +1455,7 @@ def _tower_backward(ctx, saved, dV=None, sel=None):
             return
         gemm_tn(dZ1, x, dW1, M, Hd, K, colsum=db1, accumulate=direct_w, groups=G, gsA=Hd, gsB=K, gsC=Hd * K, gsColsum=Hd,
                 ldc=K)
-    if direct_w and SIDE_STREAM and not _late["on"] and _in_backward():
+    if direct_w and SIDE_STREAM and (not _late["on"] or DP_RIDE) and _in_backward():
         _ride_dw(launch_dw1, (dZ1, x, dW1, db1))
     elif direct_w and _late["on"]:
         # split backward (data-parallel step): nothing but the optimizer reads it -- with the other weight-gradient work,
@@ -1573,6 +1573,7 @@ TOWER_SELECT = os.environ.get("SWR_TOWER_SELECT", "1") != "0"
 RIDERS_FIRST = os.environ.get("SWR_RIDERS_FIRST", "1") != "0"
 DZ_FREE = os.environ.get("SWR_DZ_FREE", "1") != "0"      # dZ recomputed inside the weight-gradient product (swr_fl_dw_bn): never written
 FOLD_BWD_ONE_LAUNCH = os.environ.get("SWR_FOLD_BWD_ONE_LAUNCH", "1") != "0"   # unfolding of dWp + the small tables' gradients in one launch
+DP_RIDE = os.environ.get("SWR_DP_RIDE", "1") != "0"           # split backward: the towers' dW rides the weight-gradient branch too
 TOWER_DW = os.environ.get("SWR_TOWER_DW", "1") != "0"         # the towers' first-layer weight gradients in one pass (swr_tower_dw)
 
 
