@@ -1427,3 +1427,27 @@ def test_tower_weight_gradients_in_one_pass(M, G, accumulate):
     scale = float(M) ** 0.5
     torch.testing.assert_close(outs[0][0].double(), ref_w, rtol=0, atol=2e-6 * scale * 4)
     torch.testing.assert_close(outs[0][1].double(), ref_b, rtol=0, atol=2e-6 * scale * 4)
+
+
+def test_weight_gradient_that_recomputes_dz_is_bitwise_the_written_dz(monkeypatch):
+    """swr_fl_dw_bn + swr_bn_bwd_dx(dZ = NULL) (the wide weight-gradient kernel applies the BatchNorm backward to dY and Z while it
+    stages them; dZ is never written) against the same step with dZ written by the dX launch and read back by swr_fl_dw: every
+    gradient BIT FOR BIT.  Config 2's column layout (160 real + 128 one-hot columns: the shape the wide kernel is built for), a
+    batch that does not fill the last 16-row stage of a split."""
+    from scenario_wise_rec import ops
+    vocabs = [1000, 5000, 8, 2, 3, 2, 8, 8, 7, 7, 3, 8, 51, 1472, 16, 35, 4, 119, 455, 8, 6, 6, 3, 3, 3, 3, 3, 3, 3, 8, 200, 300]
+    B = 32768 + 8
+    monkeypatch.setattr(ops, "DZ_FREE", False)
+    p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 7)
+    monkeypatch.setattr(ops, "DZ_FREE", True)
+    calls = []
+    real = ops.lib.swr_fl_dw_bn
+    monkeypatch.setattr(ops.lib, "swr_fl_dw_bn", lambda *a: (calls.append(1), real(*a))[1])
+    p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 7)
+    assert calls, "the weight-gradient product that recomputes dZ was not taken"
+    assert np.array_equal(p0, p1) and l0 == l1
+    for k in g0:
+        if isinstance(g0[k], tuple):
+            assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]), k
+        else:
+            assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
