@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 4
+#define SWR_ABI_VERSION 5
 
 typedef enum {
     SWR_OK = 0,

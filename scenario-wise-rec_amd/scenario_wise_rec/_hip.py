@@ -29,7 +29,7 @@ def _load():
 
 # the ABI number of include/swr.h these bindings were written against (SWR_ABI_VERSION): argument lists changed between
 # numbers, so a stale or variant libswr.so with another number would take shifted arguments -- refuse it
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 lib = _load()
 lib.swr_abi_version.restype = C.c_int
