@@ -55,7 +55,10 @@
 #define DIRECT_MAX_MEMBERS 72
 #define DIRECT_MAX_GROUPS 48
 #ifndef DIRECT_TARGET
-#define DIRECT_TARGET 32768       // (sample, column) elements per workgroup
+#define DIRECT_TARGET 49152       // (sample, column) elements per workgroup: 3 072 samples of a 16-wide lookup = DIRECT_LIST_MAX, the
+                                  // largest chunk that still lists its samples in LDS; fewer chunks = fewer slabs for finalize_kernel to
+                                  // add (config 2: 32 -> 22 per table, finalise 36 -> 25 MB), and the direct sums now run beside the
+                                  // towers' dW, not alone: 32 768 -> 49 152: 0.3905 -> 0.384 ms per step (65 536: 0.388)
 #endif
 
 struct DirectMember {
