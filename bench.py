@@ -502,8 +502,23 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         wsd = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
 
+        # as the step launches it: where the wide kernel takes the product, dZ is recomputed from dY and Z while it is staged
+        # (swr_fl_dw_bn: rows padded to 128 bytes), else read (swr_fl_dw)
+        n1p = (n1 + 31) // 32 * 32
+        bn_form = bool(ops.DZ_FREE and lib.swr_fl_dw_bn_supported(C.byref(info.fl["plan"]), n1p, n1p))
+        if bn_form:
+            dYs = [torch.nn.functional.pad(dz, (0, n1p - n1)).contiguous() for dz, _a, _i in sets]
+            Zs = [torch.randn(B, n1p, device=dev, generator=g) for _ in sets]
+            cfs = [torch.randn(n1, device=dev, generator=g) * 0.1 for _ in range(4)]
+
         def f_tn():
             dZ, _a, inf = nxt()
+            if bn_form:
+                j = st["i"] % 4
+                H.check(lib.swr_fl_dw_bn(C.byref(inf.fl["plan"]), H.ptr(inf.fl["ws"]), H.ptr(dYs[j]), n1p, H.ptr(Zs[j]), n1p, H.ptr(cfs[0]),
+                                         H.ptr(cfs[1]), H.ptr(cfs[2]), H.ptr(cfs[3]), H.ptr(dW), kf, H.ptr(db), H.ptr(wsd), nb, H.stream()),
+                        "swr_fl_dw_bn")
+                return
             H.check(lib.swr_fl_dw(C.byref(inf.fl["plan"]), H.ptr(inf.fl["ws"]), H.ptr(dZ), n1, H.ptr(dW), kf, H.ptr(db), H.ptr(wsd), nb,
                                   H.stream()), "swr_fl_dw")
 
@@ -557,7 +572,7 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         # else the blocked one (dZ read once per 128-column block of A')
         wide = os.environ.get("SWR_TN_WIDE", "1") != "0" and (n1 + 31) // 32 == 5 and (kf + 31) // 32 == 9
         n_qblk = 1 if wide else max(1, kf // 128)
-        dw_bytes = float(B) * (n_qblk * 4 * n1 + 4 * info.Kp + 4 * (info.Kp // 16) + 16)
+        dw_bytes = float(B) * (n_qblk * 4 * n1 * (2 if (wide and ops.DZ_FREE) else 1) + 4 * info.Kp + 4 * (info.Kp // 16) + 16)
         dw_name = "gemm_tn_x6w_kernel" if wide else "gemm_tn_x6g_kernel"
         roof = entry(dw_name + " (+tn_reduce): dWp = dZ^T A', A' gathered through the row keys", f_tn,
                      "void %s<" % dw_name, kf, alg_flops, k3=k_half, nbytes=dw_bytes)
