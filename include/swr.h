@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 5
+#define SWR_ABI_VERSION 6
 
 typedef enum {
     SWR_OK = 0,
@@ -248,6 +248,11 @@ int swr_fl_dw(const swr_fl_plan* plan_host, const void* fl_workspace, const floa
  * swr_bn_bwd_dx(dZ = NULL) the [B, N] gradient of the pre-activations is never written or read back.  Supported where the wide
  * weight-gradient kernel takes the product (swr_fl_dw_bn_supported); same workspace as swr_fl_dw. */
 int swr_fl_dw_bn_supported(const swr_fl_plan* plan_host, int64_t lddy, int64_t ldz);
+/* Which kernel takes swr_fl_dw_bn where both fit: 1 (default; SWR_DW_TR=0 in the environment starts at 0) = the transpose-read
+ * form (csrc/dw_tr.hip: operands stored in LDS as they arrive, read back with ds_read_b64_tr_b16; A' from the pre-split pieces
+ * by LDS-DMA; all 8 waves multiply), 0 = the wide register-transposing form (gemm_tn_x6w_kernel), whose sums are bit-identical
+ * to swr_gemm_tn on the written block.  set < 0: query only.  Returns the previous value.  Both are deterministic. */
+int swr_dw_tr_mode(int set);
 int swr_fl_dw_bn(const swr_fl_plan* plan_host, const void* fl_workspace, const float* dY, int64_t lddy, const float* Z, int64_t ldz,
                  const float* ca, const float* cb, const float* cc, const float* mean, float* dWp, int64_t lddwp, float* colsum,
                  void* workspace, size_t workspace_bytes, void* stream);

@@ -947,6 +947,7 @@ static int fl_dw_launch(const swr_fl_plan* plan, const void* fl_workspace, const
     if (bn) {
         SWR_REQUIRE(bn->Z && bn->ca && bn->cb && bn->cc && bn->mean && tn_x6_gather_wide(a, g.kp), SWR_ERR_UNSUPPORTED);
         g.a_z = bn->Z; g.a_ldz = bn->ldz; g.a_ca = bn->ca; g.a_cb = bn->cb; g.a_cc = bn->cc; g.a_mean = bn->mean;
+        g.tr_ws = ws; g.tr_voff = reinterpret_cast<const uint32_t*>(ws + h.o.voff); g.tr_mask_t = mask_t; g.tr_nr = h.NR;
     }
     return tn_x6_gather(a, g, workspace, workspace_bytes, stream);
 }

@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
 // only the rows now come from the tables (L2-resident but for the row-sparse ones) instead of a 72 MB block; one-hot column
 // pairs are expanded from two bits of the sample's mask word and, being exact in bf16, take three products instead of six.
 #include "tn_gather.h"
+#include "dw_tr.h"
 template <int PT, bool TAIL>
 __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, const TnGather g) {
     constexpr int ACOLS = PT * 32, COLS = ACOLS + TX_QCOLS + (TAIL ? 32 : 0);
@@ -2008,6 +2009,10 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     tn_x6_plan(a, n_splits, kk.rows_per_split);
     kk.splits = n_splits * GEMM_WAVES;
     const bool wide = tn_wide_ok(a);
+    // transpose-read form (dw_tr.hip): A recomputed from dY and Z, A' through the pre-split pieces; splits of a multiple of 32 rows
+    const bool tr = wide && g.a_z && g.tr_voff && dw_tr_shape_ok(a.K1, a.K2, g.tr_nr) && a.M * a.lda * 4 < (1ll << 32) &&
+                    a.M * g.a_ldz * 4 < (1ll << 32) && a.lda % 4 == 0 && g.a_ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(g.a_z) & 15u) == 0;
     const bool tail = !wide && tn_x6_tail(a);
     kk.qblk = tail ? static_cast<unsigned>(a.K2 / TX_QCOLS) : static_cast<unsigned>(swr_ceil_div(a.K2, TX_QCOLS));
     kk.tail_q0 = tail ? static_cast<int>(kk.qblk) * TX_QCOLS : 0;
@@ -2018,7 +2023,21 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     const int pt_all = static_cast<int>(swr_ceil_div(a.K1, 32));
     kk.pblk = 1;
     kk.n_tiles = kk.qblk * static_cast<unsigned>(n_splits);
-    if (wide) {
+    if (tr) {
+        DwTrArgs t;
+        t.dY = reinterpret_cast<const char*>(a.A); t.Z = reinterpret_cast<const char*>(g.a_z);
+        t.lddy_b = static_cast<uint32_t>(a.lda * 4); t.ldz_b = static_cast<uint32_t>(g.a_ldz * 4);
+        t.ca = g.a_ca; t.cb = g.a_cb; t.cc = g.a_cc; t.mean = g.a_mean;
+        t.M = a.M; t.K1 = a.K1; t.K2 = a.K2;
+        t.ws = g.tr_ws; t.voff = g.tr_voff; t.mask_t = g.tr_mask_t; t.NR = g.tr_nr;
+        t.part = kk.part; t.part_cs = kk.part_cs; t.k2p = kk.k2p;
+        t.rows_per_split = std::max<int64_t>(128, (kk.rows_per_split + 31) / 32 * 32);       // (never more splits than planned)
+        t.n_splits = static_cast<int>(swr_ceil_div(a.M, t.rows_per_split));
+        const int rc = dw_tr_launch(t, st);
+        if (rc != SWR_OK) return rc;
+        kk.rows_per_split = t.rows_per_split;
+        kk.splits = t.n_splits * GEMM_WAVES;
+    } else if (wide) {
         const int rc = tn_wide_launch(kk, g, n_splits, st);
         if (rc != SWR_OK) return rc;
     } else {

@@ -28,6 +28,9 @@ struct TnGather {
     const float* a_z;
     int64_t a_ldz;
     const float* a_ca; const float* a_cb; const float* a_cc; const float* a_mean;
+    // the pre-split pieces of the keys launch (first_layer.hip): with them and a recomputed A the transpose-read kernel (dw_tr.hip)
+    // takes the product where its shape is instantiated.  tr_voff = null: not available.
+    const char* tr_ws; const uint32_t* tr_voff; const uint32_t* tr_mask_t; int tr_nr;
 };
 
 // a = the product's description with B ignored (K2 = columns of A'); same workspace size as swr_gemm_tn_workspace_bytes

@@ -29,7 +29,7 @@ def _load():
 
 # the ABI number of include/swr.h these bindings were written against (SWR_ABI_VERSION): argument lists changed between
 # numbers, so a stale or variant libswr.so with another number would take shifted arguments -- refuse it
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 lib = _load()
 lib.swr_abi_version.restype = C.c_int
@@ -224,6 +224,7 @@ _SIGS = {
     "swr_fl_dw_workspace_bytes": (_Z, [_P]),
     "swr_fl_dw": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _Z, _P]),
     "swr_fl_dw_bn_supported": (C.c_int, [_P, _L, _L]),
+    "swr_dw_tr_mode": (C.c_int, [_I]),
     "swr_fl_dw_bn": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _Z, _P]),
     "swr_adam_catchup_multi": (C.c_int, [_P, _I, _P, _P, _P]),
     "swr_adam_rows_multi": (C.c_int, [_P, _I, _P, _P]),
