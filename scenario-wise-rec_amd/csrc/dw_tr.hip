@@ -157,16 +157,20 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
     // ---- staging: lane = (sample r of the stage, column half hb of the 16-column group)
     const int r = lane >> 1, hb = lane & 1;
     const int ur = lane >> 3, uc = lane & 7;                               // dZ staging: row of the unit's 8, 16-byte chunk of its 128 bytes
+    // (32-bit row / tile counters: M < 2^31 and M * ld * 4 < 2^32 are the launcher's conditions.  Loads past the split's last stage
+    // re-read rows of the next split -- or row M - 1 -- and are never used.)
+    const uint32_t m_last = static_cast<uint32_t>(a.M - 1), ms32 = static_cast<uint32_t>(ms), me32 = static_cast<uint32_t>(me);
+    const uint32_t t_last = static_cast<uint32_t>((a.M + 31) / 32 - 1);
     auto raw_load = [&](int u, int st, DtRaw& d) {
         const int lc = u % PT, ro = u / PT;
-        const int64_t row = min(ms + 32 * static_cast<int64_t>(min(st, n_stages - 1)) + 8 * ro + ur, a.M - 1);
+        const uint32_t row = min(ms32 + 32u * static_cast<uint32_t>(st) + static_cast<uint32_t>(8 * ro + ur), m_last);
         const uint32_t cb = static_cast<uint32_t>(min(32 * lc + 4 * uc, K1 - 4)) * 4u;
-        d.y = *reinterpret_cast<const float4*>(a.dY + (static_cast<uint32_t>(row) * a.lddy_b + cb));
-        d.z = *reinterpret_cast<const float4*>(a.Z + (static_cast<uint32_t>(row) * a.ldz_b + cb));
+        d.y = *reinterpret_cast<const float4*>(a.dY + (row * a.lddy_b + cb));
+        d.z = *reinterpret_cast<const float4*>(a.Z + (row * a.ldz_b + cb));
     };
     auto vo_load = [&](int cg, int st) -> uint32_t {
-        const int64_t T = (ms >> 5) + min(st, n_stages - 1);
-        return a.voff[(T * a.NR + min(cg, a.NR - 1)) * 64 + hb * 32 + r];
+        const uint32_t T = min((ms32 >> 5) + static_cast<uint32_t>(st), t_last);
+        return a.voff[(T * static_cast<uint32_t>(a.NR) + static_cast<uint32_t>(min(cg, a.NR - 1))) * 64u + static_cast<uint32_t>(hb * 32 + r)];
     };
     float cs[NZ > 0 ? NZ : 1][4];
 #pragma unroll
@@ -177,7 +181,7 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
     // dZ of the lane's 4 columns (fl_dx_kernel's operations in its order), its column sums, its three bf16 terms -> the stage's buffer
     auto split_store = [&](int j, int u, int st, const DtRaw& d, dt_lds zt) {
         const int lc = u % PT, ro = u / PT;
-        const bool row_ok = ms + 32 * static_cast<int64_t>(st) + 8 * ro + ur < me;
+        const bool row_ok = ms32 + 32u * static_cast<uint32_t>(st) + static_cast<uint32_t>(8 * ro + ur) < me32;
         const int c0 = 32 * lc + 4 * uc;
         const int cc_ = min(c0, K1 - 4);
         const dt_f32x4 a4 = *reinterpret_cast<__attribute__((address_space(3))) const dt_f32x4*>(coef + 4 * cc_);
@@ -208,11 +212,11 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
     // the stage's one-hot words [4][32] (wave 5): lane -> word 2 u + (lane >> 5) of sample lane & 31
     auto dma_mask = [&](int st, dt_lds mk) {
         if (OQ == 0 || W != 5) return;
-        const int64_t row = min(ms + 32 * static_cast<int64_t>(st) + i, a.M - 1);
+        const uint32_t row = min(ms32 + 32u * static_cast<uint32_t>(st) + static_cast<uint32_t>(i), m_last);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int o = min(2 * u + s, OQ - 1);
-            dt_dma4(dt_lds_addr(mk + u * 256), static_cast<uint32_t>((static_cast<int64_t>(o) * a.M + row) * 4), a.mask_t);
+            dt_dma4(dt_lds_addr(mk + u * 256), (static_cast<uint32_t>(o) * static_cast<uint32_t>(a.M) + row) * 4u, a.mask_t);
         }
     };
 
@@ -326,17 +330,25 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
         }
     };
 
-    // ---- prologue: stage 0 into buffer 0, stage 1's operands requested
+    // ---- prologue: the operands of stages 0 AND 1 are requested at once (one memory round trip in front of the first products
+    // instead of two: every CU's workgroup is here at the same time, ~110 KB per CU in flight); stage 0 goes into buffer 0
     DtRaw raw[NZ > 0 ? NZ : 1];
     uint32_t vo[NA > 0 ? NA : 1];
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) raw_load(dt_unit(W, j, NU), 0, raw[j]);
-#pragma unroll
-    for (int j = 0; j < NA; ++j) vo[j] = vo_load(dt_cg(W, j, C::NCB), 0);
     {
+        DtRaw raw0[NZ > 0 ? NZ : 1];
+        uint32_t vo0[NA > 0 ? NA : 1];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) vo0[j] = vo_load(dt_cg(W, j, C::NCB), 0);
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) raw_load(dt_unit(W, j, NU), 0, raw0[j]);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) vo[j] = vo_load(dt_cg(W, j, C::NCB), 1);
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) raw_load(dt_unit(W, j, NU), 1, raw[j]);
+        __builtin_amdgcn_sched_barrier(0);
         // coefficients (zero past K1) and the A' groups that are never copied (NR < 2 RQ), by all waves of the workgroup
         const int tid = threadIdx.x;
-        // (four loops: one loop with the source chosen by index put the four pointers into scratch)
+        // (four stores per index: one loop with the source chosen by index put the four pointers into scratch)
         for (int n = tid; n < C::NCOEF; n += DT_THREADS) {
             *reinterpret_cast<__attribute__((address_space(3))) float*>(coef + 4 * n) = n < K1 ? a.ca[n] : 0.f;
             *reinterpret_cast<__attribute__((address_space(3))) float*>(coef + 4 * (C::NCOEF + n)) = n < K1 ? a.cb[n] : 0.f;
@@ -349,19 +361,17 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
             *reinterpret_cast<__attribute__((address_space(3))) dt_u32x4*>(lds + C::ZT_BYTES + b) = z4;
             *reinterpret_cast<__attribute__((address_space(3))) dt_u32x4*>(lds + C::BUF + C::ZT_BYTES + b) = z4;
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) dma_group(dt_cg(W, j, C::NCB), vo0[j], lds + C::ZT_BYTES);
+        dma_mask(0, lds + C::ZT_BYTES + C::AT_BYTES);
+        __syncthreads();                                                   // (the coefficients)
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) split_store(j, dt_unit(W, j, NU), 0, raw0[j], lds);
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NA; ++j) dma_group(dt_cg(W, j, C::NCB), vo[j], lds + C::ZT_BYTES);
-    dma_mask(0, lds + C::ZT_BYTES + C::AT_BYTES);
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) split_store(j, dt_unit(W, j, NU), 0, raw[j], lds);
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) raw_load(dt_unit(W, j, NU), 1, raw[j]);
-#pragma unroll
-    for (int j = 0; j < NA; ++j) vo[j] = vo_load(dt_cg(W, j, C::NCB), 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     DT_STAMP(1);
 
     // Waves w and w + 4 share a SIMD: the first four stage the next stage's dZ (VALU) and then multiply, the other four multiply
@@ -534,6 +544,7 @@ int dw_tr_launch(const DwTrArgs& a, hipStream_t st) {
     if (!dw_tr_shape_ok(a.K1, a.K2, a.NR) || a.rows_per_split % 32 || a.n_splits < 1 || !a.dY || !a.Z || !a.ws || !a.voff || !a.part)
         return SWR_ERR_UNSUPPORTED;
     if (a.K2 > 16 * a.NR && !a.mask_t) return SWR_ERR_ARG;
+    if (a.M < 1 || a.M >= (1ll << 26) || a.M * a.lddy_b >= (1ll << 32) || a.M * a.ldz_b >= (1ll << 32)) return SWR_ERR_UNSUPPORTED;   // 32-bit offsets
     if ((reinterpret_cast<uintptr_t>(a.dY) & 15u) || (reinterpret_cast<uintptr_t>(a.Z) & 15u) || a.lddy_b % 16 || a.ldz_b % 16)
         return SWR_ERR_ALIGN;
     const int pt = (a.K1 + 31) / 32, rq = (16 * a.NR + 31) / 32, oq = (a.K2 - 16 * a.NR + 31) / 32;

@@ -2010,7 +2010,7 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     kk.splits = n_splits * GEMM_WAVES;
     const bool wide = tn_wide_ok(a);
     // transpose-read form (dw_tr.hip): A recomputed from dY and Z, A' through the pre-split pieces; splits of a multiple of 32 rows
-    const bool tr = wide && g.a_z && g.tr_voff && dw_tr_shape_ok(a.K1, a.K2, g.tr_nr) && a.M * a.lda * 4 < (1ll << 32) &&
+    const bool tr = wide && g.a_z && g.tr_voff && dw_tr_shape_ok(a.K1, a.K2, g.tr_nr) && a.M < (1ll << 26) && a.M * a.lda * 4 < (1ll << 32) &&
                     a.M * g.a_ldz * 4 < (1ll << 32) && a.lda % 4 == 0 && g.a_ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15u) == 0 &&
                     (reinterpret_cast<uintptr_t>(g.a_z) & 15u) == 0;
     const bool tail = !wide && tn_x6_tail(a);

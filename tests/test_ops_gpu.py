@@ -1349,13 +1349,17 @@ def test_bn_backward_inside_the_dx_product_is_bitwise_the_two_launches(monkeypat
     32 768 at these widths.)"""
     from scenario_wise_rec import ops
     vocabs = [1000, 5000, 8, 2, 3, 51, 1472, 16, 35, 4, 119, 455, 6, 3, 200, 300]
-    monkeypatch.setattr(ops, "FUSE_BN_DX", False)
-    p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, 32768, 65536, 5)
-    monkeypatch.setattr(ops, "FUSE_BN_DX", True)
-    calls = []
-    real = ops.lib.swr_bn_bwd_dx
-    monkeypatch.setattr(ops.lib, "swr_bn_bwd_dx", lambda *a: (calls.append(1), real(*a))[1])
-    p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, 32768, 65536, 5)
+    prev = ops.lib.swr_dw_tr_mode(0)          # (the weight gradient in the form whose batch splits are the written-dZ product's)
+    try:
+        monkeypatch.setattr(ops, "FUSE_BN_DX", False)
+        p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, 32768, 65536, 5)
+        monkeypatch.setattr(ops, "FUSE_BN_DX", True)
+        calls = []
+        real = ops.lib.swr_bn_bwd_dx
+        monkeypatch.setattr(ops.lib, "swr_bn_bwd_dx", lambda *a: (calls.append(1), real(*a))[1])
+        p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, 32768, 65536, 5)
+    finally:
+        ops.lib.swr_dw_tr_mode(prev)
     assert calls, "the fused BatchNorm-backward + dX product was not taken"
     assert np.array_equal(p0, p1) and l0 == l1
     for k in g0:
@@ -1433,17 +1437,22 @@ def test_weight_gradient_that_recomputes_dz_is_bitwise_the_written_dz(monkeypatc
     """swr_fl_dw_bn + swr_bn_bwd_dx(dZ = NULL) (the wide weight-gradient kernel applies the BatchNorm backward to dY and Z while it
     stages them; dZ is never written) against the same step with dZ written by the dX launch and read back by swr_fl_dw: every
     gradient BIT FOR BIT.  Config 2's column layout (160 real + 128 one-hot columns: the shape the wide kernel is built for), a
-    batch that does not fill the last 16-row stage of a split."""
+    batch that does not fill the last 16-row stage of a split.  (swr_dw_tr_mode(0): the wide form; the transpose-read form splits
+    the batch differently -- test_transpose_read_weight_gradient.)"""
     from scenario_wise_rec import ops
     vocabs = [1000, 5000, 8, 2, 3, 2, 8, 8, 7, 7, 3, 8, 51, 1472, 16, 35, 4, 119, 455, 8, 6, 6, 3, 3, 3, 3, 3, 3, 3, 8, 200, 300]
     B = 32768 + 8
-    monkeypatch.setattr(ops, "DZ_FREE", False)
-    p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 7)
-    monkeypatch.setattr(ops, "DZ_FREE", True)
-    calls = []
-    real = ops.lib.swr_fl_dw_bn
-    monkeypatch.setattr(ops.lib, "swr_fl_dw_bn", lambda *a: (calls.append(1), real(*a))[1])
-    p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 7)
+    prev = ops.lib.swr_dw_tr_mode(0)
+    try:
+        monkeypatch.setattr(ops, "DZ_FREE", False)
+        p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 7)
+        monkeypatch.setattr(ops, "DZ_FREE", True)
+        calls = []
+        real = ops.lib.swr_fl_dw_bn
+        monkeypatch.setattr(ops.lib, "swr_fl_dw_bn", lambda *a: (calls.append(1), real(*a))[1])
+        p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 7)
+    finally:
+        ops.lib.swr_dw_tr_mode(prev)
     assert calls, "the weight-gradient product that recomputes dZ was not taken"
     assert np.array_equal(p0, p1) and l0 == l1
     for k in g0:
@@ -1451,3 +1460,40 @@ def test_weight_gradient_that_recomputes_dz_is_bitwise_the_written_dz(monkeypatc
             assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]), k
         else:
             assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
+
+
+@pytest.mark.parametrize("B", [32768 + 8, 65536, 4096 + 1])
+def test_transpose_read_weight_gradient(B):
+    """csrc/dw_tr.hip (swr_dw_tr_mode(1), the default): the first layer's weight gradient with both operands stored in LDS as
+    they arrive and read back through ds_read_b64_tr_b16, A' from the pre-split pieces by LDS-DMA.  One training step at config 2's
+    column layout against the same step through the wide kernel (mode 0): forward and every gradient that does not pass through
+    the product bit for bit, the product's outputs (first-layer dW / db, the small tables' gradients) within fp32 summation noise
+    -- same bf16 terms, same six / three products, other batch splits; twice the same bits; ragged batches (a last stage of 8 / 1
+    valid rows); the oracle test of the fused step runs in this mode (test_fused_lookup_step_against_the_oracle)."""
+    from scenario_wise_rec import ops
+    vocabs = [1000, 5000, 8, 2, 3, 2, 8, 8, 7, 7, 3, 8, 51, 1472, 16, 35, 4, 119, 455, 8, 6, 6, 3, 3, 3, 3, 3, 3, 3, 8, 200, 300]
+    prev = ops.lib.swr_dw_tr_mode(0)
+    try:
+        p0, l0, g0, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 11)
+        ops.lib.swr_dw_tr_mode(1)
+        p1, l1, g1, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 11)
+        p2, l2, g2, *_ = _fused_case("MMOE", 16, vocabs, 4, B, 65536, 11)
+    finally:
+        ops.lib.swr_dw_tr_mode(prev)
+    assert np.array_equal(p0, p1) and l0 == l1
+    n_diff = 0
+    for k in g0:
+        if isinstance(g0[k], tuple):
+            assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]), k
+            assert np.array_equal(g1[k][1], g2[k][1]), k
+            continue
+        assert np.array_equal(g1[k], g2[k]), f"{k}: not deterministic"
+        # (a bias in front of a BatchNorm has a mathematically zero gradient: what both kernels return is the summation noise of the
+        # column sums of dZ -- measured against the layer's weight gradient, not against itself)
+        kw = k[:-4] + "weight" if k.endswith("bias") else k
+        scale = max(float(np.abs(g0[k]).max()), float(np.abs(g0[kw]).max()) if kw in g0 and not isinstance(g0[kw], tuple) else 0.0, 1e-12)
+        err = float(np.abs(g0[k] - g1[k]).max()) / scale
+        assert err < 2e-6, f"{k}: {err:.3e} of the largest entry"
+        n_diff += int(err > 0)
+    # (at B = 65 536 both kernels split the batch into the same 256 x 16-sample steps and the sums come out identical)
+    print(f"B {B}: {n_diff} of {len(g0)} gradients differ in the last bits")
