@@ -268,6 +268,7 @@ def main():
         batches.append(({k: torch.from_numpy(v).to(dev) for k, v in xh.items()}, torch.from_numpy(yh).to(dev)))
     x, y = batches[0]
 
+    stepper = None
     if use_dp:
         from scenario_wise_rec.parallel import DataParallelStep
         stepper = DataParallelStep(trainer, world)
@@ -392,6 +393,18 @@ def main():
         ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered,
                       "distinct_devices": len({(g["pci_bus_id"], g["uuid"], g["device_index"]) for g in gathered})}
 
+    # which collectives carried the step's exchange (N > 1; parallel.DataParallelStep): the gradient arena by ONE all-reduce above
+    # SWR_DP_ALLREDUCE_BYTES (1 MiB), else by one all-gather + a rank-ordered local sum (the 0.5 MB arena of config 2: one
+    # latency-bound collective either way); the large tables' row lists always by one all-gather
+    dp_exchange = None
+    if dist is not None and stepper is not None:
+        from scenario_wise_rec.parallel import allreduce_min_bytes
+        xb = getattr(stepper, "_xb", None)
+        arena_bytes = 4 * int(xb["A"]) if xb else None
+        dp_exchange = {"arena_collective": (("all_reduce" if xb["allreduce"] else "all_gather + rank-ordered local sum") if xb else
+                                            "all_reduce above / all_gather + local sum below the threshold"),
+                       "allreduce_min_bytes": allreduce_min_bytes(), "arena_bytes": arena_bytes,
+                       "row_lists": "all_gather of (row id, gradient) per large table, merged by swr_dp_finish", "backend": dist.get_backend()}
     if rank != 0:
         return
 
@@ -415,6 +428,7 @@ def main():
                    "ids": "uniform" if args.uniform_ids else "zipf1.05(large tables)+uniform", "hipgraph": graph is not None,
                    "batches_rotated": n_rot, "ms_per_step_single_batch_replayed": single_ms,
                    "final_loss": final_loss, "scaling": args.scaling, "other_scaling": other, "process_group": ranks_info,
+                   "dp_exchange": dp_exchange,
                    "precision_mode": ("bf16 perf mode (SWR_GEMM=bf16): ONE bf16 MFMA product per k-group, operands rounded to bf16 -- "
                                       "NOT the parity path (max logit error ~1e-3..1e-2 at these widths, tests/test_perf_mode_gpu.py); "
                                       "reported beside the fp32-accurate line, never instead of it") if bf16_mode else
@@ -540,8 +554,31 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
     ex_from = info.Kp if folded else 0
     k_half = (kf - ex_from if fused else max(0, kf - (ex_from + 63) // 64 * 64)) if ex_from > 0 else 0
 
+    # dX: the step launches fl_dx_kernel (swr_bn_bwd_dx: BatchNorm backward in the A fragment + dX = dZ W[:, sel], rows padded to
+    # 128 bytes, dZ not written where the weight gradient recomputes it) when the fused forms are on; else the plain product
+    dx_fused = bool(fused and ops.FUSE_BN_DX and lib.swr_bn_bwd_dx_supported(n1, n_sel))
+    if dx_fused:
+        n1p_ = (n1 + 31) // 32 * 32
+        nsp = (n_sel + 31) // 32 * 32
+        dYx = [torch.nn.functional.pad(dz, (0, n1p_ - n1)).contiguous() for dz, _a, _i in sets]
+        Zx = [torch.randn(B, n1p_, device=dev, generator=g) for _ in sets]
+        cfx = [torch.randn(n1, device=dev, generator=g) * 0.1 for _ in range(4)]
+        dXp = torch.empty(B, nsp, device=dev)
+        dZo = None if (ops.DZ_FREE and bn_form) else torch.empty(B, n1p_, device=dev)
+        Wt_sel = torch.empty((n_sel, n1), device=dev)
+        for _dz, _a, inf in sets:                  # the B3X image of the selected rows of W^T, once per operand set
+            H.check(lib.swr_fl_prep(C.byref(inf.fl["plan"]), H.ptr(W), W.stride(0), k0, H.ptr(inf.ohtab), tabs, len(inf.tables_p), H.ptr(inf.sel),
+                                    inf.n_sel, H.ptr(Wt_sel), n1, H.ptr(inf.fl["ws"]), H.stream()), "swr_fl_prep")
+        torch.cuda.synchronize()
+
     def f_dx():
-        dZ, _A, _i = nxt()
+        dZ, _A, inf = nxt()
+        if dx_fused:
+            j = st["i"] % 4
+            H.check(lib.swr_bn_bwd_dx(C.byref(inf.fl["plan"]), H.ptr(inf.fl["ws"]), H.ptr(dYx[j]), n1p_, H.ptr(Zx[j]), n1p_, H.ptr(cfx[0]),
+                                      H.ptr(cfx[1]), H.ptr(cfx[2]), H.ptr(cfx[3]), n_sel, H.ptr(dZo), n1p_, H.ptr(dXp), nsp, H.stream()),
+                    "swr_bn_bwd_dx")
+            return
         ops.gemm("nt", dZ, Wsel, dX, B, n_sel, n1)
 
     x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f"
@@ -572,10 +609,20 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         # else the blocked one (dZ read once per 128-column block of A')
         wide = os.environ.get("SWR_TN_WIDE", "1") != "0" and (n1 + 31) // 32 == 5 and (kf + 31) // 32 == 9
         n_qblk = 1 if wide else max(1, kf // 128)
-        dw_bytes = float(B) * (n_qblk * 4 * n1 * (2 if (wide and ops.DZ_FREE) else 1) + 4 * info.Kp + 4 * (info.Kp // 16) + 16)
-        dw_name = "gemm_tn_x6w_kernel" if wide else "gemm_tn_x6g_kernel"
-        roof = entry(dw_name + " (+tn_reduce): dWp = dZ^T A', A' gathered through the row keys", f_tn,
-                     "void %s<" % dw_name, kf, alg_flops, k3=k_half, nbytes=dw_bytes)
+        # the transpose-read form (csrc/dw_tr.hip, swr_dw_tr_mode 1) where dZ is recomputed and the shape is instantiated
+        tr = bool(bn_form and wide and lib.swr_dw_tr_mode(-1) == 1)
+        if tr:
+            # per sample: the dY and Z rows, 48 B of bf16 terms + a 4-byte offset per 8-column piece (mostly L2 hits on the table
+            # shadows), 16 B of one-hot words; per launch: one partial tile per batch split written, then read by the reduction
+            n_splits = min(256, max(1, B // 128))
+            dw_bytes = float(B) * (8 * n1 + (48 + 4) * 2 * nr + 16) + 2.0 * n_splits * n1 * kf * 4
+            dw_name, dw_label = "dw_tr_kernel", ("dw_tr_kernel (+tn_reduce4): dWp = dZ^T A', dZ recomputed from dY and Z, operands transposed by "
+                                                 "ds_read_b64_tr_b16, A' from the pre-split pieces by LDS-DMA")
+        else:
+            dw_bytes = float(B) * (n_qblk * 4 * n1 * (2 if (wide and ops.DZ_FREE) else 1) + 4 * info.Kp + 4 * (info.Kp // 16) + 16)
+            dw_name = "gemm_tn_x6w_kernel" if wide else "gemm_tn_x6g_kernel"
+            dw_label = dw_name + " (+tn_reduce): dWp = dZ^T A', A' gathered through the row keys"
+        roof = entry(dw_label, f_tn, "void %s<" % dw_name, kf, alg_flops, k3=k_half, nbytes=dw_bytes)
         fwd_ent = entry("fl_fwd_kernel (forward Z = A' Wf^T, lookup fused as the A-operand producer, BN partials in the epilogue)", f_fwd,
                         "void fl_fwd_kernel<", kf, alg_flops, k3=k_half, nbytes=fwd_bytes)
     else:
@@ -584,15 +631,32 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         fwd_ent = entry("gemm_rows_x6_kernel (forward, BN partials in the epilogue)", f_fwd, "void gemm_rows_x6_kernel<5", kf, alg_flops,
                         k3=k_half)
     roof["traffic_unit"] = "HBM bytes per launch, rocprofv3 PMC (profiles/pmc_hbm_latest.json; null if not collected)"
+    roof["traffic_source"] = pmc_source(2)
     roof["also"] = {
         ("fl_fwd_kernel(forward)" if fused else "gemm_rows_x6_kernel(forward)"): fwd_ent,
         # dX is algorithmically [B, 148] x [148, 512]; the small tables' columns are never computed (their gradients
         # come out of the weight-gradient product's one-hot block)
-        "gemm_rows_x6_kernel(dX)": entry("gemm_rows_x6_kernel (dX = dZ W, columns of the K3 tables only)", f_dx,
-                                         "void gemm_rows_x6_kernel<5", n_sel, 2.0 * B * n1 * fs * e),
+        ("fl_dx_kernel(dX)" if dx_fused else "gemm_rows_x6_kernel(dX)"): (
+            entry("fl_dx_kernel (BatchNorm backward in the A fragment + dX = dZ W[:, sel], columns of the K3 tables only; dZ "
+                  + ("not written" if dZo is None else "written") + ")", f_dx, "void fl_dx_kernel<", n_sel, 2.0 * B * n1 * fs * e,
+                  nbytes=float(B) * (8 * n1 + 4 * n_sel + (0 if dZo is None else 4 * n1))) if dx_fused else
+            entry("gemm_rows_x6_kernel (dX = dZ W, columns of the K3 tables only)", f_dx, "void gemm_rows_x6_kernel<5", n_sel,
+                  2.0 * B * n1 * fs * e)),
         ("fl_keys_kernel" if fused else "embed_gather_kernel"): gather_roofline(cfg, model, x, dev, iters, B),
         "k3_direct_sums": k3_roofline(cfg, dev, iters, B),
     }
+    # the north star's two named fractions, at the top level of `roofline`:
+    #  gather_hbm_frac  = executed bytes of the lookup -- the keys launch AND the table-row fetches that moved into the forward
+    #                     product -- over the two launches' time, against the 8 TB/s peak;
+    #  expert_mfma_busy = matrix-pipe busy fraction of the three first-layer products from the committed PMC pass
+    #                     (SQ_VALU_MFMA_BUSY_CYCLES / chip cycles, tools/pmc_mfma_summary.py)
+    keys_ent = roof["also"].get("fl_keys_kernel") if fused else None
+    if keys_ent is not None:
+        both_b = keys_ent["executed_bytes_per_launch"] + fwd_ent["executed_bytes_per_launch"]
+        both_ms = keys_ent["avg_launch_ms"] + fwd_ent["avg_launch_ms"]
+        roof["gather_hbm_frac"] = both_b / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["gather_hbm_frac_of"] = "fl_keys_kernel + fl_fwd_kernel: executed bytes of both / time of both / 8 TB/s"
+    roof["expert_mfma_busy"] = mfma_busy_source()
     return roof
 
 
@@ -606,6 +670,42 @@ def _pmc_file(config):
             return json.load(f)["kernels"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def pmc_source(config):
+    """Where the `traffic` fields of this line come from: PMC counters cannot be collected from inside the bench process, so they
+    are read from the committed summary of the same command under rocprofv3 (tools/prof_round2.sh / prof_configs_all.sh)."""
+    name = "pmc_hbm_latest.json" if config == 2 else f"pmc_hbm_cfg{config}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    src = {"file": "profiles/" + name, "measured_in_this_run": False, "commit": None, "collected": None}
+    try:
+        with open(path) as f:
+            src["collected"] = json.load(f).get("collected")
+    except (OSError, ValueError):
+        return None
+    try:
+        import subprocess
+        r = subprocess.run(["git", "log", "-1", "--format=%h %cI", "--", path], capture_output=True, text=True, cwd=ROOT, timeout=10)
+        src["commit"] = r.stdout.strip() or "no git history on this box: `git log -- profiles/%s` in the repository" % name
+    except Exception:
+        src["commit"] = "no git on this box: `git log -- profiles/%s` in the repository" % name
+    return src
+
+
+def mfma_busy_source():
+    """Matrix-pipe busy fractions of the first layer's three products from profiles/pmc_mfma_latest.json (written by
+    tools/pmc_mfma_summary.py --json from two rocprofv3 PMC passes over this bench command); None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_mfma_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {"source": {"file": "profiles/pmc_mfma_latest.json", "measured_in_this_run": False, "collected": d.get("collected")}}
+    for k, v in d.get("kernels", {}).items():
+        if any(t in k for t in ("fl_fwd_kernel", "fl_dx_kernel", "dw_tr_kernel", "gemm_tn_x6w_kernel")):
+            out[k.replace("void ", "")] = v.get("mfma_busy")
+    return out
 
 
 def pmc_traffic(kernel, config=2):

@@ -30,7 +30,7 @@
 #ifndef SWR_BM_BWD_WAVES
 #define SWR_BM_BWD_WAVES 3
 #endif
-#define BM_BWD_WAVES(NE, DD) ((NE) <= 4 && (DD) <= 5 ? SWR_BM_BWD_WAVES : 2)     // six outputs or eight experts: > 168 registers
+#define BM_BWD_WAVES(NE, DD) ((NE) <= 4 && (DD) <= 5 ? SWR_BM_BWD_WAVES : ((NE) <= 4 ? 2 : 1))     // six outputs: > 168 registers; eight experts: > 256 (48 bytes per lane of scratch at two waves)
 #define BM_MAX_D 8
 #define BM_MAX_G 32           // D * ne
 

@@ -17,6 +17,24 @@ static inline int swr_launch_status() {
     return hipGetLastError() == hipSuccess ? SWR_OK : SWR_ERR_LAUNCH;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per (kernel, device): the attribute belongs to the device the call is made on,
+// so a process-wide "done" flag leaves the second GPU of a multi-GPU process without it (its launch then fails).  Not a stream
+// operation: legal during hipGraph capture.
+#include <mutex>
+#include <set>
+#include <utility>
+static inline bool swr_raise_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.insert({fn, dev});
+    return true;
+}
+
 static inline bool swr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int64_t swr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

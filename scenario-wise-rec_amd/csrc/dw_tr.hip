@@ -553,8 +553,7 @@ int dw_tr_launch(const DwTrArgs& a, hipStream_t st) {
     if (pt == PTV && rq == RQV && oq == OQV) {                                                                              \
         const void* fn = reinterpret_cast<const void*>(dw_tr_kernel<PTV, RQV, OQV>);                                        \
         const unsigned lds = static_cast<unsigned>(DtCfg<PTV, RQV, OQV>::LDS);                                              \
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)       \
-            return SWR_ERR_LAUNCH;                                                                                          \
+        if (!swr_raise_lds(fn, static_cast<int>(lds))) return SWR_ERR_LAUNCH;                                               \
         void* kargs[] = {&k};                                                                                               \
         if (hipLaunchKernel(fn, dim3(static_cast<unsigned>(a.n_splits)), dim3(DT_THREADS), kargs, lds, st) != hipSuccess)   \
             return SWR_ERR_LAUNCH;                                                                                          \

@@ -1259,12 +1259,8 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         if (lds > 64 * 1024) {
             // above 64 KB of dynamic LDS the attribute is needed (idempotent, not a stream operation; the first call of a
             // shape happens in a warm-up step, never inside a hipGraph capture -- as bnmix.hip, gemm.hip)
-            static bool raised[2] = {false, false};
-            if (!raised[vec4 ? 1 : 0]) {
-                const void* fn = vec4 ? reinterpret_cast<const void*>(direct_kernel<4>) : reinterpret_cast<const void*>(direct_kernel<1>);
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;
-                raised[vec4 ? 1 : 0] = true;
-            }
+            const void* fn = vec4 ? reinterpret_cast<const void*>(direct_kernel<4>) : reinterpret_cast<const void*>(direct_kernel<1>);
+            if (!swr_raise_lds(fn, 160 * 1024)) return SWR_ERR_LAUNCH;
         }
         if (vec4)
             hipLaunchKernelGGL(direct_kernel<4>, dim3(static_cast<unsigned>(p.dm.n_blocks)), dim3(DIRECT_THREADS), lds, st,

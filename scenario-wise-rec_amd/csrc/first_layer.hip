@@ -848,12 +848,7 @@ extern "C" int swr_fl_fwd(const swr_fl_plan* plan, const void* workspace, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define FL_GO(NTV)                                                                                                      \
     do {                                                                                                                \
-        static bool raised = false;                                                                                     \
-        if (lds >= 64 * 1024 && !raised) {                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fl_fwd_kernel<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    80 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;                                     \
-            raised = true;                                                                                              \
-        }                                                                                                               \
+        if (lds >= 64 * 1024 && !swr_raise_lds(reinterpret_cast<const void*>(fl_fwd_kernel<NTV>), 80 * 1024)) return SWR_ERR_LAUNCH; \
         hipLaunchKernelGGL(fl_fwd_kernel<NTV>, grid, dim3(FL_THREADS), lds, st, k);                                     \
     } while (0)
     switch (h.NT) {
@@ -1199,12 +1194,7 @@ extern "C" int swr_bn_bwd_dx(const swr_fl_plan* plan, const void* fl_workspace, 
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define FL_GOX(NTV)                                                                                                     \
     do {                                                                                                                \
-        static bool raised = false;                                                                                     \
-        if (lds >= 64 * 1024 && !raised) {                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fl_dx_kernel<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    80 * 1024) != hipSuccess) return SWR_ERR_LAUNCH;                                     \
-            raised = true;                                                                                              \
-        }                                                                                                               \
+        if (lds >= 64 * 1024 && !swr_raise_lds(reinterpret_cast<const void*>(fl_dx_kernel<NTV>), 80 * 1024)) return SWR_ERR_LAUNCH; \
         hipLaunchKernelGGL(fl_dx_kernel<NTV>, grid, dim3(FL_THREADS), lds, st, k);                                      \
     } while (0)
     switch (nt) {

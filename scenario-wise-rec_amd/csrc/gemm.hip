@@ -199,7 +199,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_rows_lds_kernel(const GemmK
 // BF (SWR_GEMM=bf16, the perf mode of SURVEY.md fact 5 -- never the parity path): operands rounded to bf16, ONE product
 // per k-group instead of six; what the matrix pipes can do for this layer once the 1e-4 logit bar is given up.
 template <int NT, bool PRO, bool PS, bool BF>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD
+__global__ __launch_bounds__(GEMM_THREADS, (NT > 6 ? 1 : 2)) void gemm_rows_x6_kernel(const GemmK kk) {   // two waves per SIMD (eight accumulator
+                                                                                      // tiles: one -- 140-208 bytes per lane of scratch at two)
     constexpr int NCOL = NT * 32;
     constexpr int PLANE = NCOL * X6_PITCH;              // bf16 elements per plane
     constexpr int F4 = NCOL * X6_KC / 4;                // float4 of W per chunk
@@ -588,12 +589,7 @@ template <int NT, bool PRO, bool PS, bool BF = false>
 static void launch_x6(dim3 grid, unsigned lds, hipStream_t st, const GemmK& kk) {
     // more than 64 KB of dynamic LDS needs the attribute once per instantiation (not a stream operation; the first
     // call of a shape happens in a warm-up step, never inside a hipGraph capture)
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_x6_kernel<NT, PRO, PS, BF>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        raised = true;
-    }
+    if (lds > 64 * 1024) swr_raise_lds(reinterpret_cast<const void*>(gemm_rows_x6_kernel<NT, PRO, PS, BF>), 96 * 1024);
     hipLaunchKernelGGL((gemm_rows_x6_kernel<NT, PRO, PS, BF>), grid, dim3(GEMM_THREADS), lds, st, kk);
 }
 

@@ -14,7 +14,8 @@
 #include "common.h"
 
 #define LN_THREADS 256
-#define LN_MAXC 16            // register-resident chunks per lane
+#define LN_MAXC 16            // register-resident chunks per lane, scalar kernels; the 16-byte kernels keep LN_MAXC_V chunks of 4
+#define LN_MAXC_V 4            // (16 x 4 values x 4 arrays in the backward kernel = 256 registers: 528 bytes per lane went to scratch)
 
 struct LnK {
     int64_t M;
@@ -38,7 +39,7 @@ __device__ __forceinline__ float seg_sum(float v, int lps) {
     return v;
 }
 
-template <int VEC>
+template <int VEC, int MAXC>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const LnK k) {
     const int lps = k.lps, slots = LN_THREADS / lps;
     const int slot = threadIdx.x / lps, j0 = threadIdx.x % lps;
@@ -50,10 +51,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const LnK k) 
     for (int64_t rb = r0; rb < r1; rb += slots) {
         const int64_t r = rb + slot;
         const bool live = r < r1;
-        float x[LN_MAXC][VEC];
+        float x[MAXC][VEC];
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < MAXC; ++c) {
             const int j = j0 + c * lps;
             if (live && j < C) {
                 const float* p = k.X + r * k.ldx + static_cast<int64_t>(g) * k.N + j * VEC;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const LnK k) 
         const float mean = seg_sum<64>(s, lps) * inv_n;
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < MAXC; ++c) {
             const int j = j0 + c * lps;
             if (live && j < C) {
 #pragma unroll
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const LnK k) 
         if (!live) continue;
         if (j0 == 0 && k.mean) { k.mean[r * k.G + g] = mean; k.rstd[r * k.G + g] = rstd; }
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < MAXC; ++c) {
             const int j = j0 + c * lps;
             if (j < C) {
                 const int col = g * k.N + j * VEC;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const LnK k) 
     }
 }
 
-template <int VEC>
+template <int VEC, int MAXC>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const LnK k) {
     __shared__ float red[2][LN_THREADS * 4];          // VEC <= 4 values per (thread, chunk); chunk loop outside
     const int lps = k.lps, slots = LN_THREADS / lps;
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const LnK k) 
     const float inv_n = 1.f / static_cast<float>(k.N);
     const int64_t r0 = static_cast<int64_t>(blockIdx.x) * k.rows_per_block;
     const int64_t r1 = min(r0 + k.rows_per_block, k.M);
-    float ag[LN_MAXC][VEC], ab[LN_MAXC][VEC];        // this thread's column sums over the rows of its slot
+    float ag[MAXC][VEC], ab[MAXC][VEC];        // this thread's column sums over the rows of its slot
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c)
+    for (int c = 0; c < MAXC; ++c)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { ag[c][v] = 0.f; ab[c][v] = 0.f; }
     for (int64_t rb = r0; rb < r1; rb += slots) {
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const LnK k) 
         const bool live = r < r1;
         const float mean = live ? k.mean[r * k.G + g] : 0.f;
         const float rstd = live ? k.rstd[r * k.G + g] : 0.f;
-        float xh[LN_MAXC][VEC], dh[LN_MAXC][VEC];
+        float xh[MAXC][VEC], dh[MAXC][VEC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < MAXC; ++c) {
             const int j = j0 + c * lps;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { xh[c][v] = 0.f; dh[c][v] = 0.f; }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const LnK k) 
         s2 = seg_sum<64>(s2, lps) * inv_n;
         if (!live || !k.dX) continue;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < MAXC; ++c) {
             const int j = j0 + c * lps;
             if (j < C) {
                 float o[VEC];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const LnK k) 
     }
     // column partials of this workgroup: slots added in slot order through LDS, one chunk index at a time
     float* part = k.partials + static_cast<int64_t>(blockIdx.x) * 2 * k.G * k.N;
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
         if (c * lps >= C) break;                               // uniform
         __syncthreads();
 #pragma unroll
@@ -216,12 +217,12 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_param_reduce_kernel(cons
 }
 
 static int ln_plan(LnK& k, bool vec) {
-    const int V = vec ? 4 : 1;
+    const int V = vec ? 4 : 1, maxc = vec ? LN_MAXC_V : LN_MAXC;
     const int C = k.N / V;
     int lps = 8;
-    while (lps < 64 && lps * LN_MAXC < C) lps <<= 1;
+    while (lps < 64 && lps * maxc < C) lps <<= 1;
     while (lps < 64 && lps * 2 <= C) lps <<= 1;               // short segments: as many lanes as there are chunks
-    if (static_cast<int64_t>(lps) * LN_MAXC < C) return SWR_ERR_UNSUPPORTED;
+    if (static_cast<int64_t>(lps) * maxc < C) return SWR_ERR_UNSUPPORTED;
     k.lps = lps;
     const int slots = LN_THREADS / lps;
     int64_t blocks = swr_ceil_div(k.M, slots);
@@ -257,8 +258,8 @@ extern "C" int swr_layernorm_fwd(const swr_layernorm_args* a, void* stream) {
     int rc = ln_plan(k, vec);
     if (rc != SWR_OK) return rc;
     const dim3 grid(static_cast<unsigned>(k.n_blocks_x), static_cast<unsigned>(k.G));
-    if (vec) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, dim3(LN_THREADS), 0, static_cast<hipStream_t>(stream), k);
-    else hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, dim3(LN_THREADS), 0, static_cast<hipStream_t>(stream), k);
+    if (vec) hipLaunchKernelGGL((layernorm_fwd_kernel<4, LN_MAXC_V>), grid, dim3(LN_THREADS), 0, static_cast<hipStream_t>(stream), k);
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<1, LN_MAXC>), grid, dim3(LN_THREADS), 0, static_cast<hipStream_t>(stream), k);
     return swr_launch_status();
 }
 
@@ -289,8 +290,8 @@ extern "C" int swr_layernorm_bwd(const swr_layernorm_args* a, void* workspace, s
     k.partials = static_cast<float*>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(static_cast<unsigned>(k.n_blocks_x), static_cast<unsigned>(k.G));
-    if (vec) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(LN_THREADS), 0, st, k);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(LN_THREADS), 0, st, k);
+    if (vec) hipLaunchKernelGGL((layernorm_bwd_kernel<4, LN_MAXC_V>), grid, dim3(LN_THREADS), 0, st, k);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<1, LN_MAXC>), grid, dim3(LN_THREADS), 0, st, k);
     if (a->dgamma || a->dbeta)
         hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3(static_cast<unsigned>(swr_ceil_div(static_cast<int64_t>(k.G) * k.N, LN_THREADS))),
                            dim3(LN_THREADS), 0, st, k);

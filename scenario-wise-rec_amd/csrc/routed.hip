@@ -109,13 +109,7 @@ extern "C" int swr_routed_mmoe_eval(const float* Y, int64_t ldy, int64_t M, int 
     k.W1 = W1; k.b1 = b1; k.scale1 = scale1; k.shift1 = shift1; k.w2 = w2; k.b2 = b2;
     k.dom = domain; k.dom_dtype = domain_dtype; k.out = out;
     const size_t lds = routed_lds_bytes(n_expert, H, D, T);
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(routed_mmoe_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                150 * 1024) != hipSuccess)
-            return SWR_ERR_LAUNCH;
-        raised = true;
-    }
+    if (lds > 64 * 1024 && !swr_raise_lds(reinterpret_cast<const void*>(routed_mmoe_eval_kernel), 150 * 1024)) return SWR_ERR_LAUNCH;
     hipLaunchKernelGGL(routed_mmoe_eval_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, RT_ROWS))), dim3(RT_THREADS), lds,
                        static_cast<hipStream_t>(stream), k);
     return swr_launch_status();

@@ -590,7 +590,12 @@ class EmbedGather(Function):
                     n_pieces = sum(sl[3] // 8 for i, sl in enumerate(plan.sparse) if i not in oh_set) + (len(plan.dense) + 7) // 8
                     # (the LAYOUT -- 16-column groups -- is taken whenever the lookup qualifies; FUSED_LOOKUP only chooses between the
                     # fused launches and the written block, so that the two can be compared bit for bit)
-                    fl_ok = (ctx.n_grad_slots == ns and n_pieces <= 32 and len(plan.dense) <= 32
+                    # (the limits of fl_build, csrc/first_layer.hip: at least one real piece, one-hot block <= 128 columns, 64 slots,
+                    # the bf16 shadows of the small tables below 1 GiB; what depends on the batch is checked per call -- swr_fl_layout)
+                    shadow_bytes = sum(sl[2] * (sl[3] // 8) * 48 for i, sl in enumerate(plan.sparse)
+                                       if i not in oh_set and weights[sl[0]].numel() * 4 <= plan.dense_limit_bytes)
+                    fl_ok = (ctx.n_grad_slots == ns and 1 <= n_pieces <= 32 and len(plan.dense) <= 32 and ns <= 64
+                             and (off + 15) // 16 * 16 <= 128 and shadow_bytes < (1 << 30) - (1 << 20)
                              and all(sl[3] % 8 == 0 and weights[sl[0]].is_contiguous() and weights[sl[0]].dtype == torch.float32
                                      and weights[sl[0]].data_ptr() % 16 == 0
                                      for i, sl in enumerate(plan.sparse) if i not in oh_set)
@@ -605,6 +610,8 @@ class EmbedGather(Function):
                 plan.ld = oh_col + oh_width
         fold = getattr(plan, "fold", None) if plan.oh else None
         fl = fold is not None and fold.get("fl", False) and B > 0
+        if fl and B * max(1, fold["Kp"] // 8) * 48 >= (1 << 32) - (1 << 24):
+            fl = False          # (a lane's 32-bit piece offset cannot reach the batch's gathered pieces: the written folded layout)
         # (fused lookup: nothing of the concat is written -- autograd carries a zero-stride placeholder of its shape)
         out = _zero_scalar(dev).expand(B, plan.ld) if fl else torch.empty((B, plan.ld), dtype=torch.float32, device=dev)
         sp = (H.SparseSlot * max(ns, 1))()
@@ -1444,7 +1451,7 @@ def _tower_backward(ctx, saved, dV=None, sel=None):
         dW1 = torch.empty((N, K), dtype=torch.float32, device=dev)
         db1 = torch.empty(N, dtype=torch.float32, device=dev)
     # one pass over dZ1 and x for all towers (csrc/tower.hip tower_dw_kernel) where the shape is built, else the grouped product
-    one_pass = (TOWER_DW and lib.swr_tower_dw_supported(K, Hd, G) and x.stride(1) == 1 and x.stride(0) % 4 == 0
+    one_pass = (TOWER_DW and M > 0 and lib.swr_tower_dw_supported(K, Hd, G) and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.data_ptr() % 16 == 0 and dW1.is_contiguous() and db1.is_contiguous())
     def launch_dw1():
         if one_pass:

@@ -54,24 +54,18 @@ def state_atol(case, key, n_steps):
         return 2e-5 + 0.1 * case.meta["lr"] * n_steps * n_steps
     if g is not None and g.size:
         # single elements with a near-zero gradient inside an ordinary weight: Adam's first update is lr u(g) with
-        # u(g) = g / (|g| + eps), which swings from -1 to 1 across |g| ~ eps.  The gradient itself is only pinned to
-        # delta = 2e-4 max|g| + 3e-7 (the gradient checks of these tests: fp32 summation order, split-bf16 products), so
-        # an element is pinned to lr times the most u can move within g +- delta -- elementwise; below 1e-8 wherever
-        # |g| > 1e-4.
-        eps = float(case.meta.get("eps", 1e-8))
-        g = g.astype(np.float64)
-        delta = 2e-4 * float(np.abs(g).max()) + 3e-7
-
-        def u(x):
-            return x / (np.abs(x) + eps)
-        swing = np.maximum(np.abs(u(g + delta) - u(g)), np.abs(u(g - delta) - u(g)))
-        swing = np.where(g == 0.0, 0.0, swing)                # exact zeros are structural (rows never looked up): no slack
-        return 2e-5 + case.meta["lr"] * n_steps * swing
+        # u(g) = g / (|g| + eps), which swings from -1 to 1 across |g| ~ eps; an element whose golden gradient is below 1e-6 in
+        # magnitude (the fp32 noise floor of these sums) may therefore differ by up to lr per step.  Only THOSE elements get the
+        # slack (elementwise), capped at lr * n_steps; assert_state_close also bounds how many of them may use it.
+        slack = np.where((np.abs(g) < 1e-6) & (g != 0.0), case.meta["lr"] * n_steps, 0.0)     # exact zeros are structural: no slack
+        return 2e-5 + slack
     return 2e-5
 
 
 def assert_state_close(got, want, case, key, n_steps, rtol=1e-4):
-    """np.testing.assert_allclose with state_atol's (possibly elementwise) absolute tolerance."""
+    """np.testing.assert_allclose with state_atol's (possibly elementwise) absolute tolerance.  Where the tolerance is
+    elementwise (Adam-step slack on near-zero gradients), at most 1e-3 of the elements (one element of a small tensor) may
+    actually need more than the base 2e-5."""
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, f"{key}: shape {got.shape} != {want.shape}"
     atol = state_atol(case, key, n_steps)
@@ -83,6 +77,9 @@ def assert_state_close(got, want, case, key, n_steps, rtol=1e-4):
         i = np.unravel_index(int(np.argmax(np.where(bad, err, -1.0))), want.shape) if want.ndim else ()
         raise AssertionError(f"{key}: {int(bad.sum())} / {want.size} elements beyond rtol={rtol}, atol~{float(np.max(atol)):.3g}; "
                              f"worst |err| {float(err[i]):.3e} at {i}: got {got[i]!r}, want {want[i]!r}")
+    if np.ndim(atol):
+        used = int((err > 2e-5 + rtol * np.abs(want)).sum())
+        assert used <= max(1, int(1e-3 * want.size)), f"{key}: {used} of {want.size} elements needed the near-zero-gradient slack"
 
 
 def oracle_features(schema):
@@ -244,5 +241,59 @@ class KinkTolerantGradCheck:
             f"grad {name}: relative l2 error {rel:.3e}, max error {err.max():.3e} (largest entry {top:.3e}, atol {atol:.3e})"
         self.kinked.append((name, int((err > atol).sum()), err.size, float(err.max())))
 
-    def finish(self):
-        assert len(self.kinked) <= max(2, self.n // 2), f"{len(self.kinked)} of {self.n} gradients off: {self.kinked[:8]}"
+    def finish(self, max_kinked=None):
+        """max_kinked: the number of tensors that may need the kink form -- 0 where the fixture was conditioned
+        (dekink_mmoe_state), else the measured count of the configuration; default: half of the tensors."""
+        cap = max(2, self.n // 2) if max_kinked is None else max_kinked
+        print(f"[kinks] {len(self.kinked)} of {self.n} gradients took the kink form (cap {cap}): {self.kinked[:6]}")
+        assert len(self.kinked) <= cap, f"{len(self.kinked)} of {self.n} gradients off (cap {cap}): {self.kinked[:8]}"
+
+
+def dekink_mmoe_state(state, features, hyper, x, margin=2e-5, window=2e-3):
+    """Condition an MMoE fixture so that NO ReLU unit of the step sits at its kink: returns a copy of `state` whose BatchNorm
+    betas in front of the ReLUs (experts, then towers) are shifted by less than `window` so that every sample's pre-activation is
+    at least `margin` away from zero (zero is moved into the middle of the widest gap between neighbouring pre-activations of
+    the unit; fp32 evaluation noise of a pre-activation is ~1e-6).  With such a state two correct evaluations cannot put a
+    sample on different sides of a kink, and the full-size gradients are pinned entry by entry again.
+    fp64 restatement of the forward pass of oracle/torch_port.py; test infrastructure only."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.nn import Sparse
+    st = {k: np.array(v, copy=True) for k, v in state.items()}
+    t64 = lambda k: torch.from_numpy(st[k].astype(np.float64))
+    sparse = [f for f in features if isinstance(f, Sparse)]
+    dense = [f for f in features if not isinstance(f, Sparse)]
+    emb = [F.embedding(torch.as_tensor(x[f.name]).long(), t64(f"embedding.embed_dict.{f.shared_with or f.name}.weight")) for f in sparse]
+    e = torch.cat(emb + [torch.as_tensor(x[f.name]).double().unsqueeze(1) for f in dense], dim=1)
+
+    def bn_linear(pre, inp):
+        z = F.linear(inp, t64(pre + ".mlp.0.weight"), t64(pre + ".mlp.0.bias"))
+        return F.batch_norm(z, None, None, t64(pre + ".mlp.1.weight"), t64(pre + ".mlp.1.bias"), True, 0.1, 1e-5)
+
+    def settle(pre, z):
+        """shift beta of every unit; returns the shifted pre-activations"""
+        zn = z.numpy()
+        beta = st[pre + ".mlp.1.bias"]
+        worst = np.inf
+        for n in range(zn.shape[1]):
+            col = np.sort(zn[:, n])
+            lo, hi = np.searchsorted(col, -window), np.searchsorted(col, window)
+            near = col[max(lo - 1, 0):hi + 1]
+            if near.size < 2:
+                continue                                       # nothing near the kink
+            gaps = np.diff(near)
+            j = int(np.argmax(gaps))
+            centre = 0.5 * (near[j] + near[j + 1])
+            shift = np.float32(-centre)
+            beta[n] = np.float32(beta[n] + shift)
+            zn[:, n] += float(shift)
+            worst = min(worst, float(np.abs(zn[:, n]).min()))
+        assert worst >= margin, f"{pre}: a pre-activation within {worst:.2e} of the kink after conditioning"
+        return torch.from_numpy(zn)
+
+    D, ne = hyper["domain_num"], hyper["n_expert"]
+    experts = torch.stack([torch.relu(settle(f"experts.{j}", bn_linear(f"experts.{j}", e))) for j in range(ne)], dim=1)
+    for d in range(D):
+        gate = torch.softmax(bn_linear(f"gates.{d}", e), dim=1).unsqueeze(-1)
+        settle(f"towers.{d}", bn_linear(f"towers.{d}", (gate * experts).sum(dim=1)))
+    return st

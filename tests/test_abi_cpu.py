@@ -202,3 +202,14 @@ def test_ctrtrainer_gpus_without_a_launcher_says_how_to_launch(monkeypatch):
     assert xs["a"].tolist() == [6, 7, 8] and ys.tolist() == torch.arange(12).chunk(4)[2].tolist()
     with pytest.raises(ValueError, match="split evenly"):
         tr._my_rows({"a": torch.arange(10)}, torch.arange(10))
+
+
+def test_no_kernel_spills_registers():
+    """tools/check_scratch.py: hipcc -Rpass-analysis=kernel-resource-usage over every csrc/*.hip -- no kernel of the library may
+    have ScratchSize > 0 (a spilled kernel moves its registers through HBM: bnmix_bwd lost 40 % to 108 bytes per lane in round 3;
+    gemm_rows_x6<8>, layernorm_bwd<4> and bnmix_bwd<8, 5> did until round 5).  Cross-compiles without a GPU (~3 min, 4 jobs)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_scratch.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -25,7 +25,7 @@ import pytest
 import torch
 
 import bench
-from _golden import KinkTolerantGradCheck, assert_probs_close, logit, perturb_product
+from _golden import KinkTolerantGradCheck, assert_probs_close, dekink_mmoe_state, logit, perturb_product
 from oracle.nn import Dense, Sparse
 from oracle.optim import Adam
 from test_baseline_shapes_gpu import mix64, oracle_for, run_config
@@ -75,6 +75,10 @@ def test_cfg2_full():
     state0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     batches = [bench.synth_batch(cfg, B, seed=4000 + j) for j in range(5)]       # 0-3 train (0 twice: warm-up), 4 probes
     feats = [Dense(f"d{i}") for i in range(cfg["n_dense"])] + [Sparse(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
+    # part A's state: no ReLU unit of the step on batch 0 within 2e-5 of its kink (13.6 M pre-activations; BatchNorm betas moved
+    # by < 2e-3) -- every gradient entry is then pinned, no "kink" allowance (_golden.dekink_mmoe_state)
+    state0 = dekink_mmoe_state(state0, feats, cfg["hyper"], batches[0][0])
+    model = _cfg2_model(state0)
     big = "embedding.embed_dict.s1.weight"
 
     def to_dev(j):
@@ -109,7 +113,7 @@ def test_cfg2_full():
         else:
             got = prm.grad.cpu().numpy()
         kinks.check(got, g, 3e-4 * float(np.abs(g).max()) + 3e-9, k)
-    kinks.finish()
+    kinks.finish(max_kinked=0)
     trainer.optimizer.step()
     port.step(*batches[0], lr=LR, weight_decay=WD)
     torch.cuda.synchronize()

@@ -28,6 +28,22 @@ def per_kernel(path):
 def main():
     sq, n = per_kernel(sys.argv[1])
     gui, _ = per_kernel(sys.argv[2])
+    if len(sys.argv) > 4 and sys.argv[3] == "--json":
+        import datetime
+        import json
+        import socket
+        res = {}
+        for k, c in sq.items():
+            g = gui.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0)
+            if g < 2000:
+                continue
+            wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            res[k] = {"launches": n[k], "gui_cycles": g, "mfma_busy": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 128.0),
+                      "wait": c.get("SQ_WAIT_ANY", 0) / wc, "valu": c.get("SQ_ACTIVE_INST_VALU", 0) / wc}
+        json.dump({"source": "rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE (separate passes) over bench.py; mfma_busy = "
+                             "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)",
+                   "collected": {"utc": datetime.datetime.utcnow().isoformat(timespec="seconds"), "host": socket.gethostname()},
+                   "kernels": res}, open(sys.argv[4], "w"), indent=1)
     print(f"{'kernel':<56} {'launches':>8} {'gui_cycles':>11} {'mfma_busy':>9} {'wait':>6} {'stall':>6} {'issue':>6} {'valu':>6} {'lds':>6}")
     order = sorted(sq, key=lambda k: -gui.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0))
     for k in order:

@@ -30,7 +30,16 @@ def main():
         fk, wk = f.get(k, (0.0, 0))[0], w.get(k, (0.0, 0))[0]
         res[k] = {"fetch_size_kib_raw": fk, "write_size_kib_raw": wk,
                   "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches": f.get(k, w.get(k))[1]}
+    import datetime
+    import socket
+    import subprocess
+    try:
+        gpu = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
+        gpu = next((l.split(":", 1)[1].strip() for l in gpu.split("\n") if "Marketing Name" in l and "Instinct" in l), "")
+    except Exception:
+        gpu = ""
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py",
+               "collected": {"utc": datetime.datetime.utcnow().isoformat(timespec="seconds"), "host": socket.gethostname(), "gpu": gpu},
                "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
                "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():

@@ -19,7 +19,8 @@ python tools/pmc_to_json.py $(find $O/pmc_${T}_fetch -name "*.db" | head -1) $(f
 rm -rf $O/pmc_${T}_fetch $O/pmc_${T}_write
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/pmc_${T}_sq -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_${T}_sq.log 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc_${T}_gui -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_${T}_gui.log 2>&1
-python tools/pmc_mfma_summary.py $(find $O/pmc_${T}_sq -name "*.db" | head -1) $(find $O/pmc_${T}_gui -name "*.db" | head -1) > $O/${T}_pmc_mfma.txt
+python tools/pmc_mfma_summary.py $(find $O/pmc_${T}_sq -name "*.db" | head -1) $(find $O/pmc_${T}_gui -name "*.db" | head -1) --json $O/${T}_pmc_mfma.json > $O/${T}_pmc_mfma.txt
+cp $O/${T}_pmc_mfma.json profiles/pmc_mfma_latest.json
 rm -rf $O/pmc_${T}_sq $O/pmc_${T}_gui
 cp $O/${T}_pmc_hbm.json profiles/pmc_hbm_latest.json
 timeout 400 python bench.py --steps 20 --warmup 5 > $O/${T}_bench.json 2> $O/${T}_bench.err
