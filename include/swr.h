@@ -396,6 +396,9 @@ typedef struct {
     int64_t c2_from;
 } swr_gemm_tn_args;
 
+/* out[g][k][n] = in[g][n][k] for `groups` contiguous [N, K] matrices: the transposed weights of a (grouped) Linear, the operand of its
+ * dX product dZ W in the [N, K] layout swr_gemm_nt's bf16-split kernel stages (`basic/layers.py:253` under autograd). */
+int swr_transpose_groups(const float* in, int groups, int N, int K, float* out, void* stream);
 size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args_host);
 int swr_gemm_tn(const swr_gemm_tn_args* args_host, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -655,6 +655,30 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     return swr_launch_status();
 }
 
+// out[g][k][n] = in[g][n][k]: the transposed weights of a (grouped) layer, the operand of its dX product in the [N, K] layout the
+// bf16-split kernel stages (replaces an ATen strided copy per layer and step)
+__global__ __launch_bounds__(256) void transpose_groups_kernel(const float* __restrict__ in, int N, int K, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z, n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + static_cast<int64_t>(g) * N * K;
+    float* dst = out + static_cast<int64_t>(g) * N * K;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < N && k0 + tx < K) tile[r][tx] = src[static_cast<int64_t>(n0 + r) * K + k0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < K && n0 + tx < N) dst[static_cast<int64_t>(k0 + r) * N + n0 + tx] = tile[tx][r];
+}
+
+extern "C" int swr_transpose_groups(const float* in, int groups, int N, int K, float* out, void* stream) {
+    SWR_REQUIRE(in && out && groups >= 1 && N >= 1 && K >= 1 && groups <= 65535, SWR_ERR_ARG);
+    hipLaunchKernelGGL(transpose_groups_kernel, dim3(static_cast<unsigned>((K + 31) / 32), static_cast<unsigned>((N + 31) / 32),
+                                                      static_cast<unsigned>(groups)), dim3(256), 0, static_cast<hipStream_t>(stream), in, N, K, out);
+    return swr_launch_status();
+}
+
 extern "C" int swr_gemm_nt(const swr_gemm_args* args, void* stream) { return launch_rows<true>(args, stream); }
 extern "C" int swr_gemm_nn(const swr_gemm_args* args, void* stream) { return launch_rows<false>(args, stream); }
 
@@ -2067,8 +2091,28 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
     return swr_launch_status();
 }
 
+// a grouped product whose groups each go through the bf16-split kernel (one launch per group, swr_gemm_tn)
+static bool tn_groups_as_x6(const swr_gemm_tn_args& a) {
+    if (a.groups <= 1 || a.C2 || !use_x6() || use_bf16()) return false;
+    swr_gemm_tn_args one = a;
+    one.groups = 1;
+    // measured at config 5 (8 groups of [32 768, 128]^T x [32 768, 256]): 144 us + a 40 us reduction per group against 286 us for the
+    // grouped f32-MFMA launch -- the blocked bf16-split kernel is built for ONE wide product; off unless SWR_TN_GROUPS_X6=1
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SWR_TN_GROUPS_X6"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (!on || !tn_x6_ok(one) || 2.0 * a.M * a.K1 * a.K2 < 1.0e9) return false;
+    for (int g = 1; g < a.groups; ++g)
+        if (((reinterpret_cast<uintptr_t>(a.A + g * a.gsA) | reinterpret_cast<uintptr_t>(a.B + g * a.gsB)) & 7u) != 0) return false;
+    return true;
+}
+
 extern "C" size_t swr_gemm_tn_workspace_bytes(const swr_gemm_tn_args* args) {
     if (!args || args->M <= 0 || args->K1 <= 0 || args->K2 <= 0 || args->groups < 1) return 0;
+    if (tn_groups_as_x6(*args)) {
+        swr_gemm_tn_args one = *args;
+        one.groups = 1;
+        return swr_gemm_tn_workspace_bytes(&one);
+    }
     int ta, splits;
     int64_t rps;
     if (tn_x6_ok(*args))
@@ -2088,6 +2132,19 @@ extern "C" int swr_gemm_tn(const swr_gemm_tn_args* args, void* workspace, size_t
     if (a.C2) SWR_REQUIRE(a.groups == 1 && a.c2_from > 0 && a.c2_from < a.K2 && a.ldc >= a.c2_from && a.ldc2 >= a.K2 - a.c2_from, SWR_ERR_ARG);
     else SWR_REQUIRE(a.ldc >= a.K2, SWR_ERR_ARG);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (tn_groups_as_x6(a)) {
+        // grouped layers (the D per-domain layers of a LayerBank): the bf16-split kernel takes one group per launch -- 2.7 x the
+        // matrix rate of the grouped f32-MFMA kernel where a group is worth a launch of its own; same workspace, stream-ordered
+        swr_gemm_tn_args one = a;
+        one.groups = 1; one.gsA = one.gsB = one.gsC = one.gsColsum = 0;
+        for (int g = 0; g < a.groups; ++g) {
+            one.A = a.A + g * a.gsA; one.B = a.B + g * a.gsB; one.C = a.C + g * a.gsC;
+            one.colsum = a.colsum ? a.colsum + g * a.gsColsum : nullptr;
+            const int rc = swr_gemm_tn(&one, workspace, workspace_bytes, stream);
+            if (rc != SWR_OK) return rc;
+        }
+        return SWR_OK;
+    }
     TnK kk;
     kk.a = a;
     if (a.M == 0 && a.C2) {

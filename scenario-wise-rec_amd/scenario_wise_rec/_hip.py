@@ -225,6 +225,7 @@ _SIGS = {
     "swr_fl_dw": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _Z, _P]),
     "swr_fl_dw_bn_supported": (C.c_int, [_P, _L, _L]),
     "swr_dw_tr_mode": (C.c_int, [_I]),
+    "swr_transpose_groups": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "swr_fl_dw_bn": (C.c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _Z, _P]),
     "swr_adam_catchup_multi": (C.c_int, [_P, _I, _P, _P, _P]),
     "swr_adam_rows_multi": (C.c_int, [_P, _I, _P, _P]),
