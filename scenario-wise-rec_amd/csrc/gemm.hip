@@ -1847,8 +1847,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnK kk) {
 // the same fixed-order sum for MANY partial matrices (the wide kernel writes one per CU: 256 x 184 KB at config 2): a thread
 // owns four consecutive outputs (16-byte loads), 16 threads share them and take partials sub, sub + 16, ... (8 loads in
 // flight), their sums are added in sub order through LDS.  tn_reduce_kernel<32> reads 32-byte runs: 27 us for the 47 MB.
+#ifndef TN_RED4_SUBS
+#define TN_RED4_SUBS 16
+#endif
 __global__ __launch_bounds__(256) void tn_reduce4_kernel(const TnK kk) {
-    constexpr int SUBS = 16, OUT4 = 256 / SUBS;      // 16 float4 columns = 64 outputs per workgroup
+    constexpr int SUBS = TN_RED4_SUBS, OUT4 = 256 / SUBS;      // 16 float4 columns = 64 outputs per workgroup
     __shared__ float4 red[256];
     const swr_gemm_tn_args& a = kk.a;
     const int64_t n4 = static_cast<int64_t>(a.K1) * a.K2 / 4;
@@ -1920,7 +1923,7 @@ static bool tn_reduce4_ok(const TnK& kk) {
 }
 static void tn_reduce4(const TnK& kk, hipStream_t st) {
     const int64_t n4 = static_cast<int64_t>(kk.a.K1) * kk.a.K2 / 4;
-    hipLaunchKernelGGL(tn_reduce4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n4, 16))), dim3(256), 0, st, kk);
+    hipLaunchKernelGGL(tn_reduce4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n4, 256 / TN_RED4_SUBS))), dim3(256), 0, st, kk);
 }
 
 static int tn_plan(const swr_gemm_tn_args& a, int& ta, int& splits, int64_t& rps) {

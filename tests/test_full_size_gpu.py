@@ -272,21 +272,26 @@ def test_cfg5_full_tables():
     _full_table_case(5, 512, {"s0": 0x2545F491, "s1": 0x9E3779B1})
 
 
-def _captured_lazy_equals_eager_sweep(n, n_steps=4):
+def _captured_lazy_equals_eager_sweep(n, n_steps=4, keep_device_init=False):
     """Config n at its full size: two eager warm-up steps + capture + replays over rotating batches with lazily updated rows
     == the same steps launched eagerly with a dense Adam sweep over every table, BITWISE (state and loss sequence)."""
     from scenario_wise_rec import _hip as H
     from scenario_wise_rec.trainers import CTRTrainer
     from scenario_wise_rec.trainers.graph import GraphedStep
     cfg = copy.deepcopy(bench.CONFIGS[n])
-    cfg.pop("on_device_init", None)
+    if not keep_device_init:
+        cfg.pop("on_device_init", None)
     B = cfg["batch"]
     batches = [bench.synth_batch(cfg, B, seed=7100 + 10 * n + j) for j in range(n_steps - 1)]
     dev = [({k: torch.from_numpy(v).cuda() for k, v in x.items()}, torch.from_numpy(y).cuda()) for x, y in batches]
     order = [0, 0] + list(range(1, n_steps - 1))                     # batch 0 twice (the warm-up steps), then the others
 
     def run(lazy, graphed):
-        model, _feats = bench.build_model(cfg, seed=17)
+        if cfg.get("on_device_init"):                     # 2 x 50 M rows x 64: initialised in HBM (12.8 GB each)
+            with torch.device("cuda"):
+                model, _feats = bench.build_model(cfg, seed=17)
+        else:
+            model, _feats = bench.build_model(cfg, seed=17)
         perturb_product(model, 43)
         tr = CTRTrainer(model, f"cfg{n}-full", optimizer_params={"lr": LR, "weight_decay": WD, "lazy_rows": lazy}, device="cuda")
         tr.use_graph = False
@@ -303,12 +308,87 @@ def _captured_lazy_equals_eager_sweep(n, n_steps=4):
             losses = losses[2:]
         torch.cuda.synchronize()
         H.check_errors()
-        return {k: v.cpu().numpy() for k, v in model.state_dict().items()}, losses
+        if hasattr(model, "materialize"):
+            model.materialize()                           # lazily updated rows brought up to date
+            torch.cuda.synchronize()
+        # (tensors above 1 GiB stay on the device: a 64-bit checksum pair per tensor instead of 12.8 GB through host memory)
+        out = {}
+        for k, v in model.state_dict().items():
+            if v.numel() * v.element_size() > (1 << 30):
+                flat, s1, s2 = v.detach().reshape(-1).view(torch.int32), 0, 0
+                for c0 in range(0, flat.numel(), 1 << 27):
+                    w = flat[c0:c0 + (1 << 27)].to(torch.int64)
+                    idx = torch.arange(c0, c0 + w.numel(), device=w.device, dtype=torch.int64)
+                    s1 += int(w.sum())
+                    s2 += int((w * ((idx % 1000003) + 1)).sum())
+                out[k] = np.array([s1 % (1 << 62), s2 % (1 << 62)], dtype=np.int64)
+            else:
+                out[k] = v.cpu().numpy()
+        del model, tr
+        torch.cuda.empty_cache()
+        return out, losses
     got, losses = run(True, True)
     ref, ref_losses = run(False, False)
     assert losses == ref_losses
     for k in ref:
-        assert np.array_equal(got[k], ref[k]), f"{k}: captured + lazy differs from eager + sweep (max {np.abs(got[k].astype(np.float64) - ref[k]).max():.3e})"
+        assert np.array_equal(got[k], ref[k]), f"{k}: captured + lazy differs from eager + sweep"
+
+
+def _shard_case(n, hash_seeds, n_slice=2048):
+    """Config n at the shard bench.py runs (batch 32 768 of BASELINE config 5's 262 144 / 8, both 50 M-row tables at full size):
+    (a) captured + lazily updated rows == eager + dense Adam sweep, BITWISE, over rotating batches (the benched regime);
+    (b) the product path against the fp64 oracle on a 2 048-row slice of a batch of that shard: eval-mode probabilities within
+        1e-4 in the logit and the BCE loss, with the oracle holding the COMPACTED rows of the big tables (the rows the slice
+        looks up, gathered from the device tables; exact -- a row's value does not depend on the others)."""
+    from scenario_wise_rec import _hip as H
+    cfg = copy.deepcopy(bench.CONFIGS[n])
+    assert cfg["batch"] == 32768
+    _captured_lazy_equals_eager_sweep(n, keep_device_init=True)
+    with torch.device("cuda"):
+        model, feats = bench.build_model(cfg, seed=13)
+    perturb_product(model, 41)
+    for f in feats:
+        if f.name in hash_seeds:
+            f.hash_seed = hash_seeds[f.name]
+    x, y = bench.synth_batch(cfg, cfg["batch"], seed=900 + n)
+    rng = np.random.default_rng(n)
+    for name in hash_seeds:
+        x[name] = rng.integers(0, 1 << 40, size=cfg["batch"], dtype=np.int64)
+    xs = {k: v[:n_slice] for k, v in x.items()}
+    ys = y[:n_slice]
+    model.eval()
+    with torch.no_grad():
+        p = model({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in xs.items()}).cpu().numpy()
+    torch.cuda.synchronize()
+    H.check_errors()
+    V = {f.name: f.vocab_size for f in feats if hasattr(f, "vocab_size")}
+    named = dict(model.named_parameters())
+    state0, xo, ocfg = {}, dict(xs), copy.deepcopy(cfg)
+    big_keys = {}
+    for name, seed in hash_seeds.items():
+        rows = (mix64(xs[name].astype(np.uint64) ^ np.uint64(seed)) % np.uint64(V[name])).astype(np.int64)
+        compact = np.unique(rows)
+        key = next(k for k in named if k.endswith(f"embed_dict.{name}.weight"))
+        big_keys[key] = named[key].detach()[torch.from_numpy(compact).cuda()].cpu().numpy().copy()
+        xo[name] = np.searchsorted(compact, rows)
+        ocfg["vocabs"][int(name[1:])] = len(compact)
+    for k, v in model.state_dict().items():
+        state0[k] = big_keys[k] if k in big_keys else v.detach().cpu().numpy().copy()
+    om = oracle_for(ocfg, state0)
+    op = om.predict(xo)
+    assert_probs_close(p, op, tol=1e-4)
+    bce = lambda q: float(-np.mean(ys * np.log(np.clip(q, 1e-38, None)) + (1 - ys) * np.log(np.clip(1 - q, 1e-38, None))))
+    assert abs(bce(p.astype(np.float64)) - bce(op.astype(np.float64))) < 2e-6 * max(1.0, abs(bce(op.astype(np.float64))))
+
+
+def test_cfg5_shard():
+    """HamurSmall at bench.py --config 5's shard (batch 32 768, 2 x 50 M hashed rows x 64)."""
+    _shard_case(5, {"s0": 0x2545F491, "s1": 0x9E3779B1})
+
+
+def test_cfg6_shard():
+    """PPNet at bench.py --config 6's shard (batch 32 768, the same tables)."""
+    _shard_case(6, {"s0": 0x5DEECE66, "s1": 0xB5297A4D})
 
 
 def test_cfg3_full():
