@@ -413,8 +413,13 @@ def main():
     print(f"[bench] timed region done: {ms:.3f} ms/step", file=sys.stderr, flush=True)
     roof = None
     if not args.no_roofline:
-        roof = measure_roofline(cfg, model, trainer, x, dev, args.steps, B) if args.config == 2 else \
-            gather_roofline(cfg, model, x, dev, args.steps, B, args.config)
+        if args.config == 2:
+            roof = measure_roofline(cfg, model, trainer, x, dev, args.steps, B)
+        else:
+            # the other configurations: primary = the widest product of THEIR step (the kernel class that bounds it), timed
+            # stand-alone at the step's shapes; the lookup beside it
+            roof = product_roofline(cfg, dev, args.steps, B, args.config, ms)
+            roof.setdefault("also", {})["gather"] = gather_roofline(cfg, model, x, dev, args.steps, B, args.config)
         if roof is not None:
             roof.setdefault("also", {})["step"] = step_roofline(ms, args.config)
     out = {
@@ -658,6 +663,66 @@ def measure_roofline(cfg, model, trainer, x, dev, iters, B):
         roof["gather_hbm_frac_of"] = "fl_keys_kernel + fl_fwd_kernel: executed bytes of both / time of both / 8 TB/s"
     roof["expert_mfma_busy"] = mfma_busy_source()
     return roof
+
+
+def widest_products(cfg):
+    """The products of the widest layer of a configuration's step -- (label, K, N, launches per step) with N the stacked output
+    width the step multiplies in ONE launch (all domains / experts side by side) -- and the minimal forward flops per sample of
+    the whole dense part (SURVEY.md 8d's count: 2 K N per Linear, train step ~ 3 x forward)."""
+    e, fs, fd, h = cfg["embed_dim"], len(cfg["vocabs"]), cfg["n_dense"], cfg["hyper"]
+    k0 = fs * e + fd
+    fam = cfg["family"]
+    if fam == "SharedBottom":
+        return "bottom layer %d -> %d" % (k0, h["bottom_params"]["dims"][0]), k0, h["bottom_params"]["dims"][0]
+    if fam == "Star":
+        return "first FCN layer of the %d domains, %d -> %d each" % (h["num_domains"], k0, h["fcn_dims"][0]), k0, h["num_domains"] * h["fcn_dims"][0]
+    if fam == "PLE":
+        ne = h["domain_num"] * h["n_expert_specific"] + h["n_expert_shared"]
+        return "first layer of the %d experts, %d -> %d each" % (ne, k0, h["expert_params"]["dims"][0]), k0, ne * h["expert_params"]["dims"][0]
+    if fam in ("HamurSmall", "HamurLarge"):
+        return "first backbone layer of the %d domains, %d -> %d each" % (h["domain_num"], k0, h["fcn_dims"][0]), k0, h["domain_num"] * h["fcn_dims"][0]
+    if fam == "PPNet":
+        return "first tower layer of the %d domains, %d -> %d each" % (h["domain_num"], k0, h["fcn_dims"][0]), k0, h["domain_num"] * h["fcn_dims"][0]
+    return "first layer", k0, 128
+
+
+def product_roofline(cfg, dev, iters, B, config, ms_per_step):
+    """Roofline primary of configurations 1, 3-6: the forward product of the step's widest layer, [B, K] x [K, N] with the
+    BatchNorm partials in its epilogue, launched through ops.gemm exactly as basic/layers.LayerBank launches it (bf16-split
+    kernel gemm_rows_x6_kernel: six bf16 MFMA products per fp32 product), timed stand-alone with HIP events over graph-captured
+    launches, four rotating operand sets.  `achieved` = algorithmic flops 2 B K N / time against the dense bf16 MFMA peak."""
+    from scenario_wise_rec import ops
+    label, K, N = widest_products(cfg)
+    g = torch.Generator(device=dev).manual_seed(5)
+    Kp = (K + 3) // 4 * 4
+    sets = [(torch.randn(B, Kp, device=dev, generator=g), torch.empty(B, N, device=dev)) for _ in range(4)]
+    W = torch.randn(N, Kp, device=dev, generator=g) * 0.05
+    bias = torch.zeros(N, device=dev)
+    parts = torch.empty(((B + 31) // 32, N, 2), device=dev)
+    st = {"i": 0}
+
+    def launch():
+        A, Z = sets[st["i"] % 4]
+        st["i"] += 1
+        ops.gemm("nt", A, W, Z, B, N, K, bias=bias, stat_partials=parts, lda=Kp, ldb=Kp)
+    stream = torch.cuda.Stream()
+    ms = time_kernel_events(launch, max(10, iters), stream)
+    x6 = os.environ.get("SWR_GEMM", "")[:1].lower() != "f"
+    peak = BF16_MFMA_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
+    alg = 2.0 * B * K * N
+    tf = alg / (ms * 1e-3) / 1e12
+    tiles = (N + 31) // 32
+    nblk = (tiles + 6) // 7
+    nt = (tiles + nblk - 1) // nblk
+    nbytes = 4.0 * B * (nblk * K + N)              # A is read once per column block, Z written once
+    return {"kernel": "gemm_rows_x6_kernel<%d> (forward product of the widest layer: %s)" % (nt, label), "bound": "mfma",
+            "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "algorithmic_flops_per_launch": alg,
+            "executed_bytes_per_launch": nbytes, "avg_launch_ms": ms, "shape": f"[{B}, {K}] x [{K}, {N}]",
+            "mfma_issue_util": (6.0 if x6 else 1.0) * tf / peak, "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "share_of_step": "this launch and its two backward counterparts (dX, dW: the same flops each) ~ %.0f %% of the step"
+                             % (100.0 * 3 * ms / ms_per_step),
+            "traffic": pmc_traffic("void gemm_rows_x6_kernel<%d" % nt, config), "traffic_source": pmc_source(config),
+            "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (null if not collected)"}
 
 
 def _pmc_file(config):

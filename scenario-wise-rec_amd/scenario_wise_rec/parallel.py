@@ -27,6 +27,12 @@ from . import ops
 
 
 
+# The captured data-parallel step is ONE hipGraph with the RCCL collectives inside it wherever the process group runs over RCCL
+# (world 1 over RCCL, same box: 0.470 -> 0.428 ms per step at config 2, i.e. 1.27 x -> 1.16 x the single-GPU step); gloo collectives
+# are host-synchronous and cannot be captured: three graphs with eager collectives between them (the multi-process tests on one GPU)
+ONE_GRAPH = os.environ.get("SWR_DP_ONE_GRAPH", "auto")      # "auto": one graph over RCCL (nccl backend), three with gloo; "0" / "1" force
+
+
 def allreduce_min_bytes():
     """Gradient arenas above this size are ALL-REDUCED (SURVEY.md 8e / north star: "a single RCCL all-reduce over xGMI on
     the dense parameters") instead of all-gathered and summed locally: an all-gather delivers N x arena bytes to every
@@ -324,6 +330,14 @@ class DataParallelStep(object):
         if hasattr(opt, "hist_cap") and 2 * opt._since_flush >= opt.hist_cap:
             opt.materialize()
         snap = opt.host_counts() if hasattr(opt, "host_counts") else None
+        one = ONE_GRAPH == "1" or (ONE_GRAPH == "auto" and dist.get_backend(self.group) == "nccl")
+        if one:
+            try:
+                return self._capture_one(snap)
+            except Exception as e:                  # noqa: BLE001  (a runtime that cannot capture its collectives)
+                import sys
+                print(f"[parallel] one-graph capture failed ({type(e).__name__}: {e}); three graphs", file=sys.stderr)
+                torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events while this thread captures; in the default (global) mode
         # that poll would invalidate the capture
@@ -357,6 +371,40 @@ class DataParallelStep(object):
         self.loss = loss
         return self
 
+    def _capture_one(self, snap):
+        """The whole data-parallel step as ONE hipGraph, collectives included (SWR_DP_ONE_GRAPH=1): the rows all-gather is captured
+        on a side stream (a parallel branch of the graph: it overlaps the held-back gradient work), the arena collective on the
+        main stream behind that work, then merge + mean + optimizer.  One launch per step instead of three graph launches with
+        eager collectives and cross-stream waits between them."""
+        opt = self.trainer.optimizer
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            cur = torch.cuda.current_stream()
+            loss = self._forward_backward(self.x, self.y)
+            ops.join_side_streams()
+            arena, big, sparse = self._sparse()
+            xb = self._exchange_buffers(arena["g"], big, sparse)                # established by the warm-up steps
+            rows = bool(xb["offs"])
+            if rows:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group)
+                    self._merge_rows(xb, big)
+            ops.run_late_jobs()
+            ops.join_side_streams()
+            self._send_dense(xb, arena["g"], pack=True)
+            if rows:
+                cur.wait_stream(side)
+            self._mean_dense(xb, arena["g"])
+            opt.step()
+        if snap is not None:
+            opt.restore_host_counts(snap)
+        self._graphs = (g, None, None, xb)
+        self._big, self._arena_g = big, arena["g"]
+        self.loss = loss
+        return self
+
     def load(self, x_dict, y):
         from .trainers.graph import load_batch
         load_batch(self.x, self.y, x_dict, y)
@@ -370,6 +418,8 @@ class DataParallelStep(object):
         if getattr(self.trainer.optimizer, "clear_grads", False) and hasattr(model, "arena_dirty") and model.arena_dirty():
             model.zero_grad()              # (the captured step holds no fill: trainers/graph.py GraphedStep.replay)
         g1.replay()
+        if g1b is None:                    # one graph holds the whole step (SWR_DP_ONE_GRAPH)
+            return self.loss
         rows = bool(xb["offs"])
         if rows:
             # the row lists leave now, while the rest of the gradients is computed -- but the collective is ENQUEUED after the

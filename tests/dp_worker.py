@@ -63,7 +63,12 @@ def dump_gradients(model):
 def main():
     mode, name, out_dir = sys.argv[1:4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DP_WORKER_BACKEND", "gloo")      # "nccl": RCCL (one rank per GPU: world 1 on a one-GPU box)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     if mode == "torch-only":
         # control experiment of tools/dp8_soak.py: the SAME process topology (`world` processes on cuda:0, gloo collectives
         # over device tensors) running nothing but PyTorch's own kernels -- libswr is never loaded.  A runtime GPU fault

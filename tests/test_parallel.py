@@ -144,6 +144,20 @@ def test_two_rank_captured_step_matches_eager(limit, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("limit", [None, 2048], ids=["dense", "rows"])
+def test_one_graph_step_over_rccl_matches_eager(limit):
+    """Over RCCL the captured data-parallel step is ONE hipGraph with both collectives inside it (parallel._capture_one; the
+    rows all-gather on a parallel branch).  World size 1 over the nccl backend -- what a one-GPU box can run of the real
+    transport: two eager warm-up steps + capture + one replay land bitwise where three eager steps land."""
+    extra = () if limit is None else (str(limit),)
+    env = {"DP_WORKER_BACKEND": "nccl", "SWR_DP_ONE_GRAPH": "1"}
+    a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 1, extra=extra, env_extra=env), "state1.npz"))
+    b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 1, extra=extra, env_extra=dict(env, DP_EAGER_REFERENCE="1")), "state1.npz"))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
 def test_ctrtrainer_gpus_argument_runs_data_parallel():
     """`CTRTrainer(gpus=[0, 1])` (reference: single-process nn.DataParallel, ctr_trainer.py:45-47) = one process per GPU
     here: every process feeds the WHOLE batch, rank r trains on row chunk r.  One epoch of one batch lands on the
