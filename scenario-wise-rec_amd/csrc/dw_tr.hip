@@ -385,7 +385,11 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
     // otherwise sinks the piece-offset loads behind the dY / Z loads, and the wait for an offset then waits for all of those.
     // End of stage: waves 0-3 issued their dY / Z loads before the products (everything has landed: vmcnt(0)); waves 4-7 issue them
     // last and leave them in flight (vmcnt retires in order: "all but the last 2 NZ" = the copies have landed).
-    constexpr int N_LATE = W < 4 ? 0 : 2 * NZ;
+#ifndef DT_ROLE
+#define DT_ROLE 0            // 0: waves 0-3 split first; 1: waves 4-7 split first; 2: all split first; 3: all multiply first (experiments)
+#endif
+    constexpr bool SPLIT_FIRST = DT_ROLE == 0 ? (W < 4) : (DT_ROLE == 1 ? (W >= 4) : DT_ROLE == 2);
+    constexpr int N_LATE = SPLIT_FIRST ? 0 : 2 * NZ;
     for (int st = 0; st < n_stages; ++st) {
         dt_lds cur = lds + (st & 1) * C::BUF, nxt = lds + ((st + 1) & 1) * C::BUF;
         const bool more = st + 1 < n_stages;
@@ -421,7 +425,7 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
             __builtin_amdgcn_sched_barrier(0);
 #endif
         };
-        if (W < 4) {
+        if (SPLIT_FIRST) {
             stage_dz();
             request_dz();
             DT_FINE(1);
@@ -437,7 +441,7 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
 #pragma unroll
         for (int j = 0; j < NA; ++j) vo[j] = vo_next[j];
 #endif
-        if (W >= 4) {
+        if (!SPLIT_FIRST) {
             stage_dz();
             request_dz();
         }

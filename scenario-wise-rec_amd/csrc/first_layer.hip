@@ -19,6 +19,7 @@
 // HBM traffic at config 2 (B = 65 536): keys launch ~17 MB of ids in, ~25 MB out; forward ~45 MB in (mostly L2 hits on
 // the shadows) + 38.8 MB of Z out -- against 72 MB written + 72 MB re-read for A' before.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "rows_epilogue.h"
@@ -621,7 +622,12 @@ extern "C" int swr_fl_keys(const swr_fl_plan* plan, void* workspace, uint32_t* e
     hipStream_t st = static_cast<hipStream_t>(stream);
     bool f32 = true;
     for (int s = 0; s < plan->n_dense; ++s) f32 = f32 && plan->dense_host[s].dtype == SWR_F32;
-    const int sg = plan->B >= 32768 ? 4 : 1;
+    int sg = plan->B >= 32768 ? 4 : 1;
+    {
+        static int force = -1;                      // SWR_FLK_SG=1|2|4: sample groups per workgroup (experiments)
+        if (force < 0) { const char* e = getenv("SWR_FLK_SG"); force = e ? atoi(e) : 0; }
+        if (force == 1 || force == 2 || force == 4) sg = force;
+    }
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(plan->B, FLK_TILE * sg)));
     const unsigned lds = static_cast<unsigned>(sg) * plan->n_sparse * FLK_TILE * sizeof(uint32_t);
 #define FLK_GO(SGV)                                                                                                              \
@@ -631,6 +637,7 @@ extern "C" int swr_fl_keys(const swr_fl_plan* plan, void* workspace, uint32_t* e
         else hipLaunchKernelGGL((fl_keys_kernel<0, 0, SGV>), grid, dim3(FL_THREADS * SGV), lds, st, a);                           \
     } while (0)
     if (sg == 4) FLK_GO(4);
+    else if (sg == 2) FLK_GO(2);
     else FLK_GO(1);
 #undef FLK_GO
     return swr_launch_status();

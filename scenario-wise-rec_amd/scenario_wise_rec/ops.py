@@ -253,7 +253,12 @@ def _fork_extras():
         if ent.get("sel") is not None:
             torch.index_select(ent["src"].t(), 0, ent["sel"], out=ent["buf"])
         else:
-            ent["buf"].copy_(ent["src"].t())
+            src = ent["src"]
+            if src.is_contiguous() and src.dtype == torch.float32 and src.dim() == 2:
+                H.check(lib.swr_transpose_groups(H.ptr(src), 1, src.shape[0], src.shape[1], H.ptr(ent["buf"]), H.stream()),
+                        "swr_transpose_groups")              # (was an ATen strided copy per layer and step)
+            else:
+                ent["buf"].copy_(src.t())
         ent["epoch"] = _side["epoch"]
     if needed:
         _side["extras_ev"] = torch.cuda.Event()
