@@ -2055,6 +2055,11 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
         t.ws = g.tr_ws; t.voff = g.tr_voff; t.mask_t = g.tr_mask_t; t.NR = g.tr_nr;
         t.part = kk.part; t.part_cs = kk.part_cs; t.k2p = kk.k2p;
         t.rows_per_split = std::max<int64_t>(128, (kk.rows_per_split + 31) / 32 * 32);       // (never more splits than planned)
+        {
+            static int64_t force = -1;              // SWR_DW_TR_ROWS: rows per split (experiments: fewer, longer splits)
+            if (force < 0) { const char* e = getenv("SWR_DW_TR_ROWS"); force = e ? atoll(e) : 0; }
+            if (force >= t.rows_per_split && force % 32 == 0) t.rows_per_split = force;
+        }
         t.n_splits = static_cast<int>(swr_ceil_div(a.M, t.rows_per_split));
         const int rc = dw_tr_launch(t, st);
         if (rc != SWR_OK) return rc;

@@ -163,7 +163,14 @@ def _mark_touched(params):
 #    straight into the gradient arena is forked after dX is enqueued and joined when the autograd engine finishes
 #    (queue_callback).
 # Under hipGraph capture the forks / joins become parallel branches of the graph.
-SIDE_STREAM = os.environ.get("SWR_SIDE_STREAM", "1") != "0"      # "0": everything on one stream (debugging aid; tests/test_graph_gpu.py)
+# SWR_SIDE_STREAM: "1" side streams (the large tables' sort behind the forward pass, the first layer's weight gradient beside the
+# embedding backward), "0" everything on one stream, unset = by batch size: a replayed multi-stream graph costs the HOST ~8 us per
+# node against ~1.3 us for a single-stream one, and the side branches only pay for themselves on big steps -- measured per-GPU
+# shards (round 5): config 1 (batch 4 096) 0.240 -> 0.202 ms on one stream, config 3 (16 384) 1.316 -> 1.290, config 4 (8 192) the
+# same, configs 5 / 6 (32 768) and config 2 (65 536) 1-5 % faster WITH the branches.  Decided by the lookup that opens a step.
+_SIDE_MODE = os.environ.get("SWR_SIDE_STREAM", "auto")
+SIDE_MIN_BATCH = int(os.environ.get("SWR_SIDE_MIN_BATCH", 32768))
+SIDE_STREAM = _SIDE_MODE != "0"
 # weight-gradient products of 2e9 .. 2e10 flop run on a stream of their own (_fork_dw) next to the dX -> K3 chain: 0.535 ->
 # 0.506 ms at config 2; a fork / join pair costs ~10-20 us of edges, so smaller products stay on the main stream (forking
 # every product LOSES 0.02 ms at configs 1, 3, 4) and chip-filling ones only slow what they overlap
@@ -725,6 +732,9 @@ class EmbedGather(Function):
         ctx.fused_dx = None              # (compact dX, {position in plan.sparse: first compact column}) from the consuming layer
         ctx.n_k3_slots = ctx.n_grad_slots - (len(plan.oh) if plan.oh else 0)      # without the one-hot tables
         plan.ctx = ctx
+        if _SIDE_MODE == "auto" and not _in_backward():
+            global SIDE_STREAM
+            SIDE_STREAM = B >= SIDE_MIN_BATCH          # (the lookup opens the step: every fork decision of the step follows it)
         if need_keys and ns and B > 0 and SIDE_STREAM and getattr(plan, "want_grad", False):   # a backward may follow
             # the grouping of the large tables' entries by row needs only the keys: run it NOW on the side stream,
             # hidden behind the rest of the forward and backward pass; the backward joins before it reduces

@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# The product decides by batch size whether a step forks side streams (ops.SIDE_MIN_BATCH: below 32 768 rows one stream is faster).
+# The tests run mostly small batches and exist to exercise the multi-stream step -- forks, joins, captured branches, the skew
+# harness -- so they force the forks on; tests/test_graph_gpu.py::test_side_streams_by_batch_size covers the automatic choice and
+# the single-stream step.
+os.environ.setdefault("SWR_SIDE_STREAM", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "scenario-wise-rec_amd")
 for p in (ROOT, PKG):

@@ -324,7 +324,10 @@ def _captured_lazy_equals_eager_sweep(n, n_steps=4, keep_device_init=False):
                 out[k] = np.array([s1 % (1 << 62), s2 % (1 << 62)], dtype=np.int64)
             else:
                 out[k] = v.cpu().numpy()
+        import gc
+        g = None
         del model, tr
+        gc.collect()
         torch.cuda.empty_cache()
         return out, losses
     got, losses = run(True, True)
@@ -341,9 +344,14 @@ def _shard_case(n, hash_seeds, n_slice=2048):
         1e-4 in the logit and the BCE loss, with the oracle holding the COMPACTED rows of the big tables (the rows the slice
         looks up, gathered from the device tables; exact -- a row's value does not depend on the others)."""
     from scenario_wise_rec import _hip as H
+    import gc
     cfg = copy.deepcopy(bench.CONFIGS[n])
     assert cfg["batch"] == 32768
+    gc.collect()
+    torch.cuda.empty_cache()                  # (each arm below holds 77 GB of tables + Adam state: nothing of earlier tests may linger)
     _captured_lazy_equals_eager_sweep(n, keep_device_init=True)
+    gc.collect()
+    torch.cuda.empty_cache()
     with torch.device("cuda"):
         model, feats = bench.build_model(cfg, seed=13)
     perturb_product(model, 41)

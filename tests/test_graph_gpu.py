@@ -80,3 +80,26 @@ def test_replay_after_a_backward_pass_nobody_consumed(name):
         res[use_graph] = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     for k in res[False]:
         assert np.array_equal(res[False][k], res[True][k]), k
+
+
+@pytest.mark.parametrize("name", ["mmoe", "star"])
+def test_side_streams_by_batch_size(name, monkeypatch):
+    """ops.SIDE_STREAM in its automatic mode (the product's default; the test suite forces the forks on, conftest.py): the
+    lookup that opens a step turns the side streams on for batches of SIDE_MIN_BATCH rows and more, off below -- and the
+    single-stream step (captured and replayed) lands bitwise where the multi-stream step lands: the forks only move launches
+    between streams, never change a sum."""
+    from scenario_wise_rec import ops
+    c = Case(name)
+    monkeypatch.setattr(ops, "_SIDE_MODE", "1")
+    monkeypatch.setattr(ops, "SIDE_STREAM", True)
+    multi = _run(c, 5, use_graph=True)
+    monkeypatch.setattr(ops, "_SIDE_MODE", "auto")
+    monkeypatch.setattr(ops, "SIDE_MIN_BATCH", 1 << 30)
+    single = _run(c, 5, use_graph=True)
+    assert ops.SIDE_STREAM is False                       # decided by the lookup: the fixture's batch is below the threshold
+    monkeypatch.setattr(ops, "SIDE_MIN_BATCH", 1)
+    auto_on = _run(c, 5, use_graph=True)
+    assert ops.SIDE_STREAM is True
+    for k in multi:
+        assert np.array_equal(multi[k], single[k]), f"{k}: one stream differs from the forked step"
+        assert np.array_equal(multi[k], auto_on[k]), k
