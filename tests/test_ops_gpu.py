@@ -1462,7 +1462,7 @@ def test_weight_gradient_that_recomputes_dz_is_bitwise_the_written_dz(monkeypatc
             assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
 
 
-@pytest.mark.parametrize("B", [32768 + 8, 65536, 4096 + 1])
+@pytest.mark.parametrize("B", [32768 + 8, 65536, 4096 + 1, 8192 + 40])
 def test_transpose_read_weight_gradient(B):
     """csrc/dw_tr.hip (swr_dw_tr_mode(1), the default): the first layer's weight gradient with both operands stored in LDS as
     they arrive and read back through ds_read_b64_tr_b16, A' from the pre-split pieces by LDS-DMA.  One training step at config 2's
