@@ -314,10 +314,12 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     int tiles = 0, chunks = 0, passes = 0;
     // few sorted entries: smaller sort tiles and reduce chunks, so that the launch still covers the chip and the
     // per-walker dependent-load chain stays short
-    int items = SORT_ITEMS_MAX;
-    while (items > 1 && m.n / (SORT_THREADS * items) < 512) items >>= 1;
-    p.sm.items = items;
-    p.sm.tile = SORT_THREADS * items;
+    {
+        int64_t max_keys = 1;
+        for (int t = 0; t < n_tables; ++t)
+            if (!direct[t] && !segsum[t]) max_keys = std::max<int64_t>(max_keys, count[t]);
+        sort_choose_tile(p.sm, m.n, max_keys);
+    }
     m.chunk = CHUNK_MAX;
     while (m.chunk > 8 && m.n / m.chunk < 16384) m.chunk >>= 1;
     m.sparse_start = -1;

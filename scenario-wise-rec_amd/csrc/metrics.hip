@@ -32,6 +32,7 @@ static int mt_plan(int64_t n, int D, MetricsPlan& p) {
     while (items > 1 && n / (SORT_THREADS * items) < 512) items >>= 1;
     p.sm.items = items;
     p.sm.tile = SORT_THREADS * items;
+    p.sm.fold_scan = 0;
     p.sm.n_tables = 1;
     p.sm.seg_off[0] = 0;
     p.sm.seg_off[1] = n;

@@ -18,7 +18,24 @@ struct SortMeta {
     int32_t n_tiles;
     int32_t items;        // keys per thread of a tile
     int32_t tile;         // SORT_THREADS * items
+    int32_t fold_scan;    // no table has more than SORT_FOLD_TILES tiles: sort_scatter computes its offsets itself, no sort_scan launch
 };
+#define SORT_FOLD_TILES 64
+
+// keys per thread and tile, and whether the scan launch folds into the scatter: the smallest tile that leaves the largest table
+// <= SORT_FOLD_TILES tiles (a scatter workgroup then sums <= 64 histograms per digit itself: one launch and one kernel boundary
+// less per pass -- the sort sits ON the critical path of the single-stream steps, ops.SIDE_MIN_BATCH); tables too long for that
+// keep the three-launch pass with the tile size that fills the chip
+static inline void sort_choose_tile(SortMeta& sm, int64_t n_total, int64_t max_table_keys) {
+    for (int items = 1; items <= SORT_ITEMS_MAX; items <<= 1)
+        if ((max_table_keys + SORT_THREADS * items - 1) / (SORT_THREADS * items) <= SORT_FOLD_TILES) {
+            sm.items = items; sm.tile = SORT_THREADS * items; sm.fold_scan = 1;
+            return;
+        }
+    int items = SORT_ITEMS_MAX;
+    while (items > 1 && n_total / (SORT_THREADS * items) < 512) items >>= 1;
+    sm.items = items; sm.tile = SORT_THREADS * items; sm.fold_scan = 0;
+}
 
 // ------------------------------------------------------------------------------- segmented radix sort
 __device__ __forceinline__ int sort_table_of_tile(const SortMeta& sm, int tile) {
@@ -129,7 +146,36 @@ static __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    off[threadIdx.x] = hist[static_cast<int64_t>(tile) * 256 + threadIdx.x];
+    if (sm.fold_scan) {
+        // hist holds the raw per-tile counts: this digit's output offset = segment base + keys of smaller digits (all tiles of the
+        // table) + keys of this digit in earlier tiles -- what sort_scan_kernel would have written
+        const int t0 = sm.tile_off[t], t1 = sm.tile_off[t + 1];
+        const int d = threadIdx.x;
+        uint32_t before = 0, total = 0;
+        for (int tt = t0; tt < t1; tt += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tt + k < t1 ? hist[static_cast<int64_t>(tt + k) * 256 + d] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                total += v[k];
+                before += (tt + k < tile) ? v[k] : 0u;
+            }
+        }
+        off[d] = total;
+        __syncthreads();
+        uint32_t incl = total;
+        for (int o = 1; o < 256; o <<= 1) {               // inclusive scan of the digit totals (Hillis-Steele in LDS)
+            const uint32_t add = d >= o ? off[d - o] : 0u;
+            __syncthreads();
+            incl += add;
+            off[d] = incl;
+            __syncthreads();
+        }
+        off[d] = static_cast<uint32_t>(sm.seg_off[t]) + (incl - total) + before;
+    } else {
+        off[threadIdx.x] = hist[static_cast<int64_t>(tile) * 256 + threadIdx.x];
+    }
 #pragma unroll
     for (int w = 0; w < SORT_THREADS / 64; ++w) wc[w][threadIdx.x] = 0;
     __syncthreads();
@@ -178,7 +224,7 @@ static inline void radix_sort_launch(const SortMeta& sm, int n_passes, uint32_t*
     int cur = 0;
     for (int pass = 0; pass < n_passes; ++pass) {
         hipLaunchKernelGGL(sort_hist_kernel, dim3(sm.n_tiles), dim3(SORT_THREADS), 0, st, sm, pass, kbuf[cur], hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(sm.n_tables), dim3(SCAN_THREADS), 0, st, sm, pass, hist);
+        if (!sm.fold_scan) hipLaunchKernelGGL(sort_scan_kernel, dim3(sm.n_tables), dim3(SCAN_THREADS), 0, st, sm, pass, hist);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(sm.n_tiles), dim3(SORT_THREADS), 0, st, sm, pass, kbuf[cur], vbuf[cur],
                            kbuf[cur ^ 1], vbuf[cur ^ 1], hist);
         cur ^= 1;
