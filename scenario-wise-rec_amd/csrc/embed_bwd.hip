@@ -470,9 +470,13 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     return SWR_OK;
 }
 
+// (+ the zero-fill of both accumulator limbs, `zero16` 16-byte words from `zero`: it was a launch of its own in front of this one)
 __global__ __launch_bounds__(RB_THREADS) void build_keys_kernel(const BwdMeta m, const uint32_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ ck, uint32_t* __restrict__ val) {
+                                                                uint32_t* __restrict__ ck, uint32_t* __restrict__ val,
+                                                                uint4* __restrict__ zero, int64_t zero16) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * RB_THREADS + threadIdx.x;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * RB_THREADS;
+    for (int64_t z = i; z < zero16; z += stride) zero[z] = make_uint4(0u, 0u, 0u, 0u);
     if (i >= m.n) return;
     const int slot = m.sorted_slot[i / m.B];
     const int64_t b = i % m.B;
@@ -1216,14 +1220,17 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
     const BwdMeta& m = p.m;
     const int64_t n = m.n;
 
-    if (phases & 1) {
+    const size_t zero_bytes = static_cast<size_t>(p.off_acc_lo - p.off_acc_hi) * 2;
+    const bool zero_in_keys = (phases & 1) && n > 0 && zero_bytes % 16 == 0 && swr_aligned16(acc_hi);
+    if ((phases & 1) && !zero_in_keys) {
         // both accumulator limbs are contiguous: one zero-fill (a kernel, not a memset node); part of the keys-only half
-        rc = swr_zero_async(acc_hi, (p.off_acc_lo - p.off_acc_hi) * 2, st);
+        rc = swr_zero_async(acc_hi, zero_bytes, st);
         if (rc != SWR_OK) return rc;
     }
     if ((phases & 1) && n > 0) {
         hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
-                           st, m, keys, kbuf[0], vbuf[0]);
+                           st, m, keys, kbuf[0], vbuf[0], reinterpret_cast<uint4*>(acc_hi),
+                           zero_in_keys ? static_cast<int64_t>(zero_bytes / 16) : 0);
         radix_sort_launch(p.sm, p.n_passes, kbuf, vbuf, hist, st);
     }
     if (!(phases & 6)) return swr_launch_status();
