@@ -49,19 +49,31 @@ struct V4Plan {
     int rows;       // rows covered by one pass of the 256-thread block
 };
 
-static bool v4_ok(const ActSpec& as, int N, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3, const void* p0, const void* p1,
-                  const void* p2, const void* p3, const void* c0, const void* c1, const void* c2, const void* c3) {
-    if (N % 4 != 0 || N / 4 > BN_THREADS) return false;
+// tail: activation ranges the float4 kernels cannot take (softmax groups other than one float4, ranges that cut a float4) are
+// allowed at the END of the row -- PLE's gates are softmax groups of n_expert_specific + n_expert_shared = 3 columns behind
+// 9 x 64 expert columns (ple.py:89-94), and thread-per-column kernels ran that layer at 30 us per pass at M = 8192, every
+// workgroup waiting for its softmax lanes.  Columns [0, n4) go to the float4 threads, the <= TAIL_MAX columns [n4, N) to
+// extra workgroups of the same launch, thread = (row group, column), TAIL_U rows in flight.
+#define TAIL_MAX 64
+#define TAIL_U 4
+
+static bool v4_split(const ActSpec& as, int N, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3, const void* p0, const void* p1,
+                     const void* p2, const void* p3, const void* c0, const void* c1, const void* c2, const void* c3, int& n4) {
+    n4 = 0;
+    if (N % 4 != 0) return false;
     const int64_t lds[4] = {ld0, ld1, ld2, ld3};
     for (int i = 0; i < 4; ++i)
         if (lds[i] % 4 != 0) return false;
     const void* ps[8] = {p0, p1, p2, p3, c0, c1, c2, c3};
     for (int i = 0; i < 8; ++i)
         if (ps[i] && !swr_aligned16(ps[i])) return false;
+    int bad = N;
     for (int i = 0; i < as.n; ++i) {
-        if (as.r[i].col_lo % 4 != 0 || as.r[i].col_hi % 4 != 0) return false;
-        if (as.r[i].act == SWR_ACT_SOFTMAX && as.r[i].group != 4) return false;
+        const bool ok = as.r[i].col_lo % 4 == 0 && as.r[i].col_hi % 4 == 0 && (as.r[i].act != SWR_ACT_SOFTMAX || as.r[i].group == 4);
+        if (!ok && as.r[i].col_lo < as.r[i].col_hi) bad = std::min(bad, as.r[i].col_lo & ~3);
     }
+    if (bad < 4 || N - bad > TAIL_MAX || bad / 4 > BN_THREADS) return false;
+    n4 = bad;
     return true;
 }
 
@@ -98,12 +110,140 @@ __device__ __forceinline__ float4 act_bwd4(int act, float4 dy, float4 y) {
     return dy;
 }
 
+// ---- thread-per-column row helpers: U rows of column n in flight (rows m0 .. m0 + cnt - 1, cnt <= U; the loads of a missing row
+// repeat the last one).  A softmax column walks its group once for the maxima and once for the sums with the loads of all U rows
+// issued together -- one row at a time each of the 2 x group loads waited for the previous one.  Operation order per row = the
+// float4 kernels' (left to right over the group).
+template <int U>
+__device__ __forceinline__ void affine_act_fwd_rows(const float* __restrict__ Z, int64_t ldz, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int act, int lo, int group,
+                                                    float* __restrict__ Y, int64_t ldy, int n, int64_t m0, int cnt) {
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+    const float* z[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) z[u] = Z + (m0 + min(u, cnt - 1)) * ldz;
+    float y[U];
+    if (act == SWR_ACT_SOFTMAX) {
+        const int g0 = lo + ((n - lo) / group) * group;
+        float mx[U], den[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { mx[u] = -INFINITY; den[u] = 0.f; }
+        for (int j = 0; j < group; ++j) {
+            const float sj = scale ? scale[g0 + j] : 1.f, hj = shift ? shift[g0 + j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) mx[u] = fmaxf(mx[u], sj * z[u][g0 + j] + hj);
+        }
+        for (int j = 0; j < group; ++j) {
+            const float sj = scale ? scale[g0 + j] : 1.f, hj = shift ? shift[g0 + j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) den[u] += expf(sj * z[u][g0 + j] + hj - mx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) y[u] = expf(sc * z[u][n] + sh - mx[u]) / den[u];
+    } else {
+        float zv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) zv[u] = z[u][n];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float v = sc * zv[u] + sh;
+            y[u] = act == SWR_ACT_RELU ? fmaxf(v, 0.f) : (act == SWR_ACT_SIGMOID ? swr_sigmoid(v) : v);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (u < cnt) Y[(m0 + u) * ldy + n] = y[u];
+}
+
+// dA = act'(Y) * dY of column n for U rows (row pointers given; a softmax column needs dot(dY, Y) over its group)
+template <int U>
+__device__ __forceinline__ void act_grad_rows(int act, int lo, int group, const float* const (&dy)[U], const float* const (&y)[U], int n,
+                                              float (&da)[U]) {
+    float g[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        g[u] = dy[u][n];
+        yv[u] = act == SWR_ACT_NONE ? 0.f : y[u][n];
+    }
+    if (act == SWR_ACT_SOFTMAX) {
+        const int g0 = lo + ((n - lo) / group) * group;
+        float dot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dot[u] = 0.f;
+        for (int j = 0; j < group; ++j) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) dot[u] = fmaf(dy[u][g0 + j], y[u][g0 + j], dot[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) da[u] = yv[u] * (g[u] - dot[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            da[u] = act == SWR_ACT_RELU ? (yv[u] > 0.f ? g[u] : 0.f) : (act == SWR_ACT_SIGMOID ? g[u] * yv[u] * (1.f - yv[u]) : g[u]);
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void act_bwd_apply_rows(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy,
+                                                   const float* __restrict__ Z, int64_t ldz, const float* __restrict__ ca,
+                                                   const float* __restrict__ cb, const float* __restrict__ cc,
+                                                   const float* __restrict__ mean, int act, int lo, int group,
+                                                   float* __restrict__ dZ, int64_t lddz, int n, int64_t m0, int cnt) {
+    const float a_ = ca ? ca[n] : 1.f;
+    const float b_ = cb ? cb[n] : 0.f, c_ = cb ? cc[n] : 0.f, mu = cb ? mean[n] : 0.f;
+    const float* dy[U];
+    const float* y[U];
+    float z[U], da[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t m = m0 + min(u, cnt - 1);
+        dy[u] = dY + m * lddy;
+        y[u] = Y + m * ldy;
+        z[u] = cb ? Z[m * ldz + n] : 0.f;
+    }
+    act_grad_rows<U>(act, lo, group, dy, y, n, da);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float v = da[u];
+        if (ca) v *= a_;
+        if (cb) v = fmaf(b_, z[u] - mu, v) + c_;
+        if (u < cnt) dZ[(m0 + u) * lddz + n] = v;
+    }
+}
+
+// the tail columns [n4, N) of a float4 launch: thread = (row group, column), TAIL_U consecutive rows each
+struct TailMap {
+    int n;           // column, -1: thread idle
+    int64_t m0;      // first row
+    int cnt;         // rows (<= TAIL_U)
+};
+__device__ __forceinline__ TailMap tail_map(int tail_block, int n4, int N, int64_t M) {
+    const int tc = N - n4, groups = BN_THREADS / tc;
+    const int rg = threadIdx.x / tc, c = threadIdx.x - rg * tc;
+    TailMap t;
+    t.m0 = (static_cast<int64_t>(tail_block) * groups + rg) * TAIL_U;
+    t.n = (rg < groups && t.m0 < M) ? n4 + c : -1;
+    t.cnt = static_cast<int>(min<int64_t>(TAIL_U, M - t.m0));
+    return t;
+}
+static inline unsigned tail_blocks(int n4, int N, int64_t M) {
+    return n4 < N ? static_cast<unsigned>(swr_ceil_div(M, static_cast<int64_t>(BN_THREADS / (N - n4)) * TAIL_U)) : 0u;
+}
+
 #define V4_ITERS 8
 __global__ __launch_bounds__(BN_THREADS) void affine_act_fwd_v4_kernel(const float* __restrict__ Z, int64_t ldz,
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, const ActSpec acts,
                                                                        float* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                                       const V4Plan pl) {
+                                                                       const V4Plan pl, int v4_blocks) {
+    if (static_cast<int>(blockIdx.x) >= v4_blocks) {          // tail columns [4 vpr, N)
+        const TailMap t = tail_map(blockIdx.x - v4_blocks, 4 * pl.vpr, N, M);
+        if (t.n < 0) return;
+        int lo, group;
+        const int act = find_act(acts, t.n, lo, group);
+        affine_act_fwd_rows<TAIL_U>(Z, ldz, scale, shift, act, lo, group, Y, ldy, t.n, t.m0, t.cnt);
+        return;
+    }
     const int r_in = threadIdx.x / pl.vpr, v = threadIdx.x - r_in * pl.vpr;
     if (r_in >= pl.rows) return;
     const int n = 4 * v;
@@ -124,7 +264,16 @@ __global__ __launch_bounds__(BN_THREADS) void affine_act_fwd_v4_kernel(const flo
 __global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_v4_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
     int64_t ldz, const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ cc,
-    const float* __restrict__ mean, const ActSpec acts, float* __restrict__ dZ, int64_t lddz, int64_t M, int N, const V4Plan pl) {
+    const float* __restrict__ mean, const ActSpec acts, float* __restrict__ dZ, int64_t lddz, int64_t M, int N, const V4Plan pl,
+    int v4_blocks) {
+    if (static_cast<int>(blockIdx.x) >= v4_blocks) {          // tail columns [4 vpr, N)
+        const TailMap t = tail_map(blockIdx.x - v4_blocks, 4 * pl.vpr, N, M);
+        if (t.n < 0) return;
+        int lo, group;
+        const int act = find_act(acts, t.n, lo, group);
+        act_bwd_apply_rows<TAIL_U>(dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, act, lo, group, dZ, lddz, t.n, t.m0, t.cnt);
+        return;
+    }
     const int r_in = threadIdx.x / pl.vpr, v = threadIdx.x - r_in * pl.vpr;
     if (r_in >= pl.rows) return;
     const int n = 4 * v;
@@ -148,6 +297,33 @@ __global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_v4_kernel(
     }
 }
 
+// (sum dA, sum dA * xhat) of column n over the rows ry, ry + 4, ... of the 64-row tile at m0: TAIL_U rows in flight
+__device__ __forceinline__ void bn_act_bwd_stats_col(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy,
+                                                     const float* __restrict__ Z, int64_t ldz, float mu, float rs, int act, int lo,
+                                                     int group, int n, int ry, int64_t m0, int64_t M, float& a1, float& a2) {
+    const int rows = static_cast<int>(min<int64_t>(BWD_TILE, M - m0));
+    for (int r = ry; r < rows; r += 4 * TAIL_U) {
+        const float* dy[TAIL_U];
+        const float* y[TAIL_U];
+        float z[TAIL_U], da[TAIL_U];
+#pragma unroll
+        for (int u = 0; u < TAIL_U; ++u) {
+            const int64_t m = m0 + min(r + 4 * u, rows - 1);
+            dy[u] = dY + m * lddy;
+            y[u] = Y + m * ldy;
+            z[u] = Z[m * ldz + n];
+        }
+        act_grad_rows<TAIL_U>(act, lo, group, dy, y, n, da);
+#pragma unroll
+        for (int u = 0; u < TAIL_U; ++u) {
+            if (r + 4 * u < rows) {
+                a1 += da[u];
+                a2 = fmaf(da[u], (z[u] - mu) * rs, a2);
+            }
+        }
+    }
+}
+
 // one workgroup per (64-row tile, block of <= 64 float4 columns) (the tile layout swr_bn_bwd_finalize expects); threads
 // with the same column slot are summed through LDS in fixed order.  Wide layers are cut into column blocks: with one
 // workgroup per row tile, N = 768 left 192 threads walking 64 rows each from 256 workgroups -- 75 us for 150 MB at
@@ -155,8 +331,30 @@ __global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_v4_kernel(
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_v4_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
     int64_t ldz, const float* __restrict__ mean, const float* __restrict__ rstd, const ActSpec acts,
-    float* __restrict__ partials, int64_t M, int N, const V4Plan pl, int vpb) {
+    float* __restrict__ partials, int64_t M, int N, const V4Plan pl, int vpb, int v4_yblocks) {
     __shared__ float4 s1[BN_THREADS], s2[BN_THREADS];
+    if (static_cast<int>(blockIdx.y) >= v4_yblocks) {          // tail columns [4 vpr, N): thread = (column, row phase)
+        float* t1 = reinterpret_cast<float*>(s1);
+        float* t2 = reinterpret_cast<float*>(s2);
+        const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+        const int n = 4 * pl.vpr + cx;
+        float a1 = 0.f, a2 = 0.f;
+        if (n < N) {
+            int lo, group;
+            const int act = find_act(acts, n, lo, group);
+            bn_act_bwd_stats_col(dY, lddy, Y, ldy, Z, ldz, mean[n], rstd[n], act, lo, group, n, ry, static_cast<int64_t>(blockIdx.x) * BWD_TILE,
+                                 M, a1, a2);
+        }
+        t1[ry * 64 + cx] = a1;
+        t2[ry * 64 + cx] = a2;
+        __syncthreads();
+        if (ry == 0 && n < N) {
+            float* p = partials + (static_cast<int64_t>(blockIdx.x) * N + n) * 2;
+            p[0] = (t1[cx] + t1[64 + cx]) + (t1[128 + cx] + t1[192 + cx]);
+            p[1] = (t2[cx] + t2[64 + cx]) + (t2[128 + cx] + t2[192 + cx]);
+        }
+        return;
+    }
     const int r_in = threadIdx.x / vpb, vl = threadIdx.x - r_in * vpb;
     const int rows = BN_THREADS / vpb;
     const int v = blockIdx.y * vpb + vl;
@@ -363,45 +561,11 @@ __global__ __launch_bounds__(BN_THREADS) void affine_act_fwd_kernel(const float*
     if (n >= N) return;
     int lo, group;
     const int act = find_act(acts, n, lo, group);
-    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
     const int64_t m0 = static_cast<int64_t>(blockIdx.y) * rows_per_block, m1 = min<int64_t>(m0 + rows_per_block, M);
-    int64_t m = m0;
-    if (act != SWR_ACT_SOFTMAX) {
-        // element-wise activations: four rows in flight per thread (a 4-byte load per row and lane needs several
-        // outstanding to cover the HBM latency; one row at a time ran at 2.8 TB/s on HAMUR's [32 768, 1 225] hyper-net output)
-        for (; m + EW_UNROLL <= m1; m += EW_UNROLL) {
-            float zv[EW_UNROLL];
-#pragma unroll
-            for (int u = 0; u < EW_UNROLL; ++u) zv[u] = Z[(m + u) * ldz + n];
-#pragma unroll
-            for (int u = 0; u < EW_UNROLL; ++u) {
-                const float v = sc * zv[u] + sh;
-                Y[(m + u) * ldy + n] = act == SWR_ACT_RELU ? fmaxf(v, 0.f) : (act == SWR_ACT_SIGMOID ? swr_sigmoid(v) : v);
-            }
-        }
-    }
-    for (; m < m1; ++m) {
-        const float* z = Z + m * ldz;
-        const float v = sc * z[n] + sh;
-        float y;
-        if (act == SWR_ACT_RELU) {
-            y = fmaxf(v, 0.f);
-        } else if (act == SWR_ACT_SIGMOID) {
-            y = swr_sigmoid(v);
-        } else if (act == SWR_ACT_SOFTMAX) {
-            const int g0 = lo + ((n - lo) / group) * group;
-            float mx = -INFINITY;
-            for (int j = 0; j < group; ++j)
-                mx = fmaxf(mx, (scale ? scale[g0 + j] : 1.f) * z[g0 + j] + (shift ? shift[g0 + j] : 0.f));
-            float den = 0.f;
-            for (int j = 0; j < group; ++j)
-                den += expf((scale ? scale[g0 + j] : 1.f) * z[g0 + j] + (shift ? shift[g0 + j] : 0.f) - mx);
-            y = expf(v - mx) / den;
-        } else {
-            y = v;
-        }
-        Y[m * ldy + n] = y;
-    }
+    // four rows in flight per thread (a 4-byte load per row and lane needs several outstanding to cover the HBM latency; one
+    // row at a time ran at 2.8 TB/s on HAMUR's [32 768, 1 225] hyper-net output)
+    for (int64_t m = m0; m < m1; m += EW_UNROLL)
+        affine_act_fwd_rows<EW_UNROLL>(Z, ldz, scale, shift, act, lo, group, Y, ldy, n, m, static_cast<int>(min<int64_t>(EW_UNROLL, m1 - m)));
 }
 
 extern "C" int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scale, const float* shift,
@@ -412,12 +576,14 @@ extern "C" int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scal
     const int rc = make_acts(acts, n_acts, N, as);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
-    if (v4_ok(as, N, ldz, ldy, 4, 4, Z, Y, nullptr, nullptr, scale, shift, nullptr, nullptr)) {
+    int n4;
+    if (v4_split(as, N, ldz, ldy, 4, 4, Z, Y, nullptr, nullptr, scale, shift, nullptr, nullptr, n4)) {
         V4Plan pl;
-        pl.vpr = N / 4;
+        pl.vpr = n4 / 4;
         pl.rows = BN_THREADS / pl.vpr;
-        hipLaunchKernelGGL(affine_act_fwd_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, pl.rows * V4_ITERS))),
-                           dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N, pl);
+        const unsigned v4_blocks = static_cast<unsigned>(swr_ceil_div(M, pl.rows * V4_ITERS));
+        hipLaunchKernelGGL(affine_act_fwd_v4_kernel, dim3(v4_blocks + tail_blocks(n4, N, M)), dim3(BN_THREADS), 0,
+                           static_cast<hipStream_t>(stream), Z, ldz, scale, shift, as, Y, ldy, M, N, pl, static_cast<int>(v4_blocks));
         return swr_launch_status();
     }
     const int rpb = static_cast<int>(std::max<int64_t>(EW_ROWS, swr_ceil_div(M, 65535)));       // gridDim.y <= 65535
@@ -427,28 +593,6 @@ extern "C" int swr_affine_act_fwd(const float* Z, int64_t ldz, const float* scal
 }
 
 // --------------------------------------------------------------------------------------- backward
-// dA = act'(Y) * dY for one element (softmax needs the whole group of the row)
-__device__ __forceinline__ float act_grad(const ActSpec& acts, const float* __restrict__ dy, const float* __restrict__ y, int n) {
-    int lo, group;
-    const int act = find_act(acts, n, lo, group);
-    const float g = dy[n];
-    if (act == SWR_ACT_RELU) return y[n] > 0.f ? g : 0.f;
-    if (act == SWR_ACT_SIGMOID) return g * y[n] * (1.f - y[n]);
-    if (act == SWR_ACT_SOFTMAX) {
-        const int g0 = lo + ((n - lo) / group) * group;
-        float dot = 0.f;
-        for (int j = 0; j < group; ++j) dot = fmaf(dy[g0 + j], y[g0 + j], dot);
-        return y[n] * (g - dot);
-    }
-    return g;
-}
-
-__device__ __forceinline__ float act_grad_elem(int act, float g, float y) {          // any activation but softmax
-    if (act == SWR_ACT_RELU) return y > 0.f ? g : 0.f;
-    if (act == SWR_ACT_SIGMOID) return g * y * (1.f - y);
-    return g;
-}
-
 // block = 64 columns x 4 row phases over a 64-row tile; partials[tile][n] = (sum dA, sum dA * xhat)
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Z,
@@ -460,36 +604,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_stats_kernel(
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BWD_TILE;
     float a1 = 0.f, a2 = 0.f;
     if (n < N) {
-        const float mu = mean[n], rs = rstd[n];
         int lo_, group_;
         const int act = find_act(acts, n, lo_, group_);
-        int r = ry;
-        if (act != SWR_ACT_SOFTMAX) {
-            // four of this thread's rows in flight (same order of additions as the plain loop below)
-            for (; r + 4 * (EW_UNROLL - 1) < BWD_TILE && m0 + r + 4 * (EW_UNROLL - 1) < M; r += 4 * EW_UNROLL) {
-                float g[EW_UNROLL], y[EW_UNROLL], z[EW_UNROLL];
-#pragma unroll
-                for (int u = 0; u < EW_UNROLL; ++u) {
-                    const int64_t m = m0 + r + 4 * u;
-                    g[u] = dY[m * lddy + n];
-                    y[u] = act == SWR_ACT_NONE ? 0.f : Y[m * ldy + n];
-                    z[u] = Z[m * ldz + n];
-                }
-#pragma unroll
-                for (int u = 0; u < EW_UNROLL; ++u) {
-                    const float da = act_grad_elem(act, g[u], y[u]);
-                    a1 += da;
-                    a2 = fmaf(da, (z[u] - mu) * rs, a2);
-                }
-            }
-        }
-        for (; r < BWD_TILE; r += 4) {
-            const int64_t m = m0 + r;
-            if (m >= M) break;
-            const float da = act_grad(acts, dY + m * lddy, Y + m * ldy, n);
-            a1 += da;
-            a2 = fmaf(da, (Z[m * ldz + n] - mu) * rs, a2);
-        }
+        bn_act_bwd_stats_col(dY, lddy, Y, ldy, Z, ldz, mean[n], rstd[n], act, lo_, group_, n, ry, m0, M, a1, a2);
     }
     s1[ry][cx] = a1;
     s2[ry][cx] = a2;
@@ -508,15 +625,16 @@ extern "C" int swr_bn_act_bwd_stats(const float* dY, int64_t lddy, const float* 
     ActSpec as;
     const int rc = make_acts(acts, n_acts, N, as);
     if (rc != SWR_OK) return rc;
-    if (v4_ok(as, N, lddy, ldy, ldz, 4, dY, Y, Z, partials, mean, rstd, nullptr, nullptr)) {
+    int n4;
+    if (v4_split(as, N, lddy, ldy, ldz, 4, dY, Y, Z, partials, mean, rstd, nullptr, nullptr, n4)) {
         V4Plan pl;
-        pl.vpr = N / 4;
+        pl.vpr = n4 / 4;
         pl.rows = BN_THREADS / pl.vpr;
         const int vpb = pl.vpr < 64 ? pl.vpr : 64;
-        hipLaunchKernelGGL(bn_act_bwd_stats_v4_kernel,
-                           dim3(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE)), static_cast<unsigned>(swr_ceil_div(pl.vpr, vpb))),
+        const unsigned v4_y = static_cast<unsigned>(swr_ceil_div(pl.vpr, vpb));
+        hipLaunchKernelGGL(bn_act_bwd_stats_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE)), v4_y + (n4 < N ? 1u : 0u)),
                            dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, mean, rstd, as, partials,
-                           M, N, pl, vpb);
+                           M, N, pl, vpb, static_cast<int>(v4_y));
         return swr_launch_status();
     }
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(M, BWD_TILE)), static_cast<unsigned>(swr_ceil_div(N, 64)));
@@ -569,36 +687,12 @@ __global__ __launch_bounds__(BN_THREADS) void act_bwd_apply_kernel(
     int rows_per_block) {
     const int n = blockIdx.x * BN_THREADS + threadIdx.x;           // thread = one column, rows_per_block rows of it
     if (n >= N) return;
-    const float a_ = ca ? ca[n] : 1.f;
-    const float b_ = cb ? cb[n] : 0.f, c_ = cb ? cc[n] : 0.f, mu = cb ? mean[n] : 0.f;
     const int64_t m0 = static_cast<int64_t>(blockIdx.y) * rows_per_block, m1 = min<int64_t>(m0 + rows_per_block, M);
     int lo_, group_;
     const int act = find_act(acts, n, lo_, group_);
-    int64_t m = m0;
-    if (act != SWR_ACT_SOFTMAX) {
-        for (; m + EW_UNROLL <= m1; m += EW_UNROLL) {          // four rows in flight per thread
-            float g[EW_UNROLL], y[EW_UNROLL], z[EW_UNROLL];
-#pragma unroll
-            for (int u = 0; u < EW_UNROLL; ++u) {
-                g[u] = dY[(m + u) * lddy + n];
-                y[u] = act == SWR_ACT_NONE ? 0.f : Y[(m + u) * ldy + n];
-                z[u] = cb ? Z[(m + u) * ldz + n] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < EW_UNROLL; ++u) {
-                float v = act_grad_elem(act, g[u], y[u]);
-                if (ca) v *= a_;
-                if (cb) v = fmaf(b_, z[u] - mu, v) + c_;
-                dZ[(m + u) * lddz + n] = v;
-            }
-        }
-    }
-    for (; m < m1; ++m) {
-        float v = act_grad(acts, dY + m * lddy, Y + m * ldy, n);
-        if (ca) v *= a_;
-        if (cb) v = fmaf(b_, Z[m * ldz + n] - mu, v) + c_;
-        dZ[m * lddz + n] = v;
-    }
+    for (int64_t m = m0; m < m1; m += EW_UNROLL)               // four rows in flight per thread
+        act_bwd_apply_rows<EW_UNROLL>(dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, act, lo_, group_, dZ, lddz, n, m,
+                                      static_cast<int>(min<int64_t>(EW_UNROLL, m1 - m)));
 }
 
 extern "C" int swr_act_bwd_apply(const float* dY, int64_t lddy, const float* Y, int64_t ldy, const float* Z, int64_t ldz,
@@ -611,13 +705,15 @@ extern "C" int swr_act_bwd_apply(const float* dY, int64_t lddy, const float* Y, 
     const int rc = make_acts(acts, n_acts, N, as);
     if (rc != SWR_OK) return rc;
     if (M == 0) return SWR_OK;
-    if (v4_ok(as, N, lddy, ldy, cb ? ldz : 4, lddz, dY, Y, cb ? Z : nullptr, dZ, ca, cb, cc, mean)) {
+    int n4;
+    if (v4_split(as, N, lddy, ldy, cb ? ldz : 4, lddz, dY, Y, cb ? Z : nullptr, dZ, ca, cb, cc, mean, n4)) {
         V4Plan pl;
-        pl.vpr = N / 4;
+        pl.vpr = n4 / 4;
         pl.rows = BN_THREADS / pl.vpr;
-        hipLaunchKernelGGL(act_bwd_apply_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, pl.rows * V4_ITERS))),
-                           dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, as,
-                           dZ, lddz, M, N, pl);
+        const unsigned v4_blocks = static_cast<unsigned>(swr_ceil_div(M, pl.rows * V4_ITERS));
+        hipLaunchKernelGGL(act_bwd_apply_v4_kernel, dim3(v4_blocks + tail_blocks(n4, N, M)), dim3(BN_THREADS), 0,
+                           static_cast<hipStream_t>(stream), dY, lddy, Y, ldy, Z, ldz, ca, cb, cc, mean, as, dZ, lddz, M, N, pl,
+                           static_cast<int>(v4_blocks));
         return swr_launch_status();
     }
     const int rpb = static_cast<int>(std::max<int64_t>(EW_ROWS, swr_ceil_div(M, 65535)));       // gridDim.y <= 65535

@@ -328,15 +328,18 @@ def test_grouped_gemm_and_prologue():
     np.testing.assert_allclose(C.cpu().numpy(), want, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("M,N", [(250, 148), (33, 5), (4099, 64), (300, 1540), (130, 1792)])   # last two: rows wider than 1024 floats
-def test_linear_bn_act_block_vs_oracle(M, N):
+# last two of the first five: rows wider than 1024 floats.  (M, N, group, n_groups): trailing softmax groups that are not one float4
+# (PLE's gates: groups of n_expert_specific + n_expert_shared columns, ple.py:89-94) -- the tail workgroups of the float4 kernels
+@pytest.mark.parametrize("M,N,group,n_groups", [(250, 148, 4, 1), (33, 5, 4, 1), (4099, 64, 4, 1), (300, 1540, 4, 1), (130, 1792, 4, 1),
+                                                 (1027, 76, 3, 4), (515, 588, 3, 4), (261, 84, 9, 1), (70, 72, 5, 8), (3, 75, 3, 1)])
+def test_linear_bn_act_block_vs_oracle(M, N, group, n_groups):
     """One [Linear -> BatchNorm1d(train) -> ReLU | softmax] block, forward, running stats and every
     gradient, against the oracle tape in fp64.  Tolerance 2e-5 absolute on O(1) values."""
     from oracle import tape as T
     from scenario_wise_rec import ops
     rng = np.random.default_rng(M * N)
     K = 52
-    n_sm = 4 if N >= 8 else 0                        # trailing softmax group of 4
+    n_sm = group * n_groups if N >= 8 else 0         # trailing softmax groups
     X = rng.standard_normal((M, K)); W = rng.standard_normal((N, K)) * 0.3; b = rng.standard_normal(N) * 0.1
     g = rng.random(N) + 0.5; be = rng.standard_normal(N) * 0.2
     dY = rng.standard_normal((M, N))
@@ -345,14 +348,15 @@ def test_linear_bn_act_block_vs_oracle(M, N):
     z = T.linear(x_, W_, b_)
     y, mu, var = T.batchnorm_train(z, g_, be_, 1e-5)
     if n_sm:
-        y = T.cat1([T.relu(T.slice1(y, 0, N - n_sm)), T.softmax_rows(T.slice1(y, N - n_sm, N))])
+        y = T.cat1([T.relu(T.slice1(y, 0, N - n_sm))] +
+                   [T.softmax_rows(T.slice1(y, N - n_sm + i * group, N - n_sm + (i + 1) * group)) for i in range(n_groups)])
     else:
         y = T.relu(y)
     T.backward(y, seed=dY)
     # product
     t = {k: _dev(v, torch.float32).requires_grad_(True) for k, v in dict(X=X, W=W, b=b, g=g, be=be).items()}
     rm, rv, nbt = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
-    acts = [(0, N - n_sm, "relu", 1), (N - n_sm, N, "softmax", 4)] if n_sm else "relu"
+    acts = [(0, N - n_sm, "relu", 1), (N - n_sm, N, "softmax", group)] if n_sm else "relu"
     bn = {"gamma": [t["g"]], "beta": [t["be"]], "running_mean": [rm], "running_var": [rv], "nbt": [nbt],
           "eps": 1e-5, "momentum": 0.1}
     Y = ops.linear_bn_act(t["X"], [t["W"]], [t["b"]], bn=bn, acts=acts, training=True)
