@@ -619,7 +619,17 @@ static int launch_rows(const swr_gemm_args* args, void* stream) {
     // tiles per wave: the f32 LDS kernel keeps two waves per SIMD up to 5 tiles (VGPR + AGPR <= 256), the bf16-split
     // kernel up to 7 (252 VGPRs).  Fewer, wider column groups = fewer re-reads / re-splits of A and less padding
     // (N = 516: 3 groups of 6 tiles instead of 4 of 5).
-    const int nblk = static_cast<int>(swr_ceil_div(tiles, x6_ok ? (a.B_split ? 6 : 7) : (lds_ok ? 5 : 8)));   // pre-split: 6 (VGPRs)
+    int nblk = static_cast<int>(swr_ceil_div(tiles, x6_ok ? (a.B_split ? 6 : 7) : (lds_ok ? 5 : 8)));   // pre-split: 6 (VGPRs)
+    // short batches: a workgroup is GEMM_WAVES x 32 rows, so M = 8192 is 64 row blocks -- PLE's first-layer dX (N = 96, one column
+    // group) ran on 64 of the 256 CUs for 31 us.  While the grid is smaller than the chip, cut the columns into more groups
+    // (each output element is still one K-ordered sum: results unchanged).
+    const int64_t row_blocks = swr_ceil_div(kk.n_tiles_m, GEMM_WAVES);
+    static int fill = -1;
+    if (fill < 0) { const char* e = getenv("SWR_GEMM_FILL"); fill = (e && e[0] == '0') ? 0 : 1; }
+    if (fill) {
+        while (nblk < tiles && row_blocks * nblk * a.groups < 256) ++nblk;
+        nblk = static_cast<int>(swr_ceil_div(tiles, swr_ceil_div(tiles, nblk)));      // no empty group
+    }
     const int nt = static_cast<int>(swr_ceil_div(tiles, nblk));
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(kk.n_tiles_m, GEMM_WAVES)), static_cast<unsigned>(nblk),
                     static_cast<unsigned>(a.groups));
