@@ -465,12 +465,23 @@ def _on_side_stream(dev, fn, keep):
 # ---- split backward (data-parallel step): work whose results only the optimizer needs -- the weight-gradient products
 # and the small tables' gradients -- is held back until `run_late_jobs()`, so that the large tables' row lists are
 # ready (and on their way to the other ranks) as early as possible and the held-back work overlaps the all-gather.
-_late = {"on": False, "jobs": []}
+_late = {"on": False, "jobs": [], "rows_event": None, "rows_recorded": False}
 
 
-def split_backward(on):
-    """Set by parallel.DataParallelStep around its forward+backward; whoever sets it must call run_late_jobs()."""
+def split_backward(on, rows_event=None):
+    """Set by parallel.DataParallelStep around its forward+backward; whoever sets it must call run_late_jobs().
+    `rows_event` (the one-graph step): recorded on the main stream behind the large tables' row lists, and the small tables'
+    sums are NOT held back but forked onto the side stream at that point -- the caller's all-gather waits for the event alone
+    (not for the weight-gradient branch or those sums), and nothing is left to serialise behind the row lists."""
     _late["on"] = bool(on)
+    _late["rows_event"] = rows_event if on else None
+    if on:
+        _late["rows_recorded"] = False
+
+
+def rows_event_recorded():
+    """True when the last split backward recorded its `rows_event` (a model without large tables never reaches that point)."""
+    return _late["rows_recorded"]
 
 
 def run_late_jobs():
@@ -850,8 +861,20 @@ class EmbedGather(Function):
                 def reduce_part(part, slots=slots, keys=ctx.keys, dE=dE, ws=ws):
                     H.check(lib.swr_embed_bwd_reduce_part(slots, ns, H.ptr(keys), H.ptr(dE), dE.stride(0), B, part, H.ptr(ws),
                                                           nbytes, H.ptr(H.err_flag(dev)), H.stream()), "swr_embed_bwd_reduce_part")
-                reduce_part(1)
-                _late["jobs"].append(lambda: reduce_part(2))
+                if _late["rows_event"] is not None:
+                    # one-graph step: nothing is held back -- the small tables' sums go to the side stream (free since the sort
+                    # was joined) behind the sorted reduce; the event marks the row lists.  (Beside the sorted reduce -- legal when
+                    # no dense table is sorted -- they slow it: world-1 0.424-0.429 against 0.413-0.421 ms.)
+                    reduce_part(1)
+                    _late["rows_event"].record(torch.cuda.current_stream())
+                    _late["rows_recorded"] = True
+                    _fork_side(dev, lambda: reduce_part(2))
+                    if not _side["queued"]:
+                        _side["queued"] = True
+                        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+                else:
+                    reduce_part(1)
+                    _late["jobs"].append(lambda: reduce_part(2))
             # (measured and dropped: the sorted reduce + row lists on the weight-gradient branch while the direct sums stay
             # here -- the two halves are independent when no dense table is sorted -- 0.524 vs 0.494 ms per step)
             else:

@@ -30,6 +30,7 @@ from . import ops
 # The captured data-parallel step is ONE hipGraph with the RCCL collectives inside it wherever the process group runs over RCCL
 # (world 1 over RCCL, same box: 0.470 -> 0.428 ms per step at config 2, i.e. 1.27 x -> 1.16 x the single-GPU step); gloo collectives
 # are host-synchronous and cannot be captured: three graphs with eager collectives between them (the multi-process tests on one GPU)
+ROWS_EVENT = os.environ.get("SWR_DP_ROWS_EVENT", "1") != "0"   # one-graph step: the rows all-gather waits for the row lists alone
 ONE_GRAPH = os.environ.get("SWR_DP_ONE_GRAPH", "auto")      # "auto": one graph over RCCL (nccl backend), three with gloo; "0" / "1" force
 
 
@@ -176,11 +177,11 @@ class DataParallelStep(object):
         self._graphs = None
 
     # ---- pieces ---------------------------------------------------------------------------------------
-    def _forward_backward(self, x_dict, y):
+    def _forward_backward(self, x_dict, y, rows_event=None):
         """Forward + the part of the backward that ends with the large tables' row lists; the rest waits in
         ops.run_late_jobs()."""
         model = self.trainer.model
-        ops.split_backward(hasattr(model, "arena") and model.arena() is not None)
+        ops.split_backward(hasattr(model, "arena") and model.arena() is not None, rows_event)
         try:
             return self.trainer.forward_backward(x_dict, y).detach()
         finally:
@@ -381,13 +382,17 @@ class DataParallelStep(object):
         side = torch.cuda.Stream()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             cur = torch.cuda.current_stream()
-            loss = self._forward_backward(self.x, self.y)
+            rows_ev = torch.cuda.Event() if ROWS_EVENT else None
+            loss = self._forward_backward(self.x, self.y, rows_ev)
             ops.join_side_streams()
             arena, big, sparse = self._sparse()
             xb = self._exchange_buffers(arena["g"], big, sparse)                # established by the warm-up steps
             rows = bool(xb["offs"])
             if rows:
-                side.wait_stream(cur)
+                if rows_ev is not None and ops.rows_event_recorded():
+                    side.wait_event(rows_ev)            # the row lists alone: not the weight-gradient branch, not the small tables' sums
+                else:
+                    side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group)
                     self._merge_rows(xb, big)
