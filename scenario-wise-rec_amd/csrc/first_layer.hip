@@ -692,6 +692,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
 
     fl_u32x4 ar[4][3];     // (native vectors: a HIP uint4 is a struct, which an asm "+v" operand cannot be)
     auto a_issue = [&](uint32_t off, fl_u32x4 (&dst)[3]) {
+#ifdef FLF_NO_A           // (ablation switches FLF_*: measurement aids of tools/micro/ab_flf.sh, all off in the product build)
+        off = 0;
+#endif
         FL_ALOAD(dst[0], off, wsb, 0);
         FL_ALOAD(dst[1], off, wsb, 16);
         FL_ALOAD(dst[2], off, wsb, 32);
@@ -700,13 +703,19 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
     auto dma_chunk = [&](int c, int buf) {
         const uint4* src = k.b3 + static_cast<size_t>(c) * PITCH_U4 + wave * (PPW * 64) + lane;
         uint4* dst = lds + buf * PITCH_U4 + wave * (PPW * 64);
+#ifndef FLF_NO_DMA
 #pragma unroll
         for (int u = 0; u < PPW; ++u)
             __builtin_amdgcn_global_load_lds((fl_glb_ptr)(src + u * 64), (fl_lds_ptr)(dst + u * 64), 16, 0, 0);
+#endif
     };
     // six (real group) or three (exact A: one-hot group) products per column tile, small terms first
     auto mma_group = [&](const uint4* bp, bf16x8 ah, bf16x8 am, bf16x8 al, auto exact_c) {
         constexpr bool EX = decltype(exact_c)::value;
+#ifdef FLF_NO_MMA
+        acc[0][0] += __builtin_bit_cast(float, __builtin_bit_cast(fl_u32x4, ah)[0] ^ __builtin_bit_cast(fl_u32x4, al)[1] ^ bp[0].x);
+        return;
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
@@ -830,6 +839,17 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (!live) return;
+#ifdef FLF_NO_EPI
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[t][r];
+        if (sum == 12345.678f) k.e.C[T * 32 + i] = sum;
+        return;
+    }
+#endif
     rows_epilogue<NT>(k.e, k.n_tiles, acc, 0, T, T * 32, 0, i, s);
 }
 

@@ -4,6 +4,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef SWR_EPI_OLD
+#define SWR_EPI_OLD 0
+#endif
 
 // epilogue shared by the row-parallel kernels: lane (i, s) holds column n0 + 32t + i, rows m0 + (r & 3) + 8 (r >> 2) + 4 s
 // c_act (swr.h): the activation of a layer WITHOUT BatchNorm applied while C is stored (1 ReLU, 2 sigmoid)
@@ -22,7 +25,11 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n0 + 32 * t + i;
+#ifdef FLF_EPI_NOBIAS          // (FLF_EPI_*: ablation switches of tools/micro/ab_flf.sh, never defined in the product build)
+        float bn = 0.f;
+#else
         float bn = (bias && n < N) ? bias[n] : 0.f;
+#endif
         if (a.c_act) {
             // (wave-uniform, outside the store loops: with the activation inside them the plain case -- every product of
             // config 2 -- lost 9 us per step to the epilogue)
@@ -39,8 +46,26 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[t][r] + bn;
+#ifndef FLF_EPI_NOSTORE
                 (tile_base + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * a.ldc)[lane_off] = v;
+#endif
                 sum += v;
+                acc[t][r] = v;
+            }
+        } else if (nvalid == 32 && !a.accumulate && !SWR_EPI_OLD) {
+            // full rows, the layer's last (ragged) column tile: the same scalar-base stores under ONE lane predicate.  (Through
+            // the element-wise branch below -- a row test, a 64-bit address and an accumulate test per element -- this one
+            // tile cost the fused first layer's forward 5 of its 34 us at N = 148.)
+            const bool okn = n < N;
+            const uint32_t lane_off = static_cast<uint32_t>(4 * s) * static_cast<uint32_t>(a.ldc) + static_cast<uint32_t>(n);
+            float* __restrict__ tile_base = Cg + m0 * a.ldc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r] + bn;
+                if (okn) {
+                    (tile_base + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * a.ldc)[lane_off] = v;
+                    sum += v;
+                }
                 acc[t][r] = v;
             }
         } else {
@@ -58,7 +83,12 @@ __device__ __forceinline__ void rows_epilogue(const swr_gemm_args& a, int n_tile
                 acc[t][r] = v;
             }
         }
+#ifdef FLF_EPI_NOSTATS
+        if (sum == 12345.678f) a.C[0] = sum;
+        if (false) {
+#else
         if (a.stat_partials) {
+#endif
             // BatchNorm batch statistics of this 32-row tile, two-pass in registers
             sum += __shfl_xor(sum, 32);
             const float mean = sum / static_cast<float>(nvalid);

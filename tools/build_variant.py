@@ -21,7 +21,7 @@ def main():
     out_dir = os.path.join(B.LIB_DIR, "variants")
     os.makedirs(out_dir, exist_ok=True)
     obj = os.path.join(B.OBJ_DIR, f"variant_{name}_{src[:-4]}.o")
-    subprocess.run([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
+    subprocess.run([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
     objs = [obj if s == src else os.path.join(B.OBJ_DIR, s[:-4] + ".o")
             for s in sorted(f for f in os.listdir(B.CSRC) if f.endswith(".hip"))]
     lib = os.path.join(out_dir, f"libswr_{name}.so")

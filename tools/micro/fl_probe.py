@@ -73,17 +73,25 @@ def prep(j):
                             H.ptr(Wt), N, H.ptr(f["ws"]), H.stream()), "prep")
 
 
-Z = [torch.empty((B, N), device="cuda") for _ in range(4)]
+LDZ = int(os.environ.get("FL_LDZ", (N + 31) // 32 * 32))         # the step pads the rows of Z to 128 bytes (ops.PAD_ROWS)
+Z = [torch.empty((B, LDZ), device="cuda")[:, :N] for _ in range(4)]
 part = torch.empty(((B + 31) // 32, N, 2), device="cuda")
 
 
 def fwd(j):
     f = infos[j % 4].fl
-    H.check(lib.swr_fl_fwd(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(bias), H.ptr(Z[j % 4]), N, H.ptr(part), H.stream()), "fwd")
+    H.check(lib.swr_fl_fwd(C.byref(f["plan"]), H.ptr(f["ws"]), H.ptr(bias), H.ptr(Z[j % 4]), LDZ, H.ptr(part), H.stream()), "fwd")
 
 
 print(f"swr_fl_prep  {timed(prep):7.1f} us")
 print(f"swr_fl_fwd   {timed(fwd):7.1f} us")
+if os.environ.get("FL_ONLY") == "fwd":
+    part.zero_()
+    fwd(1)
+    torch.cuda.synchronize()
+    print(f"checksum Z {int(Z[1].contiguous().view(torch.int32).to(torch.int64).sum())}  partials {int(part.view(torch.int32).to(torch.int64).sum())}")
+    print(f"{os.environ.get('SWR_LIB', 'base').split('/')[-1]}: swr_fl_fwd {timed(fwd, 100):7.1f} us")
+    sys.exit(0)
 dZ = [torch.randn((B, N), device="cuda") * 1e-4 for _ in range(4)]
 Kf = oh.Kp + oh.oh_width
 dWp = torch.empty((N, Kf), device="cuda")
