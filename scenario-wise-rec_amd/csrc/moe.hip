@@ -698,10 +698,130 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_bwd_kernel(const float* 
     }
 }
 
+
+// ---- pipelined forward (k <= 35, long batches).  rowmat_fwd_kernel walks a sample with its loads issued as the loop reaches them (35
+// loads of one 140-byte row of H_b each, five in flight) and two vector instructions per FMA (v_readlane + v_fmac): 88 us for HAMUR's
+// [32 768, 8, 35] x [35, 35] (234 MB).  Here a wave fetches the NEXT sample's H_b (16-byte loads from the 16-byte boundary below it)
+// and rows of T into registers before it computes the current one from a wave-private LDS copy, and an FMA is ONE v_fmac with a DPP
+// row broadcast of its T operand: 71 us.  Same sums in the same order: identical bits.  (The backward in the same two forms was
+// slower than rowmat_bwd_kernel -- 193 us pipelined with read-lanes at 171 VGPRs, 385 us with broadcasts at 256 VGPRs, against
+// 150 -- and is not kept; T through the scalar cache instead of broadcasts: 152 us forward, the scalar cache does not stream.)
+// acc += t[lane E of the lane's 16-lane row] * h in ONE vector instruction: the DPP form of v_fmac with the row broadcast on its
+// first source (v_readlane + v_fmac are two).  `t` must not have been written by the two preceding instructions (DPP hazard):
+// the callers keep it loop-invariant.
+template <int E>
+__device__ __forceinline__ void rm_fmac_bcast(float& acc, float t, float h) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(h), "n"(E));
+}
+// one 16-element chunk starting at i0: acc[u] += tc[u][row element E] * hv[E] for E = 0 .. 15 (hv: the chunk's column values,
+// zero past k: those products add +-0 to sums that are never -0 ... so they are skipped instead, by a wave-uniform test)
+template <int E>
+__device__ __forceinline__ void rm_chunk(float (&acc)[RM_DB], const float (&tc)[RM_DB], const float (&hv)[16], int n) {
+    if (E < n) {
+#pragma unroll
+        for (int u = 0; u < RM_DB; ++u) rm_fmac_bcast<E>(acc[u], tc[u], hv[E]);
+    }
+    if constexpr (E + 1 < 16) rm_chunk<E + 1>(acc, tc, hv, n);
+}
+#define RM_CHUNKS 3                     // 16-element chunks of a row held in registers: k <= 48 (the launchers route k <= 35 here)
+
+template <int R>
+__global__ __launch_bounds__(RM_WAVES * 64) void rowmat_fwd2_kernel(const float* __restrict__ T, const float* __restrict__ Hm,
+                                                                    float* __restrict__ out, int64_t B, int D, int k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15;
+    const int kk = k * k, dk = D * k;
+    const bool on = lane < k;
+    const int j = on ? lane : 0;
+    float* hs = lds + wave * kk;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * RM_WAVES;
+    int64_t b = static_cast<int64_t>(blockIdx.x) * RM_WAVES + wave;
+    float4 hn[R];                        // R = 16-byte loads per lane of one H_b (from the 16-byte boundary at or below its start)
+    float tn[RM_CHUNKS][RM_DB];
+    int sh_n = 0;
+    // a row of T as RM_CHUNKS registers: chunk c holds elements 16 c + (lane & 15), the same 16 values in each of the wave's four
+    // 16-lane rows (what the row broadcast of rm_fmac_bcast reads)
+    auto fetch_t = [&](int64_t bb, int d0, float (&dst)[RM_CHUNKS][RM_DB]) {
+        const float* __restrict__ tb = T + bb * dk;
+#pragma unroll
+        for (int c = 0; c < RM_CHUNKS; ++c)
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u)
+                dst[c][u] = tb[min((d0 + u) * k + 16 * c + l16, dk - 1)];   // (elements past k / rows past D: never multiplied in / stored)
+    };
+    auto fetch = [&](int64_t bb) {
+        // 16-byte loads whatever the alignment of the sample (k k floats is rarely a multiple of 4): start at the 16-byte boundary
+        // at or below it -- the <= 3 floats in front and behind belong to the neighbouring samples / the same 16-byte granule of the
+        // allocation -- and drop them when the registers go to LDS
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(Hm + bb * kk);
+        sh_n = static_cast<int>((a0 & 15u) >> 2);
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a0 - 4 * sh_n);
+        const int n4 = (kk + sh_n + 3) >> 2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) hn[r] = lane + 64 * r < n4 ? src[lane + 64 * r] : make_float4(0.f, 0.f, 0.f, 0.f);
+        fetch_t(bb, 0, tn);
+    };
+    if (b < B) fetch(b);
+    for (; b < B; b += stride) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = 4 * (lane + 64 * r) - sh_n;
+            if (q >= 0 && q < kk) hs[q] = hn[r].x;
+            if (q + 1 >= 0 && q + 1 < kk) hs[q + 1] = hn[r].y;
+            if (q + 2 >= 0 && q + 2 < kk) hs[q + 2] = hn[r].z;
+            if (q + 3 >= 0 && q + 3 < kk) hs[q + 3] = hn[r].w;
+        }
+        float tr[RM_CHUNKS][RM_DB];
+#pragma unroll
+        for (int c = 0; c < RM_CHUNKS; ++c)
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u) tr[c][u] = tn[c][u];
+        __builtin_amdgcn_wave_barrier();
+        if (b + stride < B) fetch(b + stride);
+        for (int d0 = 0; d0 < D; d0 += RM_DB) {
+            if (d0 > 0) fetch_t(b, d0, tr);
+            float acc[RM_DB];
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u) acc[u] = 0.f;
+#pragma unroll
+            for (int c = 0; c < RM_CHUNKS; ++c) {
+                const int n = min(16, k - 16 * c);                // (wave-uniform)
+                if (n > 0) {
+                    float hv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) hv[e] = hs[min(16 * c + e, k - 1) * k + j];
+                    rm_chunk<0>(acc, tr[c], hv, n);
+                }
+                __builtin_amdgcn_sched_barrier(0);                // (one chunk's 16 column values live at a time)
+            }
+#pragma unroll
+            for (int u = 0; u < RM_DB; ++u)
+                if (on && d0 + u < D) out[b * dk + (d0 + u) * k + lane] = acc[u];
+        }
+        __builtin_amdgcn_wave_barrier();              // every lane is done with hs: the next sample overwrites it
+    }
+}
+
+static bool rowmat_pipelined() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SWR_ROWMAT_PIPE"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
 extern "C" int swr_rowmat_fwd(const float* T, const float* Hm, float* out, int64_t B, int D, int k, void* stream) {
     SWR_REQUIRE(T && Hm && out && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
     SWR_REQUIRE(k <= RM_KMAX, SWR_ERR_UNSUPPORTED);
     if (B == 0) return SWR_OK;
+    if (rowmat_pipelined() && B >= 4096 && k * k <= 64 * 20) {
+        // a wave walks ~8 samples: long enough for the prefetch to pay, short enough to fill the chip
+        const unsigned grid2 = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 1024));
+        const size_t lds2 = static_cast<size_t>(RM_WAVES) * k * k * sizeof(float);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (k * k + 3 <= 256 * 2) hipLaunchKernelGGL(rowmat_fwd2_kernel<2>, dim3(grid2), dim3(RM_WAVES * 64), lds2, st, T, Hm, out, B, D, k);
+        else hipLaunchKernelGGL(rowmat_fwd2_kernel<5>, dim3(grid2), dim3(RM_WAVES * 64), lds2, st, T, Hm, out, B, D, k);
+        return swr_launch_status();
+    }
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 16384));
     hipLaunchKernelGGL(rowmat_fwd_kernel, dim3(grid), dim3(RM_WAVES * 64), 0, static_cast<hipStream_t>(stream), T, Hm, out, B, D, k);
     return swr_launch_status();

@@ -1,24 +1,38 @@
-"""Stand-alone timing of swr_rowmat_fwd / _bwd at HAMUR's config-5 shape (B 32768, D 8, k 35), HIP events."""
-import os, sys
-import torch
+"""Stand-alone times of swr_rowmat_fwd / _bwd at HAMUR's config-5 shape ([32 768, 8, 35] x [35, 35] per sample).
+usage: SWR_ROWMAT_PIPE=0|1 python tools/micro/rowmat_probe.py"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, "scenario-wise-rec_amd"))
-from scenario_wise_rec import ops
+for p in (ROOT, os.path.join(ROOT, "scenario-wise-rec_amd")):
+    sys.path.insert(0, p)
+import torch
+
+from scenario_wise_rec import _hip as H
+from scenario_wise_rec._hip import lib
 
 B, D, k = 32768, 8, 35
-sets = [(torch.randn(B, D, k, device="cuda"), torch.randn(B, k, k, device="cuda"), torch.randn(B, D, k, device="cuda")) for _ in range(4)]
-def run(fn, n=40):
-    for i in range(5): fn(i)
+g = torch.Generator(device="cuda").manual_seed(1)
+T = [torch.randn(B, D, k, device="cuda", generator=g) for _ in range(3)]
+Hm = [torch.randn(B, k, k, device="cuda", generator=g) for _ in range(3)]
+dO = [torch.randn(B, D, k, device="cuda", generator=g) for _ in range(3)]
+out, dT, dH = torch.empty_like(T[0]), torch.empty_like(T[0]), torch.empty_like(Hm[0])
+
+
+def timed(fn, n=30):
+    for j in range(3):
+        fn(j)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(n): fn(i)
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-with torch.no_grad():
-    print("fwd us", round(run(lambda i: ops.RowMat.apply(sets[i % 4][0], sets[i % 4][1])), 1))
-T, Hm, dO = sets[0]
-T.requires_grad_(True); Hm.requires_grad_(True)
-def fb(i):
-    out = ops.RowMat.apply(T, Hm); out.backward(dO); T.grad = None; Hm.grad = None
-print("fwd+bwd us", round(run(fb), 1))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for j in range(n):
+        fn(j)
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+fwd = lambda j: H.check(lib.swr_rowmat_fwd(H.ptr(T[j % 3]), H.ptr(Hm[j % 3]), H.ptr(out), B, D, k, H.stream()), "fwd")
+bwd = lambda j, acc=0: H.check(lib.swr_rowmat_bwd(H.ptr(dO[j % 3]), H.ptr(T[j % 3]), H.ptr(Hm[j % 3]), H.ptr(dT), H.ptr(dH), acc, B, D, k, H.stream()), "bwd")
+print(f"pipe={os.environ.get('SWR_ROWMAT_PIPE', '1')}: fwd {timed(fwd):6.1f} us (234 MB)   bwd {timed(bwd):6.1f} us (431 MB)   "
+      f"bwd accumulating {timed(lambda j: bwd(j, 1)):6.1f} us (592 MB)")
