@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 6
+#define SWR_ABI_VERSION 7
 
 typedef enum {
     SWR_OK = 0,
@@ -469,13 +469,17 @@ typedef struct {
     uint8_t sel[SWR_MIX_MAX_OUT][SWR_MIX_MAX_SEL];
 } swr_mix_desc;
 
-int swr_moe_mix_fwd(const swr_mix_desc* desc_host, const float* Y, int64_t ldy,
+/* G (ABI 7): NULL -- the gate probabilities sit in Y at g_col, as above; else a tensor of their own [M, ldg] with g_col
+ * counted in IT (PLE: the gates are columns of the first layer's output while the experts run a second layer,
+ * ple.py:107-125 -- no concatenation pass).  With G the shapes must take the 16-byte path (H, x_col, row strides multiples
+ * of 4 floats, 16-byte aligned Y / P / dP / dY): SWR_ERR_UNSUPPORTED otherwise. */
+int swr_moe_mix_fwd(const swr_mix_desc* desc_host, const float* Y, int64_t ldy, const float* G, int64_t ldg,
                     float* P, int64_t ldp, int64_t M, void* stream);
 /* writes (accumulate = 0) or adds to (accumulate != 0) dY[:, expert and gate columns]; experts that no
- * output selects get a zero gradient */
+ * output selects get a zero gradient.  G / dG: both NULL, or the gate tensor and the tensor that takes its gradient */
 int swr_moe_mix_bwd(const swr_mix_desc* desc_host, const float* dP, int64_t lddp,
-                    const float* Y, int64_t ldy, float* dY, int64_t lddy, int accumulate,
-                    int64_t M, void* stream);
+                    const float* Y, int64_t ldy, const float* G, int64_t ldg, float* dY, int64_t lddy,
+                    float* dG, int64_t lddg, int accumulate, int64_t M, void* stream);
 
 /* --------------------------------------- BatchNorm + activation + gate mix -----
  * One MMoE level (mmoe.py:44-49) without materialising the activated experts / gate probabilities:

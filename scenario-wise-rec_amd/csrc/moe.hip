@@ -76,7 +76,10 @@ __global__ __launch_bounds__(MIX_WAVES * 64) void mix_fwd_kernel(const MixK k, c
 // ---- 16-byte fast path (H, x_col, row strides multiples of 4 floats): thread = 4 pooled outputs of one row; the expert
 // and gate rows are read straight from global memory (a row is 0.6 KB: the re-reads by the other outputs of the row
 // hit the CU's L1), no LDS, no barriers -> every load of a workgroup is in flight at once.
+// (the gate probabilities come from Gt / ldg: Y itself, or a tensor of their own -- PLE's gates stay in the first layer's
+// output while the experts run their second layer, ple.py:107-125; no concatenation pass)
 __global__ __launch_bounds__(256) void mix_fwd_v4_kernel(const MixK k, const float* __restrict__ Y, int64_t ldy,
+                                                         const float* __restrict__ Gt, int64_t ldg,
                                                          float* __restrict__ P, int64_t ldp, int64_t M) {
     const swr_mix_desc& d = k.d;
     const int h4n = d.H >> 2, per_row = d.n_out * h4n;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void mix_fwd_v4_kernel(const MixK k, const flo
     const int q = static_cast<int>(item - m * per_row);
     const int o = q / h4n, h = (q - o * h4n) * 4;
     const float* __restrict__ y = Y + m * ldy;
-    const float* __restrict__ g = y + d.g_col + o * d.g_stride;
+    const float* __restrict__ g = Gt + m * ldg + d.g_col + o * d.g_stride;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < d.n_sel; ++j) {
         const float gj = g[j];
@@ -97,8 +100,8 @@ __global__ __launch_bounds__(256) void mix_fwd_v4_kernel(const MixK k, const flo
     *reinterpret_cast<float4*>(P + m * ldp + o * d.H + h) = acc;
 }
 
-extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t ldy, float* P, int64_t ldp, int64_t M,
-                               void* stream) {
+extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t ldy, const float* G, int64_t ldg, float* P,
+                               int64_t ldp, int64_t M, void* stream) {
     SWR_REQUIRE(desc && Y && P && M >= 0, SWR_ERR_ARG);
     MixK k;
     const int rc = make_mix(desc, k);
@@ -107,9 +110,10 @@ extern "C" int swr_moe_mix_fwd(const swr_mix_desc* desc, const float* Y, int64_t
     if (desc->H % 4 == 0 && desc->x_col % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0 && swr_aligned16(Y) && swr_aligned16(P)) {
         const int64_t items = M * desc->n_out * (desc->H / 4);
         hipLaunchKernelGGL(mix_fwd_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(items, 256))), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
+                           static_cast<hipStream_t>(stream), k, Y, ldy, G ? G : Y, G ? ldg : ldy, P, ldp, M);
         return swr_launch_status();
     }
+    SWR_REQUIRE(G == nullptr, SWR_ERR_UNSUPPORTED);          // gates in a tensor of their own: the 16-byte path only
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 8192 ? swr_ceil_div(M, MIX_WAVES) : 8192);
     hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), MIX_WAVES * k.row_floats * sizeof(float),
                        static_cast<hipStream_t>(stream), k, Y, ldy, P, ldp, M);
@@ -173,8 +177,9 @@ __global__ __launch_bounds__(MIX_WAVES * 64) void mix_bwd_kernel(const MixK k, c
 #define MIXB_ROWS 32
 __global__ __launch_bounds__(256) void mix_bwd_v4_kernel(const MixK k, const float* __restrict__ dP, int64_t lddp,
                                                          const float* __restrict__ Y, int64_t ldy,
-                                                         float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M,
-                                                         int rows_per_wg) {
+                                                         const float* __restrict__ Gt, int64_t ldg,
+                                                         float* __restrict__ dY, int64_t lddy, float* __restrict__ dGt, int64_t lddg,
+                                                         int accumulate, int64_t M, int rows_per_wg) {
     const swr_mix_desc& d = k.d;
     const int64_t m0 = static_cast<int64_t>(blockIdx.x) * rows_per_wg;
     const int rows = static_cast<int>(min<int64_t>(rows_per_wg, M - m0));
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void mix_bwd_v4_kernel(const MixK k, const flo
         const int r = it / xper, q = it - r * xper;
         const int e = q / h4n, h = (q - e * h4n) * 4;
         const int64_t m = m0 + r;
-        const float* __restrict__ g = Y + m * ldy + d.g_col;
+        const float* __restrict__ g = Gt + m * ldg + d.g_col;
         const float* __restrict__ dp = dP + m * lddp + h;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = 0; c < k.inv_cnt[e]; ++c) {
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void mix_bwd_v4_kernel(const MixK k, const flo
             a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
         }
         const float acc = (a0 + a1) + (a2 + a3);
-        float* dst = dY + m * lddy + d.g_col + o * d.g_stride + j;
+        float* dst = dGt + m * lddg + d.g_col + o * d.g_stride + j;
         *dst = accumulate ? *dst + acc : acc;
     }
 }
@@ -228,7 +233,9 @@ __global__ __launch_bounds__(256) void mix_bwd_v4_kernel(const MixK k, const flo
 template <int NS>
 __global__ __launch_bounds__(256) void mix_bwd_ident_kernel(const MixK k, const float* __restrict__ dP, int64_t lddp,
                                                             const float* __restrict__ Y, int64_t ldy,
-                                                            float* __restrict__ dY, int64_t lddy, int accumulate, int64_t M) {
+                                                            const float* __restrict__ Gt, int64_t ldg,
+                                                            float* __restrict__ dY, int64_t lddy, float* __restrict__ dGt, int64_t lddg,
+                                                            int accumulate, int64_t M) {
     const swr_mix_desc& d = k.d;
     const int h4n = d.H >> 2;                                // lanes per row: a power of two <= 64
     const int64_t item = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) void mix_bwd_ident_kernel(const MixK k, const 
     float* __restrict__ out = dY + m * lddy;
     for (int o = 0; o < d.n_out; ++o) {
         const float4 v = *reinterpret_cast<const float4*>(dP + m * lddp + o * d.H + h);
-        const float* __restrict__ g = y + d.g_col + o * d.g_stride;
+        const float* __restrict__ g = Gt + m * ldg + d.g_col + o * d.g_stride;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             if (j < d.n_sel) {
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void mix_bwd_ident_kernel(const MixK k, const 
                 float pd = (v.x * x[j].x + v.y * x[j].y) + (v.z * x[j].z + v.w * x[j].w);
                 for (int off = 1; off < h4n; off <<= 1) pd += __shfl_xor(pd, off);
                 if (live && h == 0) {
-                    float* dst = out + d.g_col + o * d.g_stride + j;
+                    float* dst = dGt + m * lddg + d.g_col + o * d.g_stride + j;
                     *dst = accumulate ? *dst + pd : pd;
                 }
             }
@@ -277,8 +284,12 @@ __global__ __launch_bounds__(256) void mix_bwd_ident_kernel(const MixK k, const 
 }
 
 extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_t lddp, const float* Y, int64_t ldy,
-                               float* dY, int64_t lddy, int accumulate, int64_t M, void* stream) {
-    SWR_REQUIRE(desc && dP && Y && dY && M >= 0, SWR_ERR_ARG);
+                               const float* G, int64_t ldg, float* dY, int64_t lddy, float* dG, int64_t lddg, int accumulate,
+                               int64_t M, void* stream) {
+    SWR_REQUIRE(desc && dP && Y && dY && M >= 0 && (G == nullptr) == (dG == nullptr), SWR_ERR_ARG);
+    const float* Gt = G ? G : Y;
+    float* dGt = dG ? dG : dY;
+    if (!G) { ldg = ldy; lddg = lddy; }
     MixK k;
     const int rc = make_mix(desc, k);
     if (rc != SWR_OK) return rc;
@@ -293,10 +304,10 @@ extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_
             const dim3 grid(static_cast<unsigned>(swr_ceil_div(items, 256)));
             if (desc->n_sel <= 4)
                 hipLaunchKernelGGL(mix_bwd_ident_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), k, dP, lddp,
-                                   Y, ldy, dY, lddy, accumulate, M);
+                                   Y, ldy, Gt, ldg, dY, lddy, dGt, lddg, accumulate, M);
             else
                 hipLaunchKernelGGL(mix_bwd_ident_kernel<8>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), k, dP, lddp,
-                                   Y, ldy, dY, lddy, accumulate, M);
+                                   Y, ldy, Gt, ldg, dY, lddy, dGt, lddg, accumulate, M);
             return swr_launch_status();
         }
         // rows per workgroup: 32, fewer for short batches (no state is shared between rows; at M = 8192 256 workgroups walked
@@ -304,9 +315,10 @@ extern "C" int swr_moe_mix_bwd(const swr_mix_desc* desc, const float* dP, int64_
         int rpw = MIXB_ROWS;
         while (rpw > 4 && M / rpw < 1024) rpw >>= 1;
         hipLaunchKernelGGL(mix_bwd_v4_kernel, dim3(static_cast<unsigned>(swr_ceil_div(M, rpw))), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy, dY, lddy, accumulate, M, rpw);
+                           static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy, Gt, ldg, dY, lddy, dGt, lddg, accumulate, M, rpw);
         return swr_launch_status();
     }
+    SWR_REQUIRE(G == nullptr, SWR_ERR_UNSUPPORTED);
     const unsigned grid = static_cast<unsigned>(swr_ceil_div(M, MIX_WAVES) < 8192 ? swr_ceil_div(M, MIX_WAVES) : 8192);
     hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(MIX_WAVES * 64), MIX_WAVES * k.row_floats * sizeof(float),
                        static_cast<hipStream_t>(stream), k, dP, lddp, Y, ldy, dY, lddy, accumulate, M);

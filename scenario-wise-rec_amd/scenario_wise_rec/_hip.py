@@ -29,7 +29,7 @@ def _load():
 
 # the ABI number of include/swr.h these bindings were written against (SWR_ABI_VERSION): argument lists changed between
 # numbers, so a stale or variant libswr.so with another number would take shifted arguments -- refuse it
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 lib = _load()
 lib.swr_abi_version.restype = C.c_int
@@ -250,8 +250,8 @@ _SIGS = {
     "swr_bn_act_bwd_stats": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _P]),
     "swr_bn_bwd_finalize": (C.c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "swr_act_bwd_apply": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P]),
-    "swr_moe_mix_fwd": (C.c_int, [_P, _P, _L, _P, _L, _L, _P]),
-    "swr_moe_mix_bwd": (C.c_int, [_P, _P, _L, _P, _L, _P, _L, _I, _L, _P]),
+    "swr_moe_mix_fwd": (C.c_int, [_P, _P, _L, _P, _L, _P, _L, _L, _P]),
+    "swr_moe_mix_bwd": (C.c_int, [_P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _L, _P]),
     "swr_select_fwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P, _L, _P]),
     "swr_select_bwd": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _L, _P, _L, _P]),
     "swr_bce_workspace_bytes": (_Z, [_L]),

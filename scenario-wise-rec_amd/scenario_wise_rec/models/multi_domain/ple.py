@@ -103,26 +103,36 @@ class CGC(SwrModule):
         D, ns, nsh = self.domain_num, self.n_expert_specific, self.n_expert_shared
         ex, gs = self._members()
         K, nE = self.in_dim, len(ex)
+        g_sep = None
         if shared and self._fusable():
             y = self._bank_shared()(x, self.training)                  # [B, nE*H0 | gate columns]
             h0 = ex[0].block(0)[0].out_features
             xe, g_all = ops.split_cols(y, [nE * h0, y.shape[1] - nE * h0])     # (one gradient tensor in the backward)
             if ex[0].n_blocks > 1:
                 xe = mlp_bank_forward(ex, xe, shared_input=False, first_block=1)
-                y = torch.cat([xe, g_all], dim=1)
+                g_sep = g_all          # the gates stay where the first layer wrote them (no concatenation with the experts' output)
+                y = xe
         else:
             src = (lambda d: x) if shared else (lambda d: x[:, d * K:(d + 1) * K])
             xs = [m(src(i // ns if i < D * ns else D)) for i, m in enumerate(ex)]
             g_list = [g(src(d if d < D else D)) for d, g in enumerate(gs)]
             y = torch.cat(xs + g_list, dim=1)
         H_ = self.out_dim
-        g0 = nE * H_
         sel = [[d * ns + i for i in range(ns)] + [D * ns + j for j in range(nsh)] for d in range(D)]
+        if g_sep is not None and not ops.moe_mix_separate_ok(y, g_sep, ops.make_mix_desc(D, ns + nsh, H_, 0, 0, ns + nsh, sel)):
+            y, g_sep = torch.cat([y, g_sep], dim=1), None
+        g0 = 0 if g_sep is not None else nE * H_                        # first gate column (in g_sep / in y)
+        g_dom = g_shared = g_sep
+        gs0 = g0 + D * (ns + nsh)                                       # first column of the shared gate
+        if g_sep is not None and self.cur_level < self.n_level:
+            # two mixes read the gate tensor: each gets its own block (a view with its own gradient slot)
+            g_dom, g_shared = ops.split_cols(g_sep, [D * (ns + nsh), nE])
+            gs0 = 0
         desc = ops.make_mix_desc(D, ns + nsh, H_, 0, g0, ns + nsh, sel)
-        out = ops.MoeMix.apply(y, desc, y.shape[1])                     # [B, D*H]
+        out = ops.MoeMix.apply(y, desc, y.shape[1], g_dom)              # [B, D*H]
         if self.cur_level < self.n_level:
-            desc_s = ops.make_mix_desc(1, nE, H_, 0, g0 + D * (ns + nsh), nE, [list(range(nE))])
-            out = torch.cat([out, ops.MoeMix.apply(y, desc_s, y.shape[1])], dim=1)
+            desc_s = ops.make_mix_desc(1, nE, H_, 0, gs0, nE, [list(range(nE))])
+            out = torch.cat([out, ops.MoeMix.apply(y, desc_s, y.shape[1], g_shared)], dim=1)
         return out
 
     def forward(self, x_list):

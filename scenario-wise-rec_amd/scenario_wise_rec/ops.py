@@ -1840,6 +1840,7 @@ def make_mix_desc(n_out, n_sel, H_, x_col, g_col, g_stride, sel):
             d.sel[o][j] = sel[o][j]
     # columns of Y whose gradient swr_moe_mix_bwd writes: experts 0..max(sel) and the n_sel gates of every output
     n_expert = max(max(row[:n_sel]) for row in sel[:n_out]) + 1
+    d._n_expert = n_expert
     d._written = set(range(x_col, x_col + n_expert * H_))
     for o in range(n_out):
         d._written.update(range(g_col + o * g_stride, g_col + o * g_stride + n_sel))
@@ -1848,33 +1849,66 @@ def make_mix_desc(n_out, n_sel, H_, x_col, g_col, g_stride, sel):
 
 class MoeMix(Function):
     """pooled[:, o*H:(o+1)*H] = sum_j gate_o[:, j] * expert_{sel[o][j]}  (mmoe.py:48-49, ple.py:121-133).
-    `Y` holds the activated experts (from x_col) and gate probabilities (from g_col) side by side."""
+    `Y` holds the activated experts (from x_col) and gate probabilities (from g_col) side by side -- or, with `G`, the experts
+    alone and the gate probabilities sit in G (desc.g_col counted in G): PLE's gates are columns of the first layer's output
+    while the experts run a second layer (`ple.py:107-125`), and concatenating the two cost a copy pass each way."""
 
     @staticmethod
-    def forward(ctx, Y, desc, width_in):
+    def forward(ctx, Y, desc, width_in, G=None):
         H.require_device(Y)
         Y = H.f32c(Y)
         M = Y.shape[0]
         P = torch.empty((M, desc.n_out * desc.H), dtype=torch.float32, device=Y.device)
-        H.check(lib.swr_moe_mix_fwd(C.byref(desc), H.ptr(Y), Y.stride(0) if M > 1 else Y.shape[1], H.ptr(P),
-                                    P.shape[1], M, H.stream()), "swr_moe_mix_fwd")
-        ctx.desc, ctx.width_in = desc, width_in
-        ctx.save_for_backward(Y)
+        ctx.g_dst = getattr(G, "_swr_grad_dst", None) if G is not None else None
+        if G is not None:
+            G = H.f32c(G)
+        H.check(lib.swr_moe_mix_fwd(C.byref(desc), H.ptr(Y), Y.stride(0) if M > 1 else Y.shape[1], H.ptr(G),
+                                    (G.stride(0) if M > 1 else G.shape[1]) if G is not None else 0, H.ptr(P), P.shape[1], M,
+                                    H.stream()), "swr_moe_mix_fwd")
+        ctx.desc, ctx.width_in, ctx.has_g = desc, width_in, G is not None
+        if G is not None:
+            ctx.save_for_backward(Y, G)
+        else:
+            ctx.save_for_backward(Y)
         return P
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dP):
-        (Y,) = ctx.saved_tensors
+        Y = ctx.saved_tensors[0]
+        G = ctx.saved_tensors[1] if ctx.has_g else None
         dP = H.f32c(dP)
         M = Y.shape[0]
-        # the kernel writes every expert and gate column: a zero fill is only needed when Y has other columns
-        full = len(ctx.desc._written) == ctx.width_in
-        dY = (torch.empty if full else torch.zeros)((M, ctx.width_in), dtype=torch.float32, device=Y.device)
-        H.check(lib.swr_moe_mix_bwd(C.byref(ctx.desc), H.ptr(dP), dP.stride(0) if M > 1 else dP.shape[1], H.ptr(Y),
-                                    Y.stride(0) if M > 1 else Y.shape[1], H.ptr(dY), ctx.width_in, 0, M, H.stream()),
+        d = ctx.desc
+        # the kernel writes every expert and gate column: a zero fill is only needed when the tensors have other columns
+        if G is None:
+            full = len(d._written) == ctx.width_in
+            dY = (torch.empty if full else torch.zeros)((M, ctx.width_in), dtype=torch.float32, device=Y.device)
+            dG = None
+        else:
+            full = d._n_expert * d.H == ctx.width_in and d.x_col == 0
+            dY = (torch.empty if full else torch.zeros)((M, ctx.width_in), dtype=torch.float32, device=Y.device)
+            wg = G.shape[1]
+            g_full = d.g_col == 0 and d.g_stride == d.n_sel and d.n_out * d.n_sel == wg
+            # a block of a split_cols tensor: its gradient goes straight into that tensor's gradient (no copy in SplitCols.backward)
+            dG = _grad_dst_view(ctx.g_dst, M, wg, Y.device)
+            if dG is None:
+                dG = (torch.empty if g_full else torch.zeros)((M, wg), dtype=torch.float32, device=Y.device)
+            elif not g_full:
+                dG.zero_()
+        H.check(lib.swr_moe_mix_bwd(C.byref(d), H.ptr(dP), dP.stride(0) if M > 1 else dP.shape[1], H.ptr(Y),
+                                    Y.stride(0) if M > 1 else Y.shape[1], H.ptr(G),
+                                    (G.stride(0) if M > 1 else G.shape[1]) if G is not None else 0, H.ptr(dY), ctx.width_in,
+                                    H.ptr(dG), (dG.stride(0) if M > 1 else dG.shape[1]) if dG is not None else 0, 0, M, H.stream()),
                 "swr_moe_mix_bwd")
-        return dY, None, None
+        return dY, None, None, dG
+
+
+def moe_mix_separate_ok(X, G, desc):
+    """True when MoeMix can read the gate probabilities from a tensor of their own (the 16-byte path of swr_moe_mix_*)."""
+    return (X.is_cuda and X.dtype == torch.float32 and G.dtype == torch.float32 and desc.H % 4 == 0 and desc.x_col % 4 == 0
+            and X.stride(1) == 1 and G.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+            and os.environ.get("SWR_MIX_SEPARATE", "1") != "0")
 
 
 # =========================================================================== select / loss

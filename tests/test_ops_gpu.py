@@ -391,6 +391,44 @@ def test_fused_adam_matches_oracle():
         np.testing.assert_allclose(p.detach().cpu().numpy(), state[i], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("M,H_,n_expert,sel,n_before", [
+    (515, 32, 9, [[0, 1, 8], [2, 3, 8], [4, 5, 8], [6, 7, 8]], 576),     # PLE, config 4: 4 gates of 3 behind 576 other columns
+    (1000, 16, 4, [[0, 1, 2, 3]] * 3, 0),                                 # identity selection (the butterfly backward)
+    (77, 8, 5, [[0, 4], [1, 4], [2, 3]], 5)])                             # gate tensor at an odd column offset
+def test_moe_mix_with_the_gates_in_their_own_tensor(M, H_, n_expert, sel, n_before):
+    """MoeMix(X, desc, width, G): experts in X, gate probabilities in a column block of ANOTHER tensor (a split_cols view, as in
+    PLE: ple.py:107-125) -- same pooled output and gradients, bit for bit, as the concatenated form; the gate gradient lands in the
+    split_cols gradient tensor when that is 16-byte friendly."""
+    from scenario_wise_rec import ops
+    rng = np.random.default_rng(M + H_)
+    n_out, n_sel = len(sel), len(sel[0])
+    ng = n_out * n_sel
+    X0 = _dev(rng.standard_normal((M, n_expert * H_)).astype(np.float32))
+    W0 = _dev(rng.standard_normal((M, n_before + ng)).astype(np.float32))
+    dP = _dev(rng.standard_normal((M, n_out * H_)).astype(np.float32))
+    # concatenated form
+    Xa, Wa = X0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+    Ya = torch.cat([Xa, Wa[:, n_before:]], dim=1)
+    da = ops.make_mix_desc(n_out, n_sel, H_, 0, n_expert * H_, n_sel, sel)
+    Pa = ops.MoeMix.apply(Ya, da, Ya.shape[1])
+    Pa.backward(dP)
+    # separate form
+    Xb, Wb = X0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+    blocks = ops.split_cols(Wb, [n_before, ng]) if n_before else (None, ops.split_cols(Wb, [ng])[0])
+    db = ops.make_mix_desc(n_out, n_sel, H_, 0, 0, n_sel, sel)
+    assert ops.moe_mix_separate_ok(Xb, blocks[1], db)
+    Pb = ops.MoeMix.apply(Xb, db, Xb.shape[1], blocks[1])
+    loss = (Pb * dP).sum()
+    if n_before:
+        loss = loss + (blocks[0] * 2.0).sum()          # the other block takes a gradient too
+    loss.backward()
+    assert torch.equal(Pa, Pb)
+    assert torch.equal(Xa.grad, Xb.grad)
+    assert torch.equal(Wa.grad[:, n_before:], Wb.grad[:, n_before:])
+    if n_before:
+        assert bool((Wb.grad[:, :n_before] == 2.0).all())
+
+
 @pytest.mark.parametrize("M,H_,n_expert,sel,pad", [
     (1000, 32, 4, [[0, 1, 2, 3]] * 5, 0),                    # MMoE: every domain gate mixes every expert (16-byte path)
     (333, 16, 5, [[0, 1, 4], [2, 3, 4], [0, 1, 2]], 4),      # PLE-like subsets, spare columns in Y (stay zero)
