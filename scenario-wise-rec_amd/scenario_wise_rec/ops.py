@@ -1791,6 +1791,7 @@ class MatmulIO(Function):
     @staticmethod
     def forward(ctx, x, W, b, act=None):
         H.require_device(x, W)
+        ctx.pW, ctx.pb = W, b                    # the caller's objects: parameters whose .grad may live in the gradient arena
         x, W = H.f32c(x), H.f32c(W)
         M, K, N = x.shape[0], W.shape[0], W.shape[1]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
@@ -1823,11 +1824,25 @@ class MatmulIO(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
             gemm("nt", dy, W, dx, M, K, N)                    # dx[m,k] = sum_n dy[m,n] W[k,n]
-        dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
-        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_b else None
-        gemm_tn(x, dy, dW, M, K, N)                           # dW[k,n] = sum_m x[m,k] dy[m,n]
-        if db is not None:
-            colsum(dy, M, N, out=db)
+        # parameter gradients straight into the gradient arena where they live there (zeroed by the optimizer): autograd's
+        # AccumulateGrad is one tiny ATen add per parameter and step otherwise (HAMUR's adapter: 6 of them)
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            gW = _grad_alias([ctx.pW])
+            if gW is not None and tuple(gW.shape) == (K, N):
+                gemm_tn(x, dy, gW, M, K, N, accumulate=True)
+                _mark_touched([ctx.pW])
+            else:
+                dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
+                gemm_tn(x, dy, dW, M, K, N)                   # dW[k,n] = sum_m x[m,k] dy[m,n]
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            gb = _grad_alias([ctx.pb])
+            if gb is not None and tuple(gb.shape) == (N,):
+                colsum(dy, M, N, out=gb, accumulate=True)
+                _mark_touched([ctx.pb])
+            else:
+                db = torch.empty(N, dtype=torch.float32, device=x.device)
+                colsum(dy, M, N, out=db)
         return dx, dW, db, None
 
 
