@@ -55,7 +55,9 @@ struct V4Plan {
 // workgroup waiting for its softmax lanes.  Columns [0, n4) go to the float4 threads, the <= TAIL_MAX columns [n4, N) to
 // extra workgroups of the same launch, thread = (row group, column), TAIL_U rows in flight.
 #define TAIL_MAX 64
+#ifndef TAIL_U
 #define TAIL_U 4
+#endif
 
 static bool v4_split(const ActSpec& as, int N, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3, const void* p0, const void* p1,
                      const void* p2, const void* p3, const void* c0, const void* c1, const void* c2, const void* c3, int& n4) {
