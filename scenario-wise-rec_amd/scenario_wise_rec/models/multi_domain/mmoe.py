@@ -73,6 +73,11 @@ class MMOE(SwrModule):
             if experts[0].n_blocks > 1:
                 y_ex, y_gate = ops.split_cols(y, [ne * h0, y.shape[1] - ne * h0])     # (one gradient tensor in the backward)
                 ex = mlp_bank_forward(experts, y_ex, shared_input=False, first_block=1)
+                Hx = experts[0].out_dim
+                dsep = ops.make_mix_desc(D, ne, Hx, 0, 0, ne, [list(range(ne))] * D)
+                if self.training and ops.moe_mix_separate_ok(ex, y_gate, dsep):
+                    # the gates stay in the first layer's output (no concatenation pass, their gradient lands in split_cols' tensor)
+                    return mlp_bank_select(list(self.towers), ops.MoeMix.apply(ex, dsep, ex.shape[1], y_gate), domain_id)
                 y = torch.cat([ex, y_gate], dim=1)
         else:
             ex = torch.cat([m(embed_x) for m in experts], dim=1)
