@@ -13,8 +13,9 @@ step (one batch-load launch + one graph replay per step), so rows are not cache-
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with
 HIP events on the launch stream) and `cpu_baseline` (the numpy oracle timed on this box's host cores on a
-bounded sample).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), data parallel,
-weak scaling (65 536 rows per GPU).
+bounded sample).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), data parallel; the metric's
+configuration defaults to STRONG scaling there (the 65 536-row batch sharded by row, ctr_trainer.py:45-47) with the weak
+regime in `config.other_scaling`; the N = 1 line carries `config.strong_shard` (the 8 192-row shard timed on this GPU).
 """
 import argparse
 import copy
@@ -136,45 +137,70 @@ def time_kernel_events(fn, iters, stream, reps=20):
 
 
 def cpu_baseline(cfg, seconds_budget=20.0):
-    """The reference's CPU path restated (oracle/torch_port.py: torch CPU operators, checked against the numpy oracle and
-    the golden vectors), timed on this box: the SAME model, tables and batch size as the GPU run, fwd + BCE + bwd + dense
-    Adam over every table row.  torch's CPU kernels do not scale with the thread count on this step (on
-    the 2 x 64-core host of the GPU box 8-16 threads give 84 K samples/s, 64 threads 47 K, 256 threads 1 K), so the leg
-    first tries 8 / 16 / 32 / 64 threads with one step each and then times >= 3 steps at the fastest setting; `cores` is
-    that thread count."""
+    """The reference's CPU path restated (oracle/torch_port.py: torch CPU operators, every family pinned on the golden vectors),
+    timed on this box: the same model and batch shape as the GPU run, fwd + BCE + bwd + dense Adam over every table row
+    (SURVEY.md 8d).  torch's CPU kernels do not scale with the thread count on this step (on the 2 x 64-core host of the GPU
+    box 8-16 threads give 84 K samples/s at config 2, 64 threads 47 K, 256 threads 1 K), so the leg first tries 8 / 16 / 32 / 64
+    threads with one step each and then times >= 3 steps at the fastest setting; `cores` is that thread count.
+    Bounded sample: tables above 2^21 rows are cut to 2^21 rows (ids modulo) -- the CPU step's dense Adam over 2 x 50 M x 64
+    fp32 rows (config 5 / 6: 100 GB of parameter + gradient + moments) does not fit a test host -- and HAMUR, whose reference
+    forward materialises a [B, 128, 32] weight per sample, adapter and domain, runs at batch 4 096; both are named in `sample`."""
     from oracle.nn import Dense, Sparse
-    from oracle.torch_port import MMoEPort
+    from oracle.torch_port import TorchPort
     ncpu = os.cpu_count() or 1
-    B = cfg["batch"]
-    feats = [Dense(f"d{i}") for i in range(cfg["n_dense"])] + [Sparse(f"s{i}", v, cfg["embed_dim"]) for i, v in enumerate(cfg["vocabs"])]
-    model, _ = build_model(cfg)
+    cap = 1 << 21
+    cut = [v for v in cfg["vocabs"] if v > cap]
+    ccfg = dict(cfg, vocabs=[min(v, cap) for v in cfg["vocabs"]], on_device_init=False)
+    B = min(cfg["batch"], 4096) if cfg["family"].startswith("Hamur") else cfg["batch"]
+    dense = [Dense(f"d{i}") for i in range(ccfg["n_dense"])]
+    sparse = [Sparse(f"s{i}", v, ccfg["embed_dim"]) for i, v in enumerate(ccfg["vocabs"])]
+    hyper = copy.deepcopy(ccfg["hyper"])
+    if ccfg["family"] == "PPNet":
+        nid = ccfg["id_features"]
+        hyper.update(id_features=sparse[:nid], agn_features=dense + sparse[nid:])
+    else:
+        hyper["features"] = dense + sparse
+    model, _ = build_model(ccfg)
     state = {k: v.detach().numpy() for k, v in model.state_dict().items()}
     del model
-    batches = [synth_batch(cfg, B, seed=1 + j) for j in range(2)]
-    port = MMoEPort(feats, cfg["hyper"], state, threads=min(8, ncpu))
-    port.step(*batches[0])                      # warm-up (allocations, Adam state for 70 M parameters)
+    batches = []
+    for j in range(2):
+        xh, yh = synth_batch(cfg, B, seed=1 + j)
+        for i, v in enumerate(cfg["vocabs"]):
+            if v > cap:
+                xh[f"s{i}"] = xh[f"s{i}"] % cap
+        batches.append((xh, yh))
+    port = TorchPort(ccfg["family"], hyper, state, threads=min(8, ncpu))
+    port.step(*batches[0])                      # warm-up (allocations, Adam state for every table row)
     tried = {}
     for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
         torch.set_num_threads(th)
         t0 = time.perf_counter()
         port.step(*batches[1])
         tried[th] = time.perf_counter() - t0
-        if tried[th] > 2.5 * min(tried.values()):
-            break                               # more threads only get slower from here
+        if tried[th] > 2.5 * min(tried.values()) or sum(tried.values()) > seconds_budget:
+            break                               # more threads only get slower from here / the budget is spent on probing
     cores = min(tried, key=tried.get)
     torch.set_num_threads(cores)
     n, t0 = 0, time.perf_counter()
     while n < 3 or (time.perf_counter() - t0 < seconds_budget / 2 and n < 12):
         port.step(*batches[n % 2])
         n += 1
+        if n >= 1 and time.perf_counter() - t0 > 1.5 * seconds_budget:
+            break
     dt = time.perf_counter() - t0
-    return {"value": n * B / dt, "unit": "samples/s", "cores": cores, "cores_tried": sorted(tried), "host_logical_cpus": ncpu,
-            "kind": "port",
-            "sample": f"{n} full steps (fwd+BCE+bwd+dense Adam on all {sum(cfg['vocabs'])} table rows) at batch {B} after warm-up: "
-                      f"torch-CPU port of the reference step (oracle/torch_port.py) at the fastest of {sorted(tried)} threads "
-                      f"({cores}; host has {ncpu} logical CPUs, one step took " + ", ".join(f"{th}: {t:.2f} s" for th, t in sorted(tried.items())) + ")",
-            "reference_in_build_container": {"value": 46800.0, "unit": "samples/s", "cores": 8,
-                                             "note": "the reference itself, same config, 8 vCPU build container (SURVEY.md section 6)"}}
+    rows = sum(ccfg["vocabs"])
+    out = {"value": n * B / dt, "unit": "samples/s", "cores": cores, "cores_tried": sorted(tried), "host_logical_cpus": ncpu,
+           "kind": "port",
+           "sample": f"{n} full steps (fwd+BCE+bwd+dense Adam on all {rows} table rows) of {ccfg['family']} at batch {B} after warm-up: "
+                     f"torch-CPU port of the reference step (oracle/torch_port.py) at the fastest of {sorted(tried)} threads "
+                     f"({cores}; host has {ncpu} logical CPUs, one step took " + ", ".join(f"{th}: {t:.2f} s" for th, t in sorted(tried.items())) + ")"
+                     + (f"; tables of {cut} rows cut to {cap} rows (ids modulo): the CPU's dense Adam state for the full tables does not fit" if cut else "")
+                     + (f"; batch {B} instead of {cfg['batch']}: the reference's per-sample adapter weights [B, 128, 32] per domain" if B != cfg["batch"] else "")}
+    if cfg["name"].startswith("kuairand_mmoe4_e16_b65536") and B == 65536:
+        out["reference_in_build_container"] = {"value": 46800.0, "unit": "samples/s", "cores": 8,
+                                               "note": "the reference itself, same config, 8 vCPU build container (SURVEY.md section 6)"}
+    return out
 
 
 def _stage(msg):
@@ -192,16 +218,27 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: the configuration's batch PER GPU (default); strong: that batch is the GLOBAL batch, "
-                         "split by row over the GPUs (65 536 -> 8 192 per GPU at 8)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong: the configuration's batch is the GLOBAL batch, split by row over the GPUs (65 536 -> 8 192 per "
+                         "GPU at 8) -- what the reference's DataParallel does with one batch (ctr_trainer.py:45-47) and the default "
+                         "of the metric's configuration for N > 1; weak: that batch PER GPU (the default of configs 1, 3-6, whose "
+                         "`batch` already is the per-GPU shard of an 8-GPU configuration).  The other regime is reported beside "
+                         "it in `config.other_scaling`")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU batch override (0 = the configuration's): --config 2 --batch 8192 is the strong-scaling shard of "
+                         "the 65 536-row batch at 8 GPUs, runnable on one")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-shard", action="store_true", help="skip `config.strong_shard` (the 8 192-row shard of config 2 on this GPU)")
     ap.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the stand-alone kernel timing leg")
     ap.add_argument("--single-batch", action="store_true", help="replay ONE batch (cache-hot rows, no lazy-Adam lag): round-1 behaviour")
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids for the large tables (worst case for the gather)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.scaling is None:
+        args.scaling = "strong" if (args.config == 2 and args.gpus > 1 and not args.batch and cfg["batch"] % args.gpus == 0) else "weak"
+    if args.batch:
+        cfg = dict(cfg, batch=args.batch, name=f"{cfg['name']}_shard{args.batch}")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start one process per GPU ourselves (the driver's form: torch.distributed.run, one rank per GPU over
@@ -218,6 +255,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a five-line banner (version, hostname, library path) through C
+    # stdio when a communicator is created, and the buffer is flushed at exit -- BEHIND the line.  Everything but the line goes to
+    # stderr: fd 1 is pointed at fd 2 for the run and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -422,6 +465,12 @@ def main():
             roof.setdefault("also", {})["gather"] = gather_roofline(cfg, model, x, dev, args.steps, B, args.config)
         if roof is not None:
             roof.setdefault("also", {})["step"] = step_roofline(ms, args.config)
+    shard = None
+    if world == 1 and not use_dp and args.config == 2 and not args.batch and graph is not None and not args.no_strong_shard:
+        try:
+            shard = strong_shard_block(cfg, args, dev, ms)
+        except Exception as e:                     # noqa: BLE001  (the block is a report beside the line, never the line)
+            shard = {"error": f"{type(e).__name__}: {e}"}
     out = {
         "metric": "train samples/sec at batch 65 536, KuaiRand 5-domain MMoE, 1/2/4/8 MI355X" if args.config == 2
                   else "train samples/sec, " + cfg["name"],
@@ -432,7 +481,7 @@ def main():
                    "step": "fwd+BCE+bwd+Adam(all params; dense-Adam semantics on every table row, applied lazily but exactly)", "parallelism": f"dp{world}",
                    "ids": "uniform" if args.uniform_ids else "zipf1.05(large tables)+uniform", "hipgraph": graph is not None,
                    "batches_rotated": n_rot, "ms_per_step_single_batch_replayed": single_ms,
-                   "final_loss": final_loss, "scaling": args.scaling, "other_scaling": other, "process_group": ranks_info,
+                   "final_loss": final_loss, "scaling": args.scaling, "other_scaling": other, "strong_shard": shard, "process_group": ranks_info,
                    "dp_exchange": dp_exchange,
                    "precision_mode": ("bf16 perf mode (SWR_GEMM=bf16): ONE bf16 MFMA product per k-group, operands rounded to bf16 -- "
                                       "NOT the parity path (max logit error ~1e-3..1e-2 at these widths, tests/test_perf_mode_gpu.py); "
@@ -440,9 +489,82 @@ def main():
                                      "fp32-accurate: every fp32 product as six bf16 MFMA products, fp32 accumulate (parity path)"},
         "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1 and args.config == 2:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(out_fd, (json.dumps(out) + "\n").encode())
+
+
+def strong_shard_block(cfg, args, dev, ms_full, ways=8):
+    """`config.strong_shard` of the N = 1 line: the step of ONE rank of the 8-GPU strong-scaling run -- the metric's 65 536-row
+    batch sharded by row, 8 192 rows per GPU (`north_star`; reference `ctr_trainer.py:45-47`: DataParallel scatters one batch) --
+    timed on this GPU, (a) as the single-GPU graphed step and (b) through the N > 1 code path at world size 1 over RCCL (process
+    group, row-list all-gather, arena collective, merge: every launch and collective call of the 8-GPU step, its wire time not
+    included).  `projected_speedup_1_to_8` = this line's ms_per_step / (b): what 8 GPUs would reach if the collectives hid
+    completely -- an upper bound, reported because no 8-GPU node has been available to this build; the driver's own N = 8 run
+    supersedes it."""
+    import socket
+    import torch.distributed as dist
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec.trainers import CTRTrainer
+    from scenario_wise_rec.trainers.graph import GraphedStep
+    B8 = cfg["batch"] // ways
+    steps = max(args.steps, 100)
+
+    def fresh():
+        model, _ = build_model(cfg)
+        tr = CTRTrainer(model, cfg["name"] + f"_shard{B8}", optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device=str(dev))
+        tr.use_graph = False
+        model.train()
+        return tr
+
+    batches = []
+    for j in range(N_ROTATE):
+        xh, yh = synth_batch(cfg, B8, seed=9022 + 77 * j, zipf=not args.uniform_ids)
+        batches.append(({k: torch.from_numpy(v).to(dev) for k, v in xh.items()}, torch.from_numpy(yh).to(dev)))
+
+    def time_graph(g):
+        for i in range(2 * N_ROTATE):
+            g.load(*batches[i % N_ROTATE])
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            g.load(*batches[i % N_ROTATE])
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    tr = fresh()
+    g = GraphedStep(tr, batches[0][0], batches[0][1], warmup=max(2, args.warmup))
+    ms_graph = time_graph(g)
+    H.check_errors()
+    out = {"global_batch": cfg["batch"], "ways": ways, "per_gpu_batch": B8, "steps": steps, "ms_per_step_graphed": ms_graph,
+           "samples_per_s_per_gpu": B8 / ms_graph * 1e3}
+    del g, tr
+    try:
+        if not dist.is_initialized():
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from scenario_wise_rec.parallel import DataParallelStep
+        tr = fresh()
+        st = DataParallelStep(tr, 1)
+        g = st.capture(batches[0][0], batches[0][1], warmup=max(2, args.warmup))
+        ms_dp = time_graph(g)
+        H.check_errors()
+        out.update(ms_per_step_world1_rccl=ms_dp, world1_over_graphed=ms_dp / ms_graph,
+                   one_graph=bool(g._graphs[1] is None),
+                   projected_speedup_1_to_8=ms_full / ms_dp,
+                   projection_note="ms_per_step of this line (65 536 rows on one GPU) / the world-1 RCCL step of the 8 192-row shard: "
+                                   "the 1 -> 8 strong-scaling speed-up if the two collectives cost nothing on the wire (upper bound)")
+        del g, st, tr
+        dist.destroy_process_group()
+    except Exception as e:                         # noqa: BLE001
+        out["world1_rccl_error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def measure_roofline(cfg, model, trainer, x, dev, iters, B):

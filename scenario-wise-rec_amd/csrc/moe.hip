@@ -721,9 +721,14 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_bwd_kernel(const float* 
 // acc += t[lane E of the lane's 16-lane row] * h in ONE vector instruction: the DPP form of v_fmac with the row broadcast on its
 // first source (v_readlane + v_fmac are two).  `t` must not have been written by the two preceding instructions (DPP hazard):
 // the callers keep it loop-invariant.
-template <int E>
+// GUARD: the chunk's first product carries two wait states in front of it inside the SAME asm statement (hipcc's hazard
+// recogniser does not look into inline asm, and nothing else stops it from scheduling the load-to-register move of `t` right in front).
+template <int E, bool GUARD = false>
 __device__ __forceinline__ void rm_fmac_bcast(float& acc, float t, float h) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(h), "n"(E));
+    if constexpr (GUARD)
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(h), "n"(E));
+    else
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(h), "n"(E));
 }
 // one 16-element chunk starting at i0: acc[u] += tc[u][row element E] * hv[E] for E = 0 .. 15 (hv: the chunk's column values,
 // zero past k: those products add +-0 to sums that are never -0 ... so they are skipped instead, by a wave-uniform test)
@@ -731,7 +736,10 @@ template <int E>
 __device__ __forceinline__ void rm_chunk(float (&acc)[RM_DB], const float (&tc)[RM_DB], const float (&hv)[16], int n) {
     if (E < n) {
 #pragma unroll
-        for (int u = 0; u < RM_DB; ++u) rm_fmac_bcast<E>(acc[u], tc[u], hv[E]);
+        for (int u = 0; u < RM_DB; ++u) {
+            if (E == 0 && u == 0) rm_fmac_bcast<E, true>(acc[u], tc[u], hv[E]);
+            else rm_fmac_bcast<E>(acc[u], tc[u], hv[E]);
+        }
     }
     if constexpr (E + 1 < 16) rm_chunk<E + 1>(acc, tc, hv, n);
 }
@@ -770,8 +778,26 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_fwd2_kernel(const float*
         sh_n = static_cast<int>((a0 & 15u) >> 2);
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a0 - 4 * sh_n);
         const int n4 = (kk + sh_n + 3) >> 2;
+        // the caller's buffer is [Hm, Hm + B k k): the granule in front of sample 0 and the one behind sample B - 1 may reach
+        // outside it -- those two (at most) are read element by element, inside the buffer only
+        const float* const buf_lo = Hm;
+        const float* const buf_hi = Hm + B * kk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) hn[r] = lane + 64 * r < n4 ? src[lane + 64 * r] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < R; ++r) {
+            const float* q = reinterpret_cast<const float*>(src + lane + 64 * r);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane + 64 * r < n4) {
+                if (q >= buf_lo && q + 4 <= buf_hi) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (q >= buf_lo && q < buf_hi) v.x = q[0];
+                    if (q + 1 >= buf_lo && q + 1 < buf_hi) v.y = q[1];
+                    if (q + 2 >= buf_lo && q + 2 < buf_hi) v.z = q[2];
+                    if (q + 3 >= buf_lo && q + 3 < buf_hi) v.w = q[3];
+                }
+            }
+            hn[r] = v;
+        }
         fetch_t(bb, 0, tn);
     };
     if (b < B) fetch(b);

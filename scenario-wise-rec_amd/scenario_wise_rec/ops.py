@@ -490,6 +490,21 @@ def run_late_jobs():
         fn()
 
 
+def abort_step():
+    """Drop every piece of per-step state an aborted forward / backward (a failed hipGraph capture) may have left behind:
+    held-back jobs, deferred forks, riders, pending counters and the tensors kept alive for the side branches.  The caller
+    synchronises the device first and zeroes the gradients afterwards; nothing queued here is run."""
+    _late["jobs"] = []
+    _late["on"], _late["rows_event"], _late["rows_recorded"] = False, None, False
+    _side["deferred"] = []
+    _side["jobs"] = []
+    _side["pending"] = 0
+    _side["queued"] = False
+    _side["keep"].clear()
+    _dw["pending"] = 0
+    _dw["riders"] = []
+
+
 def _split_like(flat, tensors):
     """Slices of `flat` (first-dim concatenation) shaped like each of `tensors`."""
     out, off = [], 0

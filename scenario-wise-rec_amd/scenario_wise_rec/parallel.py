@@ -333,12 +333,39 @@ class DataParallelStep(object):
         snap = opt.host_counts() if hasattr(opt, "host_counts") else None
         one = ONE_GRAPH == "1" or (ONE_GRAPH == "auto" and dist.get_backend(self.group) == "nccl")
         if one:
+            err = None
             try:
-                return self._capture_one(snap)
+                self._capture_one(snap)
             except Exception as e:                  # noqa: BLE001  (a runtime that cannot capture its collectives)
-                import sys
-                print(f"[parallel] one-graph capture failed ({type(e).__name__}: {e}); three graphs", file=sys.stderr)
-                torch.cuda.synchronize()
+                err = e
+            # the choice is COLLECTIVE: one rank on three graphs beside seven on one would issue different collective
+            # sequences and hang.  (A capture executes nothing, so every rank reaches this eager all-reduce.)
+            bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.y.device)
+            torch.cuda.synchronize()
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            if int(bad.item()) == 0:
+                return self
+            if ONE_GRAPH == "1":
+                raise ops.H.SwrError(f"SWR_DP_ONE_GRAPH=1: the one-graph capture failed on "
+                                     f"{'this rank' if err is not None else 'another rank'}: {err!r}")
+            import sys
+            print(f"[parallel] one-graph capture failed ({'here: ' + repr(err) if err is not None else 'on another rank'}); "
+                  "three graphs", file=sys.stderr)
+            # whatever the aborted capture queued (held-back weight-gradient jobs that would otherwise run AGAIN in the second
+            # graph below, pending side-branch counters, sparse row lists pointing into the released capture pool) is dropped
+            self._graphs = None
+            ops.abort_step()
+            if snap is not None:
+                opt.restore_host_counts(snap)
+            for p in self.trainer.model.parameters():
+                if getattr(p, "_swr_sparse_grad", None) is not None:
+                    p._swr_sparse_grad = None          # a row list the aborted step's optimizer never consumed
+            self.trainer.model.zero_grad()
+            torch.cuda.synchronize()
+            # an eager step re-establishes the exchange buffers and the in-place row-list slots the capture asserts on
+            self.train_step(self.x, self.y)
+            torch.cuda.synchronize()
+            snap = opt.host_counts() if hasattr(opt, "host_counts") else None
         g1 = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events while this thread captures; in the default (global) mode
         # that poll would invalidate the capture

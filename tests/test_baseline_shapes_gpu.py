@@ -54,7 +54,7 @@ def oracle_for(cfg, state):
     return OracleModel(cfg["family"], hyper, st, dtype=np.float64)
 
 
-def run_config(cfg, hash_seeds=None, seed=0, full_size=False):
+def run_config(cfg, hash_seeds=None, seed=0, full_size=False, max_kinked=None):
     """full_size: gradients are compared with _golden.KinkTolerantGradCheck (ReLU units within fp32 rounding of zero, see
     there) and the state after Adam may differ by one step where a gradient entry changed sign."""
     from scenario_wise_rec import _hip as H
@@ -109,7 +109,7 @@ def run_config(cfg, hash_seeds=None, seed=0, full_size=False):
         else:
             np.testing.assert_allclose(got, g, rtol=0, atol=gtol[k], err_msg="grad " + k)
     if full_size:
-        kinks.finish()
+        kinks.finish(max_kinked)
     for k, prm in named.items():
         if k not in ograds:                  # reference grad None (PPNet's agnostic tables): untouched
             assert not getattr(prm, "_swr_touched", False), k

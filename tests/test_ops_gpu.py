@@ -1151,7 +1151,7 @@ def test_tower_head_select_bce_is_bitwise_the_three_launch_path(M, G, K, Hd, ddt
 
 
 @pytest.mark.parametrize("B,D,k,offset", [(4096, 1, 35, 0), (4099, 1, 35, 0), (1000, 3, 8, 0), (513, 2, 35, 1), (3, 1, 5, 0),
-                                          (40000, 1, 35, 0)])
+                                          (40000, 1, 35, 0), (32768, 8, 35, 0), (4099, 8, 35, 0), (4099, 8, 35, 1), (4100, 11, 20, 3)])
 def test_rowmat_sample_blocks(B, D, k, offset):
     """swr_rowmat_fwd / _bwd stage four samples per workgroup with 16-byte accesses when the tensors allow it: full and
     ragged last groups, operands that are NOT 16-byte aligned (views at an odd element offset), more samples than the grid
@@ -1173,6 +1173,33 @@ def test_rowmat_sample_blocks(B, D, k, offset):
     torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(T.grad.double(), T64.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(Hm.grad.double(), H64.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,D,k,offset", [(32768, 8, 35, 0), (4099, 8, 35, 1), (4100, 11, 20, 3), (4096, 1, 35, 0), (5000, 3, 8, 2)])
+def test_rowmat_pipelined_forward_is_bitwise_the_plain_one(B, D, k, offset):
+    """swr_rowmat_fwd takes `rowmat_fwd2_kernel` (next sample prefetched into registers, DPP row-broadcast FMAs) from 4 096 samples
+    on and `rowmat_fwd_kernel` below: same sums in the same order, so the same bits -- checked by running the long batch whole
+    (pipelined) and in slices of 2 048 samples (plain), at HAMUR's D = 8 (register-tile rows 1..7) and a D past one tile; the
+    first / last sample of an unaligned buffer take the element-wise edge loads.  Guard words around the output stay untouched."""
+    from scenario_wise_rec import _hip as H
+    g = torch.Generator(device="cuda").manual_seed(B * 31 + D * 7 + k)
+    bufT = torch.randn(B * D * k + offset, device="cuda", generator=g)
+    bufH = torch.randn(B * k * k + offset, device="cuda", generator=g)
+    T, Hm = bufT[offset:].view(B, D, k), bufH[offset:].view(B, k, k)
+    guard = 64
+    full = torch.full((B * D * k + 2 * guard,), 7.25, device="cuda")
+    out = full[guard:guard + B * D * k].view(B, D, k)
+    H.check(H.lib.swr_rowmat_fwd(H.ptr(T), H.ptr(Hm), H.ptr(out), B, D, k, H.stream()), "swr_rowmat_fwd")
+    ref = torch.empty(B, D, k, device="cuda")
+    step = 2048
+    for b0 in range(0, B, step):
+        n = min(step, B - b0)
+        H.check(H.lib.swr_rowmat_fwd(H.ptr(T[b0:b0 + n]), H.ptr(Hm[b0:b0 + n]), H.ptr(ref[b0:b0 + n]), n, D, k, H.stream()), "swr_rowmat_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert bool((full[:guard] == 7.25).all()) and bool((full[guard + B * D * k:] == 7.25).all())
+    want = torch.einsum("bdi,bij->bdj", T[:64].double(), Hm[:64].double())
+    torch.testing.assert_close(out[:64].double(), want, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("uses", [2, 3])
