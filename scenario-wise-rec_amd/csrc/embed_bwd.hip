@@ -157,6 +157,8 @@ struct HostPlan {
     int64_t sparse_acc_elems;
     size_t off_k0, off_k1, off_v0, off_v1, off_hist, off_acc_hi, off_acc_lo, total;
     int n_passes;
+    bool rank_sort;       // the segments are short: counting sort, one launch, result in buffer 1
+    int64_t max_keys;
     int n_chunks;
 };
 
@@ -319,6 +321,17 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         for (int t = 0; t < n_tables; ++t)
             if (!direct[t] && !segsum[t]) max_keys = std::max<int64_t>(max_keys, count[t]);
         sort_choose_tile(p.sm, m.n, max_keys);
+        // short segments (a strong-scaling shard, a short batch): ONE counting launch instead of two per radix pass
+        double work = 0;
+        for (int t = 0; t < n_tables; ++t)
+            if (!direct[t] && !segsum[t]) work += static_cast<double>(count[t]) * static_cast<double>(count[t]);
+        bool keys_fit = true;                                          // (the counting sort adds 1 to a key: none may be 0xFFFFFFFF)
+        for (int t = 0; t < n_tables; ++t)
+            if (!direct[t] && !segsum[t] && count[t] > 0 && m.tab[t].vocab > 0xFFFFFFFFll) keys_fit = false;
+        p.rank_sort = rank_sort_enabled() && keys_fit && m.n > 0 && max_keys <= RANK_SORT_MAX_KEYS &&
+                      work <= static_cast<double>(RANK_SORT_MAX_WORK);
+        p.max_keys = max_keys;
+        if (p.rank_sort) { p.sm.items = 1; p.sm.tile = RANK_EPB; p.sm.fold_scan = 0; }
     }
     m.chunk = CHUNK_MAX;
     while (m.chunk > 8 && m.n / m.chunk < 16384) m.chunk >>= 1;
@@ -398,6 +411,14 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
             return nb;
         };
         int64_t target = DIRECT_TARGET;
+        {
+            // short batches: at the full target a strong-scaling shard (8 192 rows, 18 row-range parts) is 54 workgroups walking
+            // 3 072 samples each on a 256-CU chip -- the launch is one long latency chain.  Halve the chunks until the grid reaches
+            // SWR_DIRECT_MIN_BLOCKS (more, smaller slabs for the finalise launch: a few MB at these sizes), not below 512 samples
+            const char* e = getenv("SWR_DIRECT_MIN_BLOCKS");
+            const int64_t min_blocks = e ? atoll(e) : 192;
+            while (min_blocks > 0 && count_blocks(target) < min_blocks && target / 2 >= 512 * 16) target /= 2;
+        }
         if (count_blocks(target) > DIRECT_RESIDENT)
             for (int64_t t2 = target + target / 16; t2 <= target + target / 2; t2 += target / 16)
                 if (count_blocks(t2) <= DIRECT_RESIDENT) { target = t2; break; }
@@ -1055,8 +1076,29 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
             } else {
                 emit(ti, cur, head, e, s_hi, s_lo, true, gid);
             }
-            // only the first walker can meet a run that started in another workgroup: find where it starts
-            if ((info & 5) && w == 0 && t.mode == 1) head_h = lower_bound_key(ck, seg0, i0, key_h);
+        }
+        // only the first walker can meet a run that started in another workgroup: find where it starts.  The whole first WAVE
+        // searches for it, 64 probes per round (three dependent loads for a 65 536-entry segment; the one-lane binary search
+        // this replaces made 16 -- under Zipf ids most workgroups open inside a hot row's run, and that chain was most of the launch)
+        if (threadIdx.x < 64) {
+            const int need = __builtin_amdgcn_readfirstlane((valid && (info & 5) && t.mode == 1) ? 1 : 0);    // (lane 0 = walker 0)
+            if (need) {
+                const uint32_t skey = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(key_h)));
+                int lo = __builtin_amdgcn_readfirstlane(static_cast<int>(seg0));       // (m.n < 2^31: 40 slots x 2^24 samples at most ... checked by the plan)
+                int hi = __builtin_amdgcn_readfirstlane(static_cast<int>(i0));
+                const int lane = static_cast<int>(threadIdx.x);
+                while (lo < hi) {
+                    const int step = (hi - lo + 63) / 64;
+                    const int p = lo + lane * step;
+                    const bool less = p < hi && ck[p] < skey;                   // monotone in the lane: sorted keys
+                    const int c = __popcll(__ballot(less));
+                    if (c == 0) { hi = lo; break; }
+                    const int nlo = lo + (c - 1) * step + 1;
+                    hi = c == 64 ? hi : min(hi, lo + c * step);
+                    lo = nlo;
+                }
+                if (w == 0) head_h = hi;
+            }
         }
         sh_sum[0][threadIdx.x] = hh; sh_sum[1][threadIdx.x] = hl;
         sh_sum[2][threadIdx.x] = th; sh_sum[3][threadIdx.x] = tl;
@@ -1227,15 +1269,32 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         rc = swr_zero_async(acc_hi, zero_bytes, st);
         if (rc != SWR_OK) return rc;
     }
-    if ((phases & 1) && n > 0) {
+    if ((phases & 1) && n > 0 && p.rank_sort) {
+        // short segments: the counting sort reads the lookup's keys itself (no build_keys launch) and carries the zero-fill
+        RankSrc src;
+        std::memset(&src, 0, sizeof(src));
+        src.keys = keys; src.B = B;
+        int ns = 0;
+        for (int t = 0; t < m.n_tables; ++t) {
+            src.first[t] = static_cast<int16_t>(ns);
+            // the slots of table t in segment order (slot_dst grows with the slot index inside a table)
+            for (int q = 0; q < m.n_sorted_slots; ++q)
+                if (slots[m.sorted_slot[q]].table_id == t) src.slot[ns++] = m.sorted_slot[q];
+        }
+        for (int t = m.n_tables; t <= MAX_SLOTS; ++t) src.first[t] = static_cast<int16_t>(ns);
+        src.zero = reinterpret_cast<uint4*>(acc_hi);
+        src.zero16 = zero_in_keys ? static_cast<int64_t>(zero_bytes / 16) : 0;
+        rank_sort_launch(p.sm, src, p.max_keys, kbuf, vbuf, st);
+    } else if ((phases & 1) && n > 0) {
         hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
                            st, m, keys, kbuf[0], vbuf[0], reinterpret_cast<uint4*>(acc_hi),
                            zero_in_keys ? static_cast<int64_t>(zero_bytes / 16) : 0);
         radix_sort_launch(p.sm, p.n_passes, kbuf, vbuf, hist, st);
     }
     if (!(phases & 6)) return swr_launch_status();
-    const uint32_t* ck = kbuf[p.n_passes & 1];               // where the last pass left the sorted entries
-    const uint32_t* sv = vbuf[p.n_passes & 1];
+    const int sorted_buf = p.rank_sort ? 1 : (p.n_passes & 1);
+    const uint32_t* ck = kbuf[sorted_buf];                   // where the last pass left the sorted entries
+    const uint32_t* sv = vbuf[sorted_buf];
 
     if (phases & 4) {
         float* part = reinterpret_cast<float*>(ws + p.off_part);

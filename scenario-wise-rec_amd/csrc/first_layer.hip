@@ -644,6 +644,16 @@ extern "C" int swr_fl_keys(const swr_fl_plan* plan, void* workspace, uint32_t* e
 }
 
 // ------------------------------------------------------------------------------------------------ forward product
+// Short batches: when a wave per 32-row tile leaves most of the chip idle (fewer than 2 workgroups per CU ... 256 CUs x 4 waves),
+// the products spread their column tiles over the grid's y dimension (NA = 1 forms).  SWR_FL_SPLIT=0 / 1 forces the choice
+// (read per call: the tests compare both forms in one process).
+static bool fl_split_columns(int64_t n_tiles, int nt) {
+    if (nt < 2) return false;
+    const char* e = getenv("SWR_FL_SPLIT");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return n_tiles * nt <= 2048;          // rows x tiles up to two waves per SIMD: 8 192 rows x 5 tiles = 1 280 waves
+}
+
 typedef __attribute__((address_space(3))) void* fl_lds_ptr;
 typedef __attribute__((address_space(1))) const void* fl_glb_ptr;
 
@@ -662,11 +672,20 @@ struct FlFwdK {
     int NR, NOg, ncr, nco, n_tiles;
 };
 
-template <int NT>
+// NA = column tiles a wave accumulates.  NA == NT: the wave owns all N columns (the long-batch form).  NA == 1 (SHORT batches): the
+// grid's y dimension walks the NT column tiles -- NT times the workgroups, each fetching only its tile's weight pieces.  At the 8 192
+// rows of a strong-scaling shard the long-batch form is 64 workgroups of four 540-MFMA chains on a 256-CU chip.  Every output element
+// sees the same products in the same order: identical bits.
+template <int NT, int NA = NT>
 __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
-    constexpr int PITCH_U4 = ((6 * NT + 3) / 4 * 4) * 64;       // uint4 per chunk (global pitch = LDS buffer size)
-    constexpr int PPW = PITCH_U4 / 64 / 4;                      // 1-KB DMA pieces per wave per chunk
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[]; // [2][PITCH_U4]
+    static_assert(NA == NT || NA == 1, "a wave takes all column tiles or one");
+    constexpr bool SPLIT = NA != NT;
+    constexpr int PITCH_U4 = ((6 * NT + 3) / 4 * 4) * 64;       // uint4 per chunk in HBM (the long-batch form's LDS buffer size too)
+    constexpr int LPITCH_U4 = SPLIT ? 8 * 64 : PITCH_U4;        // uint4 per LDS buffer: split form = 2 groups x 3 terms (+ 2 unused) pieces
+    constexpr int GSTRIDE = SPLIT ? 3 * 64 : NT * 3 * 64;       // uint4 from a chunk's first group to its second, in LDS
+    constexpr int PPW = PITCH_U4 / 64 / 4;                      // 1-KB DMA pieces per wave per chunk (long-batch form)
+    const int t0 = SPLIT ? static_cast<int>(blockIdx.y) : 0;    // first column tile of this workgroup
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[]; // [2][LPITCH_U4]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int i = lane & 31, s = lane >> 5;
@@ -676,9 +695,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
     const int NR = k.NR, ncr = k.ncr, nct = k.ncr + k.nco;
     const char* __restrict__ wsb = k.ws;
 
-    f32x16 acc[NT];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NA; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -701,6 +720,19 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
     };
     // weights of chunk c -> LDS buffer: PITCH_U4 / 64 DMA pieces of 1 KB, PPW per wave
     auto dma_chunk = [&](int c, int buf) {
+        if constexpr (SPLIT) {
+            // the six pieces (group, term) of column tile t0: wave w copies pieces w and w + 4
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = wave + 4 * u;                          // (wave-uniform)
+                if (q < 6) {
+                    const int gq = q / 3, term = q - 3 * gq;
+                    const uint4* src = k.b3 + static_cast<size_t>(c) * PITCH_U4 + gq * (NT * 3 * 64) + (t0 * 3 + term) * 64 + lane;
+                    uint4* dst = lds + buf * LPITCH_U4 + q * 64;
+                    __builtin_amdgcn_global_load_lds((fl_glb_ptr)src, (fl_lds_ptr)dst, 16, 0, 0);
+                }
+            }
+        } else {
         const uint4* src = k.b3 + static_cast<size_t>(c) * PITCH_U4 + wave * (PPW * 64) + lane;
         uint4* dst = lds + buf * PITCH_U4 + wave * (PPW * 64);
 #ifndef FLF_NO_DMA
@@ -708,6 +740,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
         for (int u = 0; u < PPW; ++u)
             __builtin_amdgcn_global_load_lds((fl_glb_ptr)(src + u * 64), (fl_lds_ptr)(dst + u * 64), 16, 0, 0);
 #endif
+        }
     };
     // six (real group) or three (exact A: one-hot group) products per column tile, small terms first
     auto mma_group = [&](const uint4* bp, bf16x8 ah, bf16x8 am, bf16x8 al, auto exact_c) {
@@ -717,7 +750,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
         return;
 #endif
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NA; ++t) {
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
             const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
@@ -763,7 +796,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
         for (int gq = 0; gq < 2; ++gq) {
             constexpr int dummy = 0; (void)dummy;
             const int slot = 2 * BUF + gq;
-            const uint4* bp = lds + BUF * PITCH_U4 + gq * (NT * 3 * 64) + lane;
+            const uint4* bp = lds + BUF * LPITCH_U4 + gq * GSTRIDE + lane;
             // (an odd group count leaves the second half of the last chunk empty: its ring slot was never loaded, and
             // whatever bits it holds -- NaN patterns included -- must not meet the zero weights)
             if (2 * C + gq < NR)
@@ -825,7 +858,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
             f[1] = ((byte >> 2) & 1u) * 0x3F80u | ((byte >> 3) & 1u) * 0x3F800000u;
             f[2] = ((byte >> 4) & 1u) * 0x3F80u | ((byte >> 5) & 1u) * 0x3F800000u;
             f[3] = ((byte >> 6) & 1u) * 0x3F80u | ((byte >> 7) & 1u) * 0x3F800000u;
-            const uint4* bp = lds + buf * PITCH_U4 + gq * (NT * 3 * 64) + lane;
+            const uint4* bp = lds + buf * LPITCH_U4 + gq * GSTRIDE + lane;
             const bf16x8 ah = __builtin_bit_cast(bf16x8, f);
             if (q < k.NOg) mma_group(bp, ah, ah, ah, std::true_type{});
         }
@@ -843,14 +876,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_fwd_kernel(const FlFwdK k) {
     {
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NA; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += acc[t][r];
         if (sum == 12345.678f) k.e.C[T * 32 + i] = sum;
         return;
     }
 #endif
-    rows_epilogue<NT>(k.e, k.n_tiles, acc, 0, T, T * 32, 0, i, s);
+    rows_epilogue<NA>(k.e, k.n_tiles, acc, 0, T, T * 32, 32 * t0, i, s);
 }
 
 extern "C" int swr_fl_fwd(const swr_fl_plan* plan, const void* workspace, const float* bias, float* Z, int64_t ldz,
@@ -873,6 +906,17 @@ extern "C" int swr_fl_fwd(const swr_fl_plan* plan, const void* workspace, const 
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(h.n_tiles, 4)));
     const unsigned lds = static_cast<unsigned>(2 * fl_pitch_blocks(h.NT) * 1024);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (fl_split_columns(h.n_tiles, h.NT)) {
+        // short batch: one column tile per workgroup (grid y), 16 KB of LDS
+        const dim3 grid2(grid.x, static_cast<unsigned>(h.NT));
+        switch (h.NT) {
+            case 2: hipLaunchKernelGGL((fl_fwd_kernel<2, 1>), grid2, dim3(FL_THREADS), 16 * 1024, st, k); break;
+            case 3: hipLaunchKernelGGL((fl_fwd_kernel<3, 1>), grid2, dim3(FL_THREADS), 16 * 1024, st, k); break;
+            case 4: hipLaunchKernelGGL((fl_fwd_kernel<4, 1>), grid2, dim3(FL_THREADS), 16 * 1024, st, k); break;
+            default: hipLaunchKernelGGL((fl_fwd_kernel<5, 1>), grid2, dim3(FL_THREADS), 16 * 1024, st, k); break;
+        }
+        return swr_launch_status();
+    }
 #define FL_GO(NTV)                                                                                                      \
     do {                                                                                                                \
         if (lds >= 64 * 1024 && !swr_raise_lds(reinterpret_cast<const void*>(fl_fwd_kernel<NTV>), 80 * 1024)) return SWR_ERR_LAUNCH; \
@@ -1016,12 +1060,19 @@ struct FlDxK {
 #define FL_XLOAD(dst, voff, sbase, OFF) \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 
-template <int NT>
+// NA: as in fl_fwd_kernel -- NA == 1 spreads the NT output column tiles over the grid's y dimension (short batches); every
+// workgroup column rebuilds the dZ fragment (loads from L2, a few VALU), the first one writes dZ out where it is wanted.
+template <int NT, int NA = NT>
 __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
+    static_assert(NA == NT || NA == 1, "a wave takes all column tiles or one");
+    constexpr bool SPLIT = NA != NT;
     constexpr int PITCH_U4 = ((6 * NT + 3) / 4 * 4) * 64;
+    constexpr int LPITCH_U4 = SPLIT ? 8 * 64 : PITCH_U4;
+    constexpr int GSTRIDE = SPLIT ? 3 * 64 : NT * 3 * 64;
     constexpr int PPW = PITCH_U4 / 64 / 4;
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];          // [2][PITCH_U4] weights | 4 x 160 coefficients
-    float* coef = reinterpret_cast<float*>(lds + 2 * PITCH_U4);          // ca | cb | cc | mean, 160 each (zero past K)
+    const int ct0 = SPLIT ? static_cast<int>(blockIdx.y) : 0;            // first output column tile of this workgroup
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];          // [2][LPITCH_U4] weights | 4 x 160 coefficients
+    float* coef = reinterpret_cast<float*>(lds + 2 * LPITCH_U4);         // ca | cb | cc | mean, 160 each (zero past K)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int i = lane & 31, s = lane >> 5;
@@ -1045,9 +1096,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
     const uint32_t oy_t0 = static_cast<uint32_t>(row) * k.lddy_b + t0, oy_t1 = static_cast<uint32_t>(row) * k.lddy_b + t1;
     const uint32_t oz_t0 = static_cast<uint32_t>(row) * k.ldz_b + t0, oz_t1 = static_cast<uint32_t>(row) * k.ldz_b + t1;
 
-    f32x16 acc[NT];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NA; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -1076,11 +1127,24 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
         }
     };
     auto dma_chunk = [&](int c, int buf) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = wave + 4 * u;                          // piece (group, term) of column tile ct0; (wave-uniform)
+                if (q < 6) {
+                    const int gq = q / 3, term = q - 3 * gq;
+                    const uint4* src = k.b3x + static_cast<size_t>(c) * PITCH_U4 + gq * (NT * 3 * 64) + (ct0 * 3 + term) * 64 + lane;
+                    uint4* dst = lds + buf * LPITCH_U4 + q * 64;
+                    __builtin_amdgcn_global_load_lds((fl_glb_ptr)src, (fl_lds_ptr)dst, 16, 0, 0);
+                }
+            }
+        } else {
         const uint4* src = k.b3x + static_cast<size_t>(c) * PITCH_U4 + wave * (PPW * 64) + lane;
         uint4* dst = lds + buf * PITCH_U4 + wave * (PPW * 64);
 #pragma unroll
         for (int u = 0; u < PPW; ++u)
             __builtin_amdgcn_global_load_lds((fl_glb_ptr)(src + u * 64), (fl_lds_ptr)(dst + u * 64), 16, 0, 0);
+        }
     };
 
     a_issue(0, ar[0]);
@@ -1098,7 +1162,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
     __syncthreads();                     // (the coefficients too)
     __builtin_amdgcn_sched_barrier(0);
 
-    float* __restrict__ dzrow = k.dZ ? k.dZ + row * k.lddz : nullptr;      // null: the weight-gradient product recomputes dZ (swr_fl_dw_bn)
+    float* __restrict__ dzrow = (k.dZ && ct0 == 0) ? k.dZ + row * k.lddz : nullptr;   // null: the weight-gradient product recomputes dZ (swr_fl_dw_bn)
     // dZ of the lane's 8 columns of group g (the operations of act_bwd_apply_v4_kernel, bn.hip, in its order), written out,
     // and its three bf16 terms
     auto make_frag = [&](int g, const fl_u32x4 (&raw)[4], bf16x8& ah, bf16x8& am, bf16x8& al) {
@@ -1122,7 +1186,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
     };
     auto mma_group = [&](const uint4* bp, bf16x8 ah, bf16x8 am, bf16x8 al) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NA; ++t) {
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 0) * 64]);
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 1) * 64]);
             const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(t * 3 + 2) * 64]);
@@ -1152,9 +1216,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
         __builtin_amdgcn_sched_barrier(0);       // the slots' values are consumed before their registers are re-loaded
         if (2 * C + 4 < ng) a_issue(2 * C + 4, ar[2 * BUF]);
         if (2 * C + 5 < ng) a_issue(2 * C + 5, ar[2 * BUF + 1]);
-        const uint4* bp = lds + BUF * PITCH_U4 + lane;
+        const uint4* bp = lds + BUF * LPITCH_U4 + lane;
         mma_group(bp, h0, m0_, l0);
-        if (g1_on) mma_group(bp + NT * 3 * 64, h1, m1, l1);
+        if (g1_on) mma_group(bp + GSTRIDE, h1, m1, l1);
         constexpr int NB = 2 * (BUF ^ 1);
         const int n_issued = __builtin_amdgcn_readfirstlane(min(2, max(0, ng - (2 * C + 4))));
         fl_u32x4 t0_ = ar[NB][0], t1_ = ar[NB][1], t2_ = ar[NB][2], t3_ = ar[NB][3], t4_ = ar[NB + 1][0], t5_ = ar[NB + 1][1],
@@ -1189,7 +1253,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void fl_dx_kernel(const FlDxK k) {
     swr_gemm_args e;
     e.M = k.M; e.N = k.n_out; e.C = k.dX; e.ldc = k.lddx; e.bias = nullptr; e.stat_partials = nullptr; e.groups = 1; e.gsC = 0;
     e.gsBias = 0; e.c_act = 0; e.accumulate = 0;
-    rows_epilogue<NT>(e, k.n_tiles, acc, 0, T, T * 32, 0, i, s);
+    rows_epilogue<NA>(e, k.n_tiles, acc, 0, T, T * 32, 32 * ct0, i, s);
 }
 
 extern "C" int swr_bn_bwd_dx_supported(int K, int n_out) {
@@ -1219,6 +1283,17 @@ extern "C" int swr_bn_bwd_dx(const swr_fl_plan* plan, const void* fl_workspace, 
     const dim3 grid(static_cast<unsigned>(swr_ceil_div(h.n_tiles, 4)));
     const unsigned lds = static_cast<unsigned>(2 * fl_pitch_blocks(nt) * 1024 + 4 * 160 * sizeof(float));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (fl_split_columns(h.n_tiles, nt)) {
+        const dim3 grid2(grid.x, static_cast<unsigned>(nt));
+        const unsigned lds2 = static_cast<unsigned>(16 * 1024 + 4 * 160 * sizeof(float));
+        switch (nt) {
+            case 2: hipLaunchKernelGGL((fl_dx_kernel<2, 1>), grid2, dim3(FL_THREADS), lds2, st, k); break;
+            case 3: hipLaunchKernelGGL((fl_dx_kernel<3, 1>), grid2, dim3(FL_THREADS), lds2, st, k); break;
+            case 4: hipLaunchKernelGGL((fl_dx_kernel<4, 1>), grid2, dim3(FL_THREADS), lds2, st, k); break;
+            default: hipLaunchKernelGGL((fl_dx_kernel<5, 1>), grid2, dim3(FL_THREADS), lds2, st, k); break;
+        }
+        return swr_launch_status();
+    }
 #define FL_GOX(NTV)                                                                                                     \
     do {                                                                                                                \
         if (lds >= 64 * 1024 && !swr_raise_lds(reinterpret_cast<const void*>(fl_dx_kernel<NTV>), 80 * 1024)) return SWR_ERR_LAUNCH; \

@@ -1969,12 +1969,21 @@ static bool tn_wide_ok(const swr_gemm_tn_args& a) {
     const int pt = static_cast<int>(swr_ceil_div(a.K1, 32)), qt = static_cast<int>(swr_ceil_div(a.K2, 32));
     return !use_bf16() && tn_wide_enabled() && tn_wide_shape(pt, qt) && a.K2 <= 8 * TNG_MAX_PIECES && a.M >= 256 * TX_ROWS;
 }
+// rows per batch split below which the wide / transpose-read products are not cut (SWR_TN_MIN_ROWS, a multiple of 32; read per call).
+// 256 rows (8 stages of 32) amortise a split's two bursts -- operands of its first stages in, its partial tile out -- at long batches;
+// at a short batch (the 8 192-row strong-scaling shard) that leaves 32 workgroups on 256 CUs, and the product is all latency: fewer
+// rows per split, more CUs
+static int64_t tn_min_rows() {
+    const char* e = getenv("SWR_TN_MIN_ROWS");
+    const int64_t v = e ? atoll(e) : 0;
+    return (v >= 32 && v % 32 == 0) ? v : 64;
+}
 static void tn_x6_plan(const swr_gemm_tn_args& a, int& n_splits, int64_t& rps) {
     constexpr int blocks_target = 256;   // one per CU
     const int qblk = tn_x6_tail(a) ? a.K2 / TX_QCOLS : static_cast<int>(swr_ceil_div(a.K2, TX_QCOLS));
     const int pblk = static_cast<int>(swr_ceil_div(swr_ceil_div(a.K1, 32), TN_TA_MAX));
     int64_t want = tn_wide_ok(a) ? blocks_target : std::max<int64_t>(1, blocks_target / (qblk * pblk));
-    want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (8 * TX_ROWS)));
+    want = std::min<int64_t>(want, std::max<int64_t>(1, a.M / (tn_wide_ok(a) ? tn_min_rows() : 8 * TX_ROWS)));
     rps = swr_ceil_div(swr_ceil_div(a.M, want), TX_ROWS) * TX_ROWS;
     n_splits = static_cast<int>(swr_ceil_div(a.M, rps));
 }
@@ -2064,7 +2073,7 @@ int tn_x6_gather(const swr_gemm_tn_args& a, const TnGather& g, void* workspace, 
         t.M = a.M; t.K1 = a.K1; t.K2 = a.K2;
         t.ws = g.tr_ws; t.voff = g.tr_voff; t.mask_t = g.tr_mask_t; t.NR = g.tr_nr;
         t.part = kk.part; t.part_cs = kk.part_cs; t.k2p = kk.k2p;
-        t.rows_per_split = std::max<int64_t>(128, (kk.rows_per_split + 31) / 32 * 32);       // (never more splits than planned)
+        t.rows_per_split = std::max<int64_t>(std::min<int64_t>(128, tn_min_rows()), (kk.rows_per_split + 31) / 32 * 32);   // (never more splits than planned)
         {
             static int64_t force = -1;              // SWR_DW_TR_ROWS: rows per split (experiments: fewer, longer splits)
             if (force < 0) { const char* e = getenv("SWR_DW_TR_ROWS"); force = e ? atoll(e) : 0; }

@@ -218,6 +218,132 @@ static __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const
 }
 
 
+// ------------------------------------------------------------------------------- rank sort (short segments, ONE launch)
+// A segment of n <= RANK_SORT_MAX_KEYS keys is sorted by COUNTING: the output position of entry i is the number of entries j with
+// (key_j, j) < (key_i, i) -- n^2 comparisons, embarrassingly parallel, one launch instead of two per 8-bit pass (a 3-pass sort of
+// the 8 192 keys of a strong-scaling shard was 6 launches of ~5 us on the critical path of a single-stream step; the 67 M
+// comparisons spread over the chip take less than two of them).  Stable by construction (ties broken by position), so the
+// permutation -- and everything downstream of it -- is bit-identical to the radix passes'.
+// Workgroup = RANK_EPB consecutive entries i of one segment (their keys are wave-uniform: scalar registers); thread t owns the
+// entries j = t, t + 256, ... of the segment (coalesced loads, all in flight at once) and counts, for each i, how many of them
+// come first: `<=` for rows of j wholly in front of the block, `<` behind it, the exact (key, position) order in the one row
+// that holds the block.  Counters leave through LDS ([thread][i], summed by columns).
+#define RANK_EPB 16
+#define RANK_THREADS 256
+#define RANK_ROWS_MAX 64                       // rows of 256 entries per segment: n <= 16 384
+#define RANK_SORT_MAX_KEYS (RANK_ROWS_MAX * RANK_THREADS)
+#define RANK_SORT_MAX_WORK (3ll << 26)         // sum over segments of n^2 up to which the counting sort is taken (2 x 8 192^2 and a bit)
+
+static inline bool rank_sort_enabled() {          // SWR_RANK_SORT=0: radix passes (read per call: the tests compare both in one process)
+    const char* e = getenv("SWR_RANK_SORT");
+    return !(e && e[0] == '0');
+}
+
+// where the entries come from: straight from the lookup's key matrix [slot][B] -- segment t is the concatenation of the B keys of
+// each of its slots, entry (slot, b) carries the payload slot << 24 | b -- so the launch that used to write the unsorted entries
+// (build_keys_kernel) is not needed; the zero-fill that launch carried rides here
+struct RankSrc {
+    const uint32_t* keys;
+    int64_t B;
+    int16_t slot[MAX_SLOTS];         // slots of segment t, in segment order: slot[first[t]] .. slot[first[t + 1] - 1]
+    int16_t first[MAX_SLOTS + 1];
+    uint4* zero;                     // 16-byte words to clear (the caller's accumulators)
+    int64_t zero16;
+};
+
+template <int ROWS>
+static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const SortMeta sm, const RankSrc src, uint32_t* __restrict__ kout,
+                                                                         uint32_t* __restrict__ vout) {
+    __shared__ uint32_t cnt[RANK_THREADS][RANK_EPB + 1];
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int t = sort_table_of_tile(sm, tile);
+    const int64_t seg = sm.seg_off[t];
+    const int len = static_cast<int>(sm.seg_off[t + 1] - seg);
+    const int i0 = (tile - sm.tile_off[t]) * RANK_EPB;                 // first entry of the block (inside the segment)
+    const int s_first = src.first[t];
+    const bool one_slot = src.first[t + 1] - s_first == 1;             // (wave-uniform) the common case: no division per entry
+    const int B = static_cast<int>(src.B);
+    const uint32_t* __restrict__ k0 = src.keys + static_cast<int64_t>(src.slot[s_first]) * src.B;
+    // entry j of the segment -> (slot, sample); its key
+    auto locate = [&](int j, int& slot, int& b) {
+        if (one_slot) { slot = src.slot[s_first]; b = j; return; }
+        const int k = j / B;
+        slot = src.slot[s_first + k];
+        b = j - k * B;
+    };
+    auto key_at = [&](int j) -> uint32_t {
+        if (one_slot) return k0[j];
+        int slot, b;
+        locate(j, slot, b);
+        return src.keys[static_cast<int64_t>(slot) * src.B + b];
+    };
+    const int row_of_block = i0 / RANK_THREADS;                        // (RANK_EPB divides RANK_THREADS: the block lies in one row)
+    // x = the entry's key as the loop below compares it: every comparison is `x < key_i + 1` with the right-hand sides loop-invariant
+    // scalars.  Rows in front of the block count when key_j <= key_i: x = key_j; the block's row and the rows behind it when
+    // key_j < key_i: x = key_j + 1 (real keys are < 0xFFFFFFFF, the launcher checks: no wrap); padding never counts: x = 0xFFFFFFFF
+    uint32_t x[ROWS];
+    uint32_t kb = 0xFFFFFFFFu;                                         // the thread's key in the block's own row
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int j = r * RANK_THREADS + tid;
+        const uint32_t kj = j < len ? key_at(j) : 0xFFFFFFFFu;
+        if (r == row_of_block) kb = kj;
+        x[r] = (j < len && r >= row_of_block) ? kj + 1u : kj;
+    }
+    uint32_t thr[RANK_EPB];
+#pragma unroll
+    for (int e = 0; e < RANK_EPB; ++e)
+        thr[e] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(key_at(min(i0 + e, len - 1))))) + 1u;
+    uint32_t c[RANK_EPB];
+    // the block's own row: entries with an EQUAL key come first when they stand in front
+    {
+        const int j = row_of_block * RANK_THREADS + tid;
+#pragma unroll
+        for (int e = 0; e < RANK_EPB; ++e) c[e] = (j < len && kb + 1u == thr[e] && j < i0 + e) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+        for (int e = 0; e < RANK_EPB; ++e) c[e] += x[r] < thr[e] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < RANK_EPB; ++e) cnt[tid][e] = c[e];
+    __syncthreads();
+    // column sums: thread (e, part) adds 16 of the 256 partial counts of entry e; then the 16 parts
+    constexpr int PARTS = RANK_THREADS / RANK_EPB;
+    const int e = tid & (RANK_EPB - 1), part = tid / RANK_EPB;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < RANK_THREADS / PARTS; ++q) sum += cnt[part * (RANK_THREADS / PARTS) + q][e];
+    __syncthreads();
+    cnt[part][e] = sum;
+    __syncthreads();
+    if (tid < RANK_EPB && i0 + tid < len) {
+        uint32_t pos = 0;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) pos += cnt[q][tid];
+        int slot, b;
+        locate(i0 + tid, slot, b);
+        kout[seg + pos] = key_at(i0 + tid);
+        vout[seg + pos] = (static_cast<uint32_t>(slot) << 24) | static_cast<uint32_t>(b);
+    }
+    // (behind the sort's own loads: in front of them the fill's stores delayed the first round trip of every workgroup)
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * RANK_THREADS;
+    for (int64_t z = static_cast<int64_t>(tile) * RANK_THREADS + tid; z < src.zero16; z += stride) src.zero[z] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// the counting sort of every segment, one launch: sm.tile == RANK_EPB (sm.tile_off counts blocks); result in buffer 1
+static inline void rank_sort_launch(const SortMeta& sm, const RankSrc& src, int64_t max_keys, uint32_t* const kbuf[2], uint32_t* const vbuf[2],
+                                    hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(sm.n_tiles)), block(RANK_THREADS);
+    const int rows = static_cast<int>((max_keys + RANK_THREADS - 1) / RANK_THREADS);
+    if (rows <= 8) hipLaunchKernelGGL(rank_sort_kernel<8>, grid, block, 0, st, sm, src, kbuf[1], vbuf[1]);
+    else if (rows <= 16) hipLaunchKernelGGL(rank_sort_kernel<16>, grid, block, 0, st, sm, src, kbuf[1], vbuf[1]);
+    else if (rows <= 32) hipLaunchKernelGGL(rank_sort_kernel<32>, grid, block, 0, st, sm, src, kbuf[1], vbuf[1]);
+    else hipLaunchKernelGGL(rank_sort_kernel<RANK_ROWS_MAX>, grid, block, 0, st, sm, src, kbuf[1], vbuf[1]);
+}
+
 // every pass of the sort on `st`: keys / values ping-pong between buffer 0 and 1; the result is in buffer (n_passes & 1)
 static inline void radix_sort_launch(const SortMeta& sm, int n_passes, uint32_t* const kbuf[2], uint32_t* const vbuf[2],
                                      uint32_t* hist, hipStream_t st) {

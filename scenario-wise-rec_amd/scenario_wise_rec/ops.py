@@ -177,6 +177,7 @@ SIDE_STREAM = _SIDE_MODE != "0"
 SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = 2e9, 2e10
 PAD_ROWS = os.environ.get("SWR_PAD_ROWS", "1") != "0"          # 128-byte aligned rows for the tensors of a fused gate-mix level
 FUSE_BN_DX = os.environ.get("SWR_FUSE_BN_DX", "1") != "0"      # BatchNorm backward applied inside the first layer's dX product
+FUSE_BN_DX_SINGLE = os.environ.get("SWR_FUSE_BN_DX_SINGLE", "1") != "0"   # ... also where the step runs on ONE stream (short batches)
 _side = {"streams": {}, "keep": [], "queued": False, "deferred": [], "pending": 0,
          "jobs": [],        # one-shot callables that ride the next forward-time fork (the trainer's zero_grad)
          "wt": {},          # (ptr, N, K) -> {"src": W view, "buf": W^T, "epoch": fork that refreshed it}
@@ -1200,7 +1201,7 @@ class LinearBNAct(Function):
             fuse_dx = (FUSE_BN_DX and ctx.fl_fused and ctx.mix is not None and oh0 is not None and oh0.n_sel > 0
                        and ctx.needs_input_grad[1] and getattr(ctx, "wt_sel", None) is not None and dY.stride(0) % 4 == 0
                        and lib.swr_bn_bwd_dx_supported(Ntot, oh0.n_sel)
-                       and ((SIDE_STREAM and SIDE_DW_MIN_FLOP <= n_dw < SIDE_DW_MAX_FLOP) or _late["on"]))
+                       and ((SIDE_STREAM and SIDE_DW_MIN_FLOP <= n_dw < SIDE_DW_MAX_FLOP) or _late["on"] or FUSE_BN_DX_SINGLE))
             if fuse_dx:
                 bn_dx = (dY, ca, cb, cc)
             else:
@@ -1296,9 +1297,12 @@ class LinearBNAct(Function):
         # measured: forking every small product LOSES 0.02 ms at configs 1, 3 and 4)
         side_dw = direct_w and SIDE_STREAM and SIDE_DW_MIN_FLOP <= 2.0 * M * Ntot * K < SIDE_DW_MAX_FLOP
         late_dw = direct_w and _late["on"] and ctx.needs_input_grad[1] and not side_dw
+        # single-stream step (short batches) with the BatchNorm backward inside the dX product: dX first, the weight gradient --
+        # which recomputes dZ from dY and Z, or reads the dZ that launch wrote -- right behind it on the same stream
+        after_dx = bn_dx is not None and not side_dw and not late_dw
         if late_dw:
             _late["jobs"].append(launch_dw)       # split backward: dX first, this product after the row lists are out
-        elif not side_dw:
+        elif not side_dw and not after_dx:
             launch_dw()
         dx = None
         if oh is not None:
@@ -1354,6 +1358,8 @@ class LinearBNAct(Function):
                     gemm("nn", dZ, W, dx, M, K, Ntot)
                 if dx.shape[1] != K:
                     dx = dx[:, :K]
+        if after_dx:
+            launch_dw()
         if side_dw:
             # forked AFTER the dX product is enqueued: dX is on the critical path and must not share the MFMA pipes
             # with dW; dW then overlaps whatever the main stream does next (the embedding backward, lower layers).

@@ -175,6 +175,59 @@ def test_embedding_backward_flags_out_of_range_gradient():
         H.check_errors()
 
 
+@pytest.mark.parametrize("B,dim,vocabs,limit", [(8192, 16, [4371900, 35], 1 << 20), (8192, 32, [748000, 20000, 300], 1 << 20),
+                                                (5000, 16, [70000, 3], 1 << 30),       # sorted DENSE table (stripes), ragged rows
+                                                (257, 8, [100000], 1024), (16384, 16, [1 << 22], 1 << 20), (31, 64, [5000], 1024),
+                                                (4096, 16, [90000], 1024)])            # (+ the shared slot: a segment of 2 B keys)
+def test_embedding_backward_counting_sort_is_bitwise_the_radix_sort(B, dim, vocabs, limit, monkeypatch):
+    """Short segments (<= 16 384 keys per table: a strong-scaling shard, config 4's per-GPU batch) are sorted by ONE counting
+    launch (csrc/radix_sort.h rank_sort_kernel) instead of two launches per radix pass.  Both sorts are stable, so the row lists,
+    the dense gradients and the order of every sum are the same: bitwise, including the run markers of repeated rows."""
+    from scenario_wise_rec.basic.features import SparseFeature
+    from scenario_wise_rec.basic.layers import EmbeddingLayer
+    rng = np.random.default_rng(B + dim + len(vocabs))
+    feats = [SparseFeature(f"s{i}", v, dim) for i, v in enumerate(vocabs)]
+    feats.append(SparseFeature("shared", vocabs[0], dim, shared_with="s0"))
+    layer = EmbeddingLayer(feats)
+    layer.dense_table_limit_bytes = limit
+    layer.to("cuda")
+    x = {f.name: rng.integers(0, f.vocab_size, size=B) for f in feats}
+    x["s0"][: B // 3] = x["s0"][0]                                                 # a long run of one row
+    x["s0"][B // 3: B // 2] = rng.integers(0, 50, size=B // 2 - B // 3)            # many short runs
+    x["shared"][: B // 4] = x["s0"][0]
+    xd = {k: _dev(v) for k, v in x.items()}
+    g = _dev(rng.standard_normal((B, dim * len(feats))).astype(np.float32) * np.float32(1e-3))
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SWR_RANK_SORT", mode)
+        layer.zero_grad()
+        for p in layer.parameters():
+            p._swr_sparse_grad = None
+        layer(xd, feats, squeeze_dim=True).backward(g)
+        torch.cuda.synchronize()
+        out = []
+        for p in layer.parameters():
+            sg = getattr(p, "_swr_sparse_grad", None)
+            out.append((sg[0].clone(), sg[1].clone()) if sg is not None else (p.grad.clone(),))
+        res.append(out)
+    for a, b in zip(*res):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    # and against fp64 sums (the sort decides nothing about the values)
+    want = np.zeros((vocabs[0], dim), np.float64)
+    gh = g.cpu().numpy().astype(np.float64)
+    np.add.at(want, x["s0"], gh[:, :dim])
+    np.add.at(want, x["shared"], gh[:, len(vocabs) * dim:])
+    first = res[1][0]
+    if len(first) == 2:
+        urow, ugrad = first[0].cpu().numpy(), first[1].cpu().numpy()
+        got = np.zeros_like(want)
+        got[urow[urow >= 0]] = ugrad[urow >= 0]
+    else:
+        got = first[0].cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * np.abs(want).max())
+
+
 def test_embedding_backward_is_deterministic():
     from scenario_wise_rec.basic.features import SparseFeature
     from scenario_wise_rec.basic.layers import EmbeddingLayer
@@ -1411,11 +1464,36 @@ def test_fused_lookup_step_is_bitwise_the_written_layout(family, E, vocabs, n_de
             assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
 
 
+@pytest.mark.parametrize("family,E,vocabs,n_dense,B,limit", [
+    ("MMOE", 16, [1000, 5000, 8, 2, 3, 51, 1472, 16, 35, 4, 119, 455, 6, 3, 200, 300], 4, 8192 + 37, 65536),
+    ("MMOE", 16, [7, 50, 3000, 2], 2, 1000, None),
+    ("SharedBottom", 8, [6040, 3706, 2, 21, 3439, 18], 1, 4096, None),
+    ("SharedBottom", 32, [300, 9, 1000], 3, 65, 20000),
+], ids=["kuairand_like_shard", "smoke_shape", "movielens_e8", "e32_ragged"])
+def test_short_batch_column_split_products_are_bitwise_the_whole_row_ones(family, E, vocabs, n_dense, B, limit, monkeypatch):
+    """Short batches spread the first layer's forward product and its BatchNorm-backward + dX product over the column tiles too
+    (csrc/first_layer.hip, the NA = 1 forms: one 32-column tile per workgroup, grid y = tiles; chosen by batch size, forced here
+    through SWR_FL_SPLIT): every output element is the same chain of products, so the step -- probabilities, loss, every
+    gradient, the row lists -- must not change by a bit."""
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SWR_FL_SPLIT", mode)
+        res.append(_fused_case(family, E, vocabs, n_dense, B, limit, 3))
+    (p0, l0, g0, *_), (p1, l1, g1, *_) = res
+    assert np.array_equal(p0, p1) and l0 == l1
+    assert set(g0) == set(g1)
+    for k in g0:
+        if isinstance(g0[k], tuple):
+            assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]), k
+        else:
+            assert np.array_equal(g0[k], g1[k]), f"{k}: max diff {np.abs(g0[k] - g1[k]).max():.3e}"
+
+
 def test_bn_backward_inside_the_dx_product_is_bitwise_the_two_launches(monkeypatch):
     """swr_bn_bwd_dx (csrc/first_layer.hip): dZ = ca dY + cb (Z - mean) + cc computed in the A fragment of the first layer's dX
     product and written out for the weight gradient, against swr_act_bwd_apply + swr_gemm_nt -- same operations in the same
-    order: every gradient BIT FOR BIT.  (Taken only where the weight-gradient product is forked behind dX: a batch of
-    32 768 at these widths.)"""
+    order: every gradient BIT FOR BIT.  (A batch of 32 768: the weight-gradient product is forked behind dX; on single-stream
+    steps the same launch runs in front of the weight gradient, ops.FUSE_BN_DX_SINGLE.)"""
     from scenario_wise_rec import ops
     vocabs = [1000, 5000, 8, 2, 3, 51, 1472, 16, 35, 4, 119, 455, 6, 3, 200, 300]
     prev = ops.lib.swr_dw_tr_mode(0)          # (the weight gradient in the form whose batch splits are the written-dZ product's)
