@@ -1,5 +1,12 @@
 // Shared helpers for the libswr HIP sources (gfx950 / CDNA4 only).
 #pragma once
+// -DSWR_X3 (variant builds only, tools/build_variant.py): every fp32 product as THREE bf16 products (h h, h m, m h) instead of six --
+// the terms of order 2^-16 (l h, h l, m m) are dropped.  A measurement build: the product library never defines it.
+#ifdef SWR_X3
+#define SWR_X3_ON 1
+#else
+#define SWR_X3_ON 0
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>

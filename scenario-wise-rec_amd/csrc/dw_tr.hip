@@ -320,8 +320,9 @@ __device__ __forceinline__ void dt_wave(const DwTrArgs& a, dt_lds lds, const int
             f32x16 c0 = acc[t0], c1 = acc[t1 < NW ? t1 : t0];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                if (j < n0) c0 = prod(ks, t0, j, c0);
-                if (j < n1) c1 = prod(ks, t1, j, c1);
+                // (SWR_X3 measurement builds skip the small terms: products 0-2 of a real tile, product 0 of a one-hot tile)
+                if (j < n0 && !(SWR_X3_ON && j < (n0 == 6 ? 3 : 1))) c0 = prod(ks, t0, j, c0);
+                if (j < n1 && !(SWR_X3_ON && j < (n1 == 6 ? 3 : 1))) c1 = prod(ks, t1, j, c1);
             }
             acc[t0] = c0;
             if (t1 < NW) acc[t1] = c1;

@@ -422,10 +422,23 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
         if (count_blocks(target) > DIRECT_RESIDENT)
             for (int64_t t2 = target + target / 16; t2 <= target + target / 2; t2 += target / 16)
                 if (count_blocks(t2) <= DIRECT_RESIDENT) { target = t2; break; }
+        // balance: a single-lookup workgroup walks only the samples whose row falls in ITS row range -- chunk / parts of them.  With one
+        // chunk size for all, the one-part workgroups of the small tables (35 .. 200 rows) walk 3 072 samples in six dependent rounds
+        // while a sixth of the 1 472-row table walks 512 in one, and the launch lasts as long as the former.  SWR_DIRECT_E > 0: chunk
+        // = E x parts (expected matches per workgroup = E), within [512, the common chunk]
+        int64_t e_target = 0;
+        { const char* e = getenv("SWR_DIRECT_E"); e_target = e ? atoll(e) : 0; }
         int blocks = 0;
         for (int gi = 0; gi < dm.n_groups; ++gi) {
             DirectGroup& g = dm.grp[gi];
             g.chunk = static_cast<int32_t>(std::min<int64_t>(B, std::max<int64_t>(64, target / g.width)));
+            if (e_target > 0 && g.n_members == 1) {
+                int parts = 0;
+                for (int gj = 0; gj < dm.n_groups; ++gj)
+                    parts += dm.grp[gj].n_members == 1 && dm.mem[dm.grp[gj].member0].slot == dm.mem[g.member0].slot;
+                const int64_t c = std::max<int64_t>(512, e_target * parts);
+                if (c < g.chunk) g.chunk = static_cast<int32_t>(c);
+            }
             g.block0 = blocks;
             blocks += static_cast<int>(swr_ceil_div(B, g.chunk));
         }

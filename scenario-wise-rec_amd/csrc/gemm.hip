@@ -347,9 +347,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (NT > 6 ? 1 : 2)) void gemm_rows_x6_k
                 if (t + 1 < NT) b_read(nxt, gq, t + 1, DB ? HALF : 0);
                 __builtin_amdgcn_sched_barrier(0);      // next tile's LDS reads are issued before this tile's MFMAs
                 f32x16 c_ = acc[t];
-                if (!EX && !BF) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cur[0], c_, 0, 0, 0);     // small terms first
-                if (!BF) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[2], c_, 0, 0, 0);
-                if (!EX && !BF) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[1], c_, 0, 0, 0);
+                if ((!EX && !BF) && !SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cur[0], c_, 0, 0, 0);     // small terms first
+                if ((!BF) && !SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[2], c_, 0, 0, 0);
+                if ((!EX && !BF) && !SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[1], c_, 0, 0, 0);
                 if (!EX && !BF) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cur[0], c_, 0, 0, 0);
                 if (!BF) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[1], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cur[0], c_, 0, 0, 0);
@@ -1033,9 +1033,9 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
                 __builtin_amdgcn_sched_barrier(0);      // the next tile's LDS reads are issued before this tile's MFMAs
                 f32x16 c_ = acc[t];
                 if (!BF) {
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);     // small terms first
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);     // small terms first
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], c_, 0, 0, 0);
                 }
@@ -1053,9 +1053,9 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6_kernel(const TnK kk) {
                     frag(ta, buf, 32 * pt_);
                     f32x16 c_ = acc_tail[t];
                     if (!BF) {
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[2], c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[1], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[2], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[1], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[0], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[1], c_, 0, 0, 0);
                     }
@@ -1325,14 +1325,14 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, c
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 c_ = acc[t];
                 if (!q_exact) {
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
                 } else {
-                    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                    if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
                     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
                 }
@@ -1349,14 +1349,14 @@ __global__ __launch_bounds__(TX_THREADS) void gemm_tn_x6g_kernel(const TnK kk, c
                     frag(ta, buf, 32 * pt_);
                     f32x16 c_ = acc_tail[t];
                     if (!t_exact) {
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[2], c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[1], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[2], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[1], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[0], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[1], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[0], c_, 0, 0, 0);
                     } else {
-                        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
+                        if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[2], tb[0], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[1], tb[0], c_, 0, 0, 0);
                         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[0], tb[0], c_, 0, 0, 0);
                     }
@@ -1518,14 +1518,14 @@ __device__ __forceinline__ void wide_mul(const TnK& kk, const __bf16* Lx, int n_
             bf16x8 (&b)[3] = bq[bcur];
             f32x16 c_ = acc[t];
             if (D.q[W][t] < QE) {
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
+                if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], c_, 0, 0, 0);
+                if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
             } else {
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
+                if (!SWR_X3_ON) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], c_, 0, 0, 0);
                 c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], c_, 0, 0, 0);
             }
