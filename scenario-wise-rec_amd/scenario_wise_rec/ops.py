@@ -884,10 +884,7 @@ class EmbedGather(Function):
                     reduce_part(1)
                     _late["rows_event"].record(torch.cuda.current_stream())
                     _late["rows_recorded"] = True
-                    _fork_side(dev, lambda: reduce_part(2))
-                    if not _side["queued"]:
-                        _side["queued"] = True
-                        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+                    _on_side_stream(dev, lambda: reduce_part(2), (dE, ctx.keys, ws))      # (operands held until the join)
                 else:
                     reduce_part(1)
                     _late["jobs"].append(lambda: reduce_part(2))

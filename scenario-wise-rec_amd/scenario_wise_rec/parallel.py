@@ -30,6 +30,7 @@ from . import ops
 # The captured data-parallel step is ONE hipGraph with the RCCL collectives inside it wherever the process group runs over RCCL
 # (world 1 over RCCL, same box: 0.470 -> 0.428 ms per step at config 2, i.e. 1.27 x -> 1.16 x the single-GPU step); gloo collectives
 # are host-synchronous and cannot be captured: three graphs with eager collectives between them (the multi-process tests on one GPU)
+ONE_STREAM = os.environ.get("SWR_DP_ONE_STREAM", "auto")      # "1" / "0" / auto = with the step (ops.SIDE_STREAM): the exchange on the step's one stream
 ROWS_EVENT = os.environ.get("SWR_DP_ROWS_EVENT", "1") != "0"   # one-graph step: the rows all-gather waits for the row lists alone
 ONE_GRAPH = os.environ.get("SWR_DP_ONE_GRAPH", "auto")      # "auto": one graph over RCCL (nccl backend), three with gloo; "0" / "1" force
 
@@ -415,7 +416,15 @@ class DataParallelStep(object):
             arena, big, sparse = self._sparse()
             xb = self._exchange_buffers(arena["g"], big, sparse)                # established by the warm-up steps
             rows = bool(xb["offs"])
-            if rows:
+            # short batches (the step itself runs on ONE stream, ops.SIDE_MIN_BATCH): the exchange stays on that stream too.  A replayed
+            # multi-stream graph costs the HOST ~8 us per node -- at the 8 192-row strong-scaling shard of config 2 the two-branch
+            # step was issued in 0.23 ms per replay and ran in 0.26: host-bound -- and the branch only hides ~15 us of row exchange
+            single = ONE_STREAM == "1" or (ONE_STREAM == "auto" and not ops.SIDE_STREAM)
+            self._single_stream = single
+            if rows and single:
+                dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group)
+                self._merge_rows(xb, big)
+            elif rows:
                 if rows_ev is not None and ops.rows_event_recorded():
                     side.wait_event(rows_ev)            # the row lists alone: not the weight-gradient branch, not the small tables' sums
                 else:
@@ -426,7 +435,7 @@ class DataParallelStep(object):
             ops.run_late_jobs()
             ops.join_side_streams()
             self._send_dense(xb, arena["g"], pack=True)
-            if rows:
+            if rows and not single:
                 cur.wait_stream(side)
             self._mean_dense(xb, arena["g"])
             opt.step()
