@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 7
+#define SWR_ABI_VERSION 8
 
 typedef enum {
     SWR_OK = 0,
@@ -550,6 +550,12 @@ int swr_tower_head_select_bce_fwd(const float* Z1, int64_t ldz, int G, int H, co
                                   const float* w2, const float* b2, const void* domain, int dom_dtype, const void* y,
                                   int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
                                   uint32_t* ticket, void* stream);
+/* ABI 8: with the optimizer's step bookkeeping as a rider (see swr_select_bce_fwd_adv) */
+int swr_tower_head_select_bce_fwd_adv(const float* Z1, int64_t ldz, int G, int H, const float* scale, const float* shift,
+                                      const float* w2, const float* b2, const void* domain, int dom_dtype, const void* y,
+                                      int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
+                                      uint32_t* ticket, void* adv_hyper, float* adv_hist, int64_t adv_hist_cap,
+                                      void* stream);
 int swr_tower_supported(int K, int H);
 int swr_tower_fwd_linear(const swr_tower_args* args_host, void* stream);
 int swr_tower_fwd_head(const swr_tower_args* args_host, void* stream);
@@ -592,6 +598,17 @@ int swr_select_bce_fwd(const float* V, int64_t ldv, int D, const void* domain, i
                        void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream);
 int swr_select_bce_bwd(const float* p, const void* y, int y_dtype, int D, const void* domain,
                        int dom_dtype, int64_t M, const float* dloss, float* dV, int64_t lddv, void* stream);
+/* ABI 8: the same launch carrying the optimizer's step bookkeeping as a RIDER (optim.Adam's `state["step"] += 1` and the bias
+ * corrections of the step, ctr_trainer.py:73 through torch/optim/adam.py): when `adv_hyper` (a swr_adam_hyper*, declared further
+ * down) is not NULL the one thread that finishes
+ * the launch also does what swr_adam_advance(adv_hyper, adv_hist, adv_hist_cap) does -- the loss kernel reads none of those fields,
+ * every reader of them (the lookup's lazy-row catch-up before, the optimizer's kernels after) sits behind a kernel boundary --
+ * and the 1-thread swr_adam_advance launch (~5 us of a launch-bound short-batch step) is not needed.  All three NULL / 0: exactly
+ * swr_select_bce_fwd. */
+int swr_select_bce_fwd_adv(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype,
+                           const void* y, int y_dtype, int64_t M, float* p, float* loss,
+                           void* workspace, size_t workspace_bytes, uint32_t* ticket,
+                           void* adv_hyper, float* adv_hist, int64_t adv_hist_cap, void* stream);
 
 /* -------------------------------------------------------- elementwise -----
  * small helpers of STAR / PPNet / HAMUR middles */

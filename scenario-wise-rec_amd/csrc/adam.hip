@@ -2,28 +2,13 @@
 // (trainers/ctr_trainer.py:50-52,73) as HBM-streaming kernels: 4 reads + 3 writes of 4 bytes per
 // parameter.  Step count / bias corrections live in device memory so a captured hipGraph replays.
 #include "common.h"
+#include "adam_advance.h"
 
 #define AD_THREADS 256
 
 __global__ void adam_advance_kernel(swr_adam_hyper* h, float* hist, int64_t cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    h->step += 1;
-    const double t = static_cast<double>(h->step);
-    const double bc1 = 1.0 - pow(h->beta1, t), bc2 = 1.0 - pow(h->beta2, t);
-    h->step_size = static_cast<float>(h->lr / bc1);
-    h->inv_bc2_sqrt = static_cast<float>(1.0 / sqrt(bc2));
-    h->one_minus_b1 = static_cast<float>(1.0 - h->beta1);
-    h->b2 = static_cast<float>(h->beta2);
-    h->one_minus_b2 = static_cast<float>(1.0 - h->beta2);
-    h->eps_f = static_cast<float>(h->eps);
-    h->wd_f = static_cast<float>(h->weight_decay);
-    if (hist) {                              // per-step scalars, replayed later by the lazy row catch-up: a RING of
-        const uint32_t mask = static_cast<uint32_t>(cap - 1);      // `cap` (a power of two) steps -- the host flushes
-        h->hist_mask = mask;                                        // every lazily updated table before a row can lag that far
-        const int64_t slot = h->step & static_cast<int64_t>(mask);
-        hist[2 * slot] = h->step_size;
-        hist[2 * slot + 1] = h->inv_bc2_sqrt;
-    }
+    swr_adam_advance_body(h, hist, cap);
 }
 
 extern "C" int swr_adam_advance(swr_adam_hyper* hyper, float* hist, int64_t hist_cap, void* stream) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "adam_advance.h"
 
 #define EW_THREADS 256
 
@@ -458,8 +459,11 @@ extern "C" int swr_bce_bwd(const float* p, const void* y, int y_dtype, int64_t M
 
 // per-workgroup loss partial + the final fixed-order fp64 sum by whichever workgroup draws the last ticket (no spinning: a
 // workgroup either is last or leaves); the ticket word is zero on entry and zero again on exit
+// `adv` (nullable): the optimizer's step bookkeeping rides here -- run by the one thread that finishes the launch (swr.h
+// "swr_select_bce_fwd_adv")
+struct BceAdv { swr_adam_hyper* hyper; float* hist; int64_t cap; };
 __device__ __forceinline__ void bce_finish(float acc, float* sm, double* smd, bool* is_last, float* part, int n_part,
-                                           uint32_t* ticket, float* __restrict__ loss, int64_t M) {
+                                           uint32_t* ticket, float* __restrict__ loss, int64_t M, const BceAdv adv = BceAdv{nullptr, nullptr, 0}) {
     const float tot = block_sum(acc, sm);
     if (threadIdx.x == 0) {
         part[blockIdx.x] = tot;
@@ -476,6 +480,7 @@ __device__ __forceinline__ void bce_finish(float acc, float* sm, double* smd, bo
     if (threadIdx.x == 0) {
         *loss = static_cast<float>(total / static_cast<double>(M));
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (adv.hyper) swr_adam_advance_body(adv.hyper, adv.hist, adv.cap);
     }
 }
 
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(EW_THREADS) void select_bce_fwd_kernel(const float*
                                                                     const void* __restrict__ domain, int dom_dtype,
                                                                     const void* __restrict__ y, int y_dtype, int64_t M,
                                                                     float* __restrict__ p_out, float* part, int n_part,
-                                                                    uint32_t* ticket, float* __restrict__ loss) {
+                                                                    uint32_t* ticket, float* __restrict__ loss, const BceAdv adv) {
     __shared__ float sm[EW_THREADS / 64];
     __shared__ double smd[EW_THREADS / 64];
     __shared__ bool is_last;
@@ -506,19 +511,31 @@ __global__ __launch_bounds__(EW_THREADS) void select_bce_fwd_kernel(const float*
             acc -= yi * lp + (1.f - yi) * l1;
         }
     }
-    bce_finish(acc, sm, smd, &is_last, part, n_part, ticket, loss, M);
+    bce_finish(acc, sm, smd, &is_last, part, n_part, ticket, loss, M, adv);
 }
 
+extern "C" int swr_select_bce_fwd_adv(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype, const void* y,
+                                      int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
+                                      uint32_t* ticket, void* adv_hyper, float* adv_hist, int64_t adv_hist_cap, void* stream);
 extern "C" int swr_select_bce_fwd(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype, const void* y,
                                   int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
                                   uint32_t* ticket, void* stream) {
+    return swr_select_bce_fwd_adv(V, ldv, D, domain, dom_dtype, y, y_dtype, M, p, loss, workspace, workspace_bytes, ticket, nullptr,
+                                  nullptr, 0, stream);
+}
+extern "C" int swr_select_bce_fwd_adv(const float* V, int64_t ldv, int D, const void* domain, int dom_dtype, const void* y,
+                                      int y_dtype, int64_t M, float* p, float* loss, void* workspace, size_t workspace_bytes,
+                                      uint32_t* ticket, void* adv_hyper, float* adv_hist, int64_t adv_hist_cap, void* stream) {
     SWR_REQUIRE(V && domain && y && p && loss && workspace && ticket && D > 0 && M > 0 && ldv >= D, SWR_ERR_ARG);
+    SWR_REQUIRE(!adv_hyper || !adv_hist || (adv_hist_cap > 1 && adv_hist_cap <= (1ll << 31) && (adv_hist_cap & (adv_hist_cap - 1)) == 0),
+                SWR_ERR_ARG);
+    const BceAdv adv = {static_cast<swr_adam_hyper*>(adv_hyper), adv_hyper ? adv_hist : nullptr, adv_hist_cap};
     SWR_REQUIRE(swr_is_index_dtype(dom_dtype), SWR_ERR_DTYPE);
     SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
     SWR_REQUIRE(workspace_bytes >= swr_bce_workspace_bytes(M), SWR_ERR_WORKSPACE);
     const int nb = static_cast<int>(swr_ceil_div(M, BCE_PER_BLOCK));
     hipLaunchKernelGGL(select_bce_fwd_kernel, dim3(nb), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), V, ldv, D, domain,
-                       dom_dtype, y, y_dtype, M, p, static_cast<float*>(workspace), nb, ticket, loss);
+                       dom_dtype, y, y_dtype, M, p, static_cast<float*>(workspace), nb, ticket, loss, adv);
     return swr_launch_status();
 }
 
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(EW_THREADS) void tower_head_select_bce_kernel(
     const float* __restrict__ Z1, int64_t ldz, int G, int Hd, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ w2, const float* __restrict__ b2, const void* __restrict__ domain, int dom_dtype,
     const void* __restrict__ y, int y_dtype, int64_t M, float* __restrict__ p_out, float* part, int n_part, uint32_t* ticket,
-    float* __restrict__ loss) {
+    float* __restrict__ loss, const BceAdv adv) {
     __shared__ float sm[EW_THREADS / 64];
     __shared__ double smd[EW_THREADS / 64];
     __shared__ bool is_last;
@@ -562,14 +579,30 @@ __global__ __launch_bounds__(EW_THREADS) void tower_head_select_bce_kernel(
             acc -= yi * lp + (1.f - yi) * l1;
         }
     }
-    bce_finish(acc, sm, smd, &is_last, part, n_part, ticket, loss, M);
+    bce_finish(acc, sm, smd, &is_last, part, n_part, ticket, loss, M, adv);
 }
 
+extern "C" int swr_tower_head_select_bce_fwd_adv(const float* Z1, int64_t ldz, int G, int H, const float* scale,
+                                                 const float* shift, const float* w2, const float* b2, const void* domain,
+                                                 int dom_dtype, const void* y, int y_dtype, int64_t M, float* p, float* loss,
+                                                 void* workspace, size_t workspace_bytes, uint32_t* ticket, void* adv_hyper,
+                                                 float* adv_hist, int64_t adv_hist_cap, void* stream);
 extern "C" int swr_tower_head_select_bce_fwd(const float* Z1, int64_t ldz, int G, int H, const float* scale,
                                              const float* shift, const float* w2, const float* b2, const void* domain,
                                              int dom_dtype, const void* y, int y_dtype, int64_t M, float* p, float* loss,
                                              void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream) {
+    return swr_tower_head_select_bce_fwd_adv(Z1, ldz, G, H, scale, shift, w2, b2, domain, dom_dtype, y, y_dtype, M, p, loss, workspace,
+                                             workspace_bytes, ticket, nullptr, nullptr, 0, stream);
+}
+extern "C" int swr_tower_head_select_bce_fwd_adv(const float* Z1, int64_t ldz, int G, int H, const float* scale,
+                                                 const float* shift, const float* w2, const float* b2, const void* domain,
+                                                 int dom_dtype, const void* y, int y_dtype, int64_t M, float* p, float* loss,
+                                                 void* workspace, size_t workspace_bytes, uint32_t* ticket, void* adv_hyper,
+                                                 float* adv_hist, int64_t adv_hist_cap, void* stream) {
     SWR_REQUIRE(Z1 && scale && shift && w2 && domain && y && p && loss && workspace && ticket && G > 0 && M > 0, SWR_ERR_ARG);
+    SWR_REQUIRE(!adv_hyper || !adv_hist || (adv_hist_cap > 1 && adv_hist_cap <= (1ll << 31) && (adv_hist_cap & (adv_hist_cap - 1)) == 0),
+                SWR_ERR_ARG);
+    const BceAdv adv = {static_cast<swr_adam_hyper*>(adv_hyper), adv_hyper ? adv_hist : nullptr, adv_hist_cap};
     SWR_REQUIRE(H > 0 && H % 4 == 0 && ldz >= static_cast<int64_t>(G) * H && ldz % 4 == 0 && swr_aligned16(Z1), SWR_ERR_ALIGN);
     SWR_REQUIRE(swr_is_index_dtype(dom_dtype), SWR_ERR_DTYPE);
     SWR_REQUIRE(swr_is_value_dtype(y_dtype), SWR_ERR_DTYPE);
@@ -577,7 +610,7 @@ extern "C" int swr_tower_head_select_bce_fwd(const float* Z1, int64_t ldz, int G
     const int nb = static_cast<int>(swr_ceil_div(M, BCE_PER_BLOCK));
     hipLaunchKernelGGL(tower_head_select_bce_kernel, dim3(nb), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), Z1, ldz, G,
                        H, scale, shift, w2, b2, domain, dom_dtype, y, y_dtype, M, p, static_cast<float*>(workspace), nb, ticket,
-                       loss);
+                       loss, adv);
     return swr_launch_status();
 }
 

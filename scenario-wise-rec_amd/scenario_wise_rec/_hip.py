@@ -29,7 +29,7 @@ def _load():
 
 # the ABI number of include/swr.h these bindings were written against (SWR_ABI_VERSION): argument lists changed between
 # numbers, so a stale or variant libswr.so with another number would take shifted arguments -- refuse it
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 lib = _load()
 lib.swr_abi_version.restype = C.c_int
@@ -258,8 +258,10 @@ _SIGS = {
     "swr_bce_fwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _Z, _P]),
     "swr_bce_bwd": (C.c_int, [_P, _P, _I, _L, _P, _P, _P]),
     "swr_select_bce_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
+    "swr_select_bce_fwd_adv": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P, _P, _L, _P]),
     "swr_select_bce_bwd": (C.c_int, [_P, _P, _I, _I, _P, _I, _L, _P, _P, _L, _P]),
     "swr_tower_head_select_bce_fwd": (C.c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P]),
+    "swr_tower_head_select_bce_fwd_adv": (C.c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _L, _P, _P, _P, _Z, _P, _P, _P, _L, _P]),
     "swr_bnmix_supported": (C.c_int, [_I, _I, _I]),
     "swr_bnmix_tile_rows": (C.c_int, []),
     "swr_bnmix_fwd": (C.c_int, [_P, _P]),

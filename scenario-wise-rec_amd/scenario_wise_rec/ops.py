@@ -232,6 +232,43 @@ def _skew(point):
         H.check(lib.swr_spin_us(us, H.stream()), "swr_spin_us")
 
 
+# ---- the optimizer's step bookkeeping as a rider of the fused loss launch (swr.h swr_select_bce_fwd_adv): the trainer offers a
+# callable that returns (hyper, hist, hist_cap) -- and books the step on the host -- when the advance may ride, or None; the
+# fused select + BCE launch of the step takes it; `flush_loss_rider()` (after the forward pass) runs it as the ordinary side job
+# when no such launch came by.  SWR_LOSS_RIDER=0: never ride.
+LOSS_RIDER = os.environ.get("SWR_LOSS_RIDER", "1") != "0"
+_rider = {"offer": None, "fallback": None}
+
+
+def offer_loss_rider(offer, fallback):
+    """Single-stream steps (short batches) only: there the 1-thread launch sits on the critical path (-1.5 us per step at the
+    8 192-row shard of config 2 and at config 1); a step with side branches runs it on the forward-time fork, off the critical
+    path, where riding the loss launch instead was measured 1-3 us SLOWER (config 2 at batch 65 536)."""
+    if LOSS_RIDER and not SIDE_STREAM:
+        _rider["offer"], _rider["fallback"] = offer, fallback
+    else:
+        _rider["offer"] = _rider["fallback"] = None
+        add_side_job(fallback, backward_needs=False)
+
+
+def take_loss_rider():
+    """-> (hyper, hist, cap) tensors / int for the launch's rider arguments, or (None, None, 0)."""
+    offer, _rider["offer"] = _rider["offer"], None
+    if offer is None:
+        return None, None, 0
+    got = offer()
+    if got is None:
+        return None, None, 0          # (the fallback stays: flush_loss_rider runs it)
+    _rider["fallback"] = None
+    return got
+
+
+def flush_loss_rider():
+    fb, _rider["fallback"], _rider["offer"] = _rider["fallback"], None, None
+    if fb is not None:
+        fb()
+
+
 def add_side_job(fn, backward_needs=True):
     """Run `fn()` on the side stream inside the next forward-time fork (EmbedGather.forward); `run_side_jobs()` runs
     whatever is still pending on the current stream.  `backward_needs=False`: nothing in the backward pass reads what the
@@ -504,6 +541,7 @@ def abort_step():
     _side["keep"].clear()
     _dw["pending"] = 0
     _dw["riders"] = []
+    _rider["offer"] = _rider["fallback"] = None
 
 
 def _split_like(flat, tensors):
@@ -1601,10 +1639,12 @@ class TowerHeadSelectBCE(Function):
         nbytes = lib.swr_bce_workspace_bytes(M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         Z1, scale, shift, w2 = saved[2], saved[5], saved[6], saved[8]
-        H.check(lib.swr_tower_head_select_bce_fwd(H.ptr(Z1), G * Hd, G, Hd, H.ptr(scale), H.ptr(shift), H.ptr(w2), H.ptr(b2),
-                                                  H.ptr(domain), H.dtype_code(domain), H.ptr(y), H.dtype_code(y), M, H.ptr(p),
-                                                  H.ptr(loss), H.ptr(ws), nbytes, H.ptr(H.ticket(dev)), H.stream()),
-                "swr_tower_head_select_bce_fwd")
+        adv_hyper, adv_hist, adv_cap = take_loss_rider()      # the optimizer's step bookkeeping, if it asked for a ride
+        H.check(lib.swr_tower_head_select_bce_fwd_adv(H.ptr(Z1), G * Hd, G, Hd, H.ptr(scale), H.ptr(shift), H.ptr(w2), H.ptr(b2),
+                                                      H.ptr(domain), H.dtype_code(domain), H.ptr(y), H.dtype_code(y), M, H.ptr(p),
+                                                      H.ptr(loss), H.ptr(ws), nbytes, H.ptr(H.ticket(dev)), H.ptr(adv_hyper),
+                                                      H.ptr(adv_hist), adv_cap, H.stream()),
+                "swr_tower_head_select_bce_fwd_adv")
         ctx.cfg, ctx.dims, ctx.params = cfg, dims, params
         ctx.save_for_backward(*saved, p, domain, y)
         ctx.set_materialize_grads(False)
@@ -2024,9 +2064,11 @@ class SelectBCE(Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         nbytes = lib.swr_bce_workspace_bytes(M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        H.check(lib.swr_select_bce_fwd(H.ptr(V), V.stride(0) if M > 1 else D, D, H.ptr(domain), H.dtype_code(domain),
-                                       H.ptr(y), H.dtype_code(y), M, H.ptr(p), H.ptr(loss), H.ptr(ws), nbytes,
-                                       H.ptr(H.ticket(dev)), H.stream()), "swr_select_bce_fwd")
+        adv_hyper, adv_hist, adv_cap = take_loss_rider()
+        H.check(lib.swr_select_bce_fwd_adv(H.ptr(V), V.stride(0) if M > 1 else D, D, H.ptr(domain), H.dtype_code(domain),
+                                           H.ptr(y), H.dtype_code(y), M, H.ptr(p), H.ptr(loss), H.ptr(ws), nbytes,
+                                           H.ptr(H.ticket(dev)), H.ptr(adv_hyper), H.ptr(adv_hist), adv_cap, H.stream()),
+                "swr_select_bce_fwd_adv")
         ctx.save_for_backward(p, domain, y)
         ctx.D = D
         ctx.set_materialize_grads(False)

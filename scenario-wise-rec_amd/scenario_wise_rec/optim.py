@@ -178,6 +178,24 @@ class FusedAdam(torch.optim.Optimizer):
         _EARLY_ADVANCED.add(hyper.data_ptr())
 
     @torch.no_grad()
+    def advance_rider(self):
+        """`advance_early` without its launch: the same bookkeeping on the host, and the device arguments for the launch that will
+        carry the advance as a rider (the step's fused loss launch, ops.take_loss_rider) -- or None where advance_early would
+        not advance either."""
+        if len(self.param_groups) != 1 or 0 not in self._hyper or getattr(self, "_advanced", False):
+            return None
+        ent = self._hyper[0]
+        if self.lazy_rows and self._since_flush + 3 >= self.hist_cap:
+            return None
+        hyper = self._hyper_dev(0, self.param_groups[0], ent[0].device)
+        hist = ent[2]
+        ent[3] += 1
+        self._since_flush += 1
+        self._advanced = True
+        _EARLY_ADVANCED.add(hyper.data_ptr())
+        return hyper, hist, (self.hist_cap if hist is not None else 0)
+
+    @torch.no_grad()
     def materialize(self):
         """Bring every lazily updated table fully up to date (exact); cheap no-op when nothing is pending."""
         for st in self._big.values():

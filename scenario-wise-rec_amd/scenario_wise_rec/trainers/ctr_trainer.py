@@ -130,6 +130,7 @@ class CTRTrainer(object):
         else:
             y_pred = self.model(x_dict)
             loss = self.criterion(y_pred, y)
+        ops.flush_loss_rider()       # the optimizer's step bookkeeping, unless the fused loss launch carried it
         ops.run_side_jobs()          # zero_grad, unless the fork already ran it
         ops._stamp("m_fwd_end")
         ops.join_side_extras()       # zero_grad / W^T copies forked during the forward pass: needed from the first backward
@@ -149,8 +150,12 @@ class CTRTrainer(object):
         return self._local_step(x_dict, y)
 
     def _local_step(self, x_dict, y):
-        if hasattr(self.optimizer, "advance_early"):
-            ops.add_side_job(self.optimizer.advance_early, backward_needs=False)      # the step-counter launch leaves the critical path too
+        if hasattr(self.optimizer, "advance_rider"):
+            # the step-counter launch leaves the step: it rides the fused select + BCE launch (or, where the model has none,
+            # runs as a side job after the forward pass)
+            ops.offer_loss_rider(self.optimizer.advance_rider, self.optimizer.advance_early)
+        elif hasattr(self.optimizer, "advance_early"):
+            ops.add_side_job(self.optimizer.advance_early, backward_needs=False)
         loss = self.forward_backward(x_dict, y)
         self.optimizer.step()
         ops._stamp("m_end")

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_status_strings():
     from scenario_wise_rec import _hip as H
-    assert H.lib.swr_abi_version() == H.ABI_VERSION == 7
+    assert H.lib.swr_abi_version() == H.ABI_VERSION == 8
     assert H.lib.swr_status_str(0) == b"ok"
     assert b"workspace" in H.lib.swr_status_str(-6)
     assert H.lib.swr_device_available() in (0, 1)

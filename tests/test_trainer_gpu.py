@@ -257,3 +257,45 @@ def test_optimizer_cleared_gradients_replace_the_zero_grad_fill(name, limit, mon
         res[clear] = _state(model)
     for k, v in res[False].items():
         assert np.array_equal(v, res[True][k]), k
+
+
+@pytest.mark.parametrize("name,limit", [("mmoe", None), ("mmoe", 2048), ("star", 2048), ("epnet", None), ("hamur_small", None)])
+def test_step_bookkeeping_rides_the_loss_launch_without_changing_a_bit(name, limit, monkeypatch):
+    """The optimizer's step counter / bias corrections advance as a RIDER of the fused select + BCE launch (swr.h
+    swr_select_bce_fwd_adv, ops.offer_loss_rider) instead of a 1-thread launch of their own: the same steps with the rider off
+    (SWR_LOSS_RIDER=0: ops.LOSS_RIDER) give the same bits -- state, lazily updated rows, loss sequence -- and where a rider is
+    possible (a model whose forward ends in the fused select + BCE; from the second step on) no swr_adam_advance launch is left."""
+    from scenario_wise_rec import _hip as H
+    from scenario_wise_rec import ops
+    from scenario_wise_rec.trainers import CTRTrainer
+    _limit(monkeypatch, limit)
+    c = Case(name)
+    res, launches = [], []
+    real = ops.lib.swr_adam_advance
+    monkeypatch.setattr(ops, "SIDE_STREAM", False)        # the rider is for single-stream steps (short batches)
+    monkeypatch.setattr(ops, "_SIDE_MODE", "0")
+    for rider in (False, True):
+        monkeypatch.setattr(ops, "LOSS_RIDER", rider)
+        count = []
+        import scenario_wise_rec.optim as optim
+        monkeypatch.setattr(optim.lib, "swr_adam_advance", lambda *a, _c=count: (_c.append(1), real(*a))[1])
+        model = build_product_model(c)
+        tr = CTRTrainer(model, "rider", optimizer_params={"lr": LR, "weight_decay": WD}, device="cuda")
+        tr.use_graph = False
+        model.train()
+        losses = []
+        for s in (0, 1, 2, 0, 1):
+            x, y = c.batch(s)
+            losses.append(float(tr.train_step(to_device(x), torch.from_numpy(y).cuda()).detach()))
+        torch.cuda.synchronize()
+        H.check_errors()
+        if hasattr(model, "materialize"):
+            model.materialize()
+        res.append((_state(model), losses, int(tr.optimizer._hyper[0][3])))
+        launches.append(len(count))
+    (s0, l0, n0), (s1, l1, n1) = res
+    assert l0 == l1 and n0 == n1
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
+    if name in ("mmoe", "hamur_small"):      # (EPNet has no domain select, STAR adds its auxiliary logit inside it: plain BCE there,
+        assert launches[1] <= 1 < launches[0], launches      # the advance stays a launch.)  Step 1 creates the device scalars; steps 2..5 ride
