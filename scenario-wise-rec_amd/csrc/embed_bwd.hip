@@ -1295,6 +1295,10 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
                 if (slots[m.sorted_slot[q]].table_id == t) src.slot[ns++] = m.sorted_slot[q];
         }
         for (int t = m.n_tables; t <= MAX_SLOTS; ++t) src.first[t] = static_cast<int16_t>(ns);
+        for (int t = 0; t < m.n_tables; ++t) {
+            src.n_of[t] = static_cast<int16_t>(src.first[t + 1] - src.first[t]);
+            src.slot0[t] = src.n_of[t] > 0 ? src.slot[src.first[t]] : 0;
+        }
         src.zero = reinterpret_cast<uint4*>(acc_hi);
         src.zero16 = zero_in_keys ? static_cast<int64_t>(zero_bytes / 16) : 0;
         rank_sort_launch(p.sm, src, p.max_keys, kbuf, vbuf, st);

@@ -247,6 +247,8 @@ struct RankSrc {
     int64_t B;
     int16_t slot[MAX_SLOTS];         // slots of segment t, in segment order: slot[first[t]] .. slot[first[t + 1] - 1]
     int16_t first[MAX_SLOTS + 1];
+    int16_t slot0[MAX_SLOTS];        // = slot[first[t]] and first[t + 1] - first[t]: what a one-slot segment (the common case) needs,
+    int16_t n_of[MAX_SLOTS];         //   one load level away from t (through `first` the key loads sat behind two dependent loads)
     uint4* zero;                     // 16-byte words to clear (the caller's accumulators)
     int64_t zero16;
 };
@@ -262,12 +264,13 @@ static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const So
     const int len = static_cast<int>(sm.seg_off[t + 1] - seg);
     const int i0 = (tile - sm.tile_off[t]) * RANK_EPB;                 // first entry of the block (inside the segment)
     const int s_first = src.first[t];
-    const bool one_slot = src.first[t + 1] - s_first == 1;             // (wave-uniform) the common case: no division per entry
+    const int slot_first = src.slot0[t];
+    const bool one_slot = src.n_of[t] == 1;                            // (wave-uniform) the common case: no division per entry
     const int B = static_cast<int>(src.B);
-    const uint32_t* __restrict__ k0 = src.keys + static_cast<int64_t>(src.slot[s_first]) * src.B;
+    const uint32_t* __restrict__ k0 = src.keys + static_cast<int64_t>(slot_first) * src.B;
     // entry j of the segment -> (slot, sample); its key
     auto locate = [&](int j, int& slot, int& b) {
-        if (one_slot) { slot = src.slot[s_first]; b = j; return; }
+        if (one_slot) { slot = slot_first; b = j; return; }
         const int k = j / B;
         slot = src.slot[s_first + k];
         b = j - k * B;
