@@ -994,6 +994,8 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
     __shared__ long long w_head[2][NW];             // sorted position where the open head / tail run starts
     __shared__ uint32_t w_key[2][NW];
     __shared__ int w_info[NW];                      // bit 0 head open, bit 1 tail open, bit 2 through; table << 8
+    __shared__ int s_col[MAX_SLOTS];                // m.slot_col: indexed per lane below -- from the kernel arguments that is a
+    if (threadIdx.x < MAX_SLOTS) s_col[threadIdx.x] = m.slot_col[threadIdx.x];   // memory load between the payload and its gradient row
     const int w = threadIdx.x / LPE, e0 = threadIdx.x % LPE;
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * NW + w;
     const bool valid = gid < n_chunks;
@@ -1027,12 +1029,24 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
     // independent and in flight together; only then does the run logic walk them (no per-entry load chain)
     constexpr int BATCH = 8;
     const int cnt = static_cast<int>(i1 - i0);
+    // the chunk's neighbours and its first batch of entries in ONE round of independent loads (they used to be three dependent
+    // round trips -- neighbours, first key, batch -- in front of the gradient rows: at short batches the launch is nothing but that chain)
     uint32_t prev_key = 0u, next_key = 0u;
+    uint32_t ks0[BATCH], vs0[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) { ks0[j] = 0u; vs0[j] = 0u; }
     if (valid) {
         prev_key = (i0 > seg0) ? ck[i0 - 1] : 0u;
         next_key = (i1 < seg1) ? ck[i1] : 0u;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int64_t i = i0 + min(j, cnt - 1);
+            ks0[j] = ck[i];
+            vs0[j] = val[i];
+        }
     }
     uint32_t bad = 0u;
+    __syncthreads();                                        // (s_col)
     for (int c0 = 0; c0 < m.dim_max; c0 += LPE) {          // same trip count for every walker (barriers inside)
         const int e = c0 + e0;
         int info = 0;
@@ -1040,24 +1054,29 @@ __global__ __launch_bounds__(RB_THREADS) void reduce_kernel(const BwdMeta m, int
         int64_t head_h = 0, head_t = 0;
         uint32_t key_h = 0u, key_t = 0u;
         if (valid) {
-            uint32_t cur = ck[i0];
+            uint32_t cur = ks0[0];
             int64_t head = i0;
             bool in_first = !((i0 == seg0) || (prev_key != cur));   // the first run continues the previous chunk's
             long long s_hi = 0, s_lo = 0;
             for (int j0 = 0; j0 < cnt; j0 += BATCH) {
                 uint32_t ks[BATCH], vs[BATCH];
                 float x[BATCH];
+                if (j0 == 0) {
 #pragma unroll
-                for (int j = 0; j < BATCH; ++j) {
-                    const int64_t i = i0 + min(j0 + j, cnt - 1);
-                    ks[j] = ck[i];
-                    vs[j] = val[i];
+                    for (int j = 0; j < BATCH; ++j) { ks[j] = ks0[j]; vs[j] = vs0[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < BATCH; ++j) {
+                        const int64_t i = i0 + min(j0 + j, cnt - 1);
+                        ks[j] = ck[i];
+                        vs[j] = val[i];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < BATCH; ++j) {
                     const int slot = static_cast<int>(vs[j] >> 24);
                     const int64_t b = vs[j] & 0xFFFFFFu;
-                    x[j] = e < t.dim ? dE[b * ld + m.slot_col[slot] + e] : 0.f;
+                    x[j] = e < t.dim ? dE[b * ld + s_col[slot] + e] : 0.f;
                 }
                 long long fh[BATCH], fl[BATCH];
                 to_fixed_n<BATCH>(x, fh, fl, bad);
