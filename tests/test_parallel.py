@@ -144,13 +144,16 @@ def test_two_rank_captured_step_matches_eager(limit, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("one_stream", ["0", "1"], ids=["branch", "one_stream"])
 @pytest.mark.parametrize("limit", [None, 2048], ids=["dense", "rows"])
-def test_one_graph_step_over_rccl_matches_eager(limit):
-    """Over RCCL the captured data-parallel step is ONE hipGraph with both collectives inside it (parallel._capture_one; the
-    rows all-gather on a parallel branch).  World size 1 over the nccl backend -- what a one-GPU box can run of the real
-    transport: two eager warm-up steps + capture + one replay land bitwise where three eager steps land."""
+def test_one_graph_step_over_rccl_matches_eager(limit, one_stream):
+    """Over RCCL the captured data-parallel step is ONE hipGraph with both collectives inside it (parallel._capture_one): the
+    rows all-gather on a parallel branch (long batches) or on the step's one stream (short batches: SWR_DP_ONE_STREAM, a
+    multi-stream graph is host-bound there).  World size 1 over the nccl backend -- what a one-GPU box can run of the real
+    transport: two eager warm-up steps + capture + one replay land bitwise where three eager steps land.  SWR_DP_ONE_GRAPH=1
+    FORCES the one-graph capture: a capture that fails raises (it used to fall back to three graphs and pass)."""
     extra = () if limit is None else (str(limit),)
-    env = {"DP_WORKER_BACKEND": "nccl", "SWR_DP_ONE_GRAPH": "1"}
+    env = {"DP_WORKER_BACKEND": "nccl", "SWR_DP_ONE_GRAPH": "1", "SWR_DP_ONE_STREAM": one_stream}
     a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 1, extra=extra, env_extra=env), "state1.npz"))
     b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 1, extra=extra, env_extra=dict(env, DP_EAGER_REFERENCE="1")), "state1.npz"))
     for k in a.files:

@@ -10,7 +10,7 @@ for c in ${CONFIGS:-1 3 4 5 6}; do
   python tools/pmc_to_json.py $(find $O/pmc_cfg${c}_f -name "*.db" | head -1) $(find $O/pmc_cfg${c}_w -name "*.db" | head -1) $O/pmc_hbm_cfg$c.json > /dev/null
   cp $O/pmc_hbm_cfg$c.json profiles/pmc_hbm_cfg$c.json
   rm -rf $O/pmc_cfg${c}_f $O/pmc_cfg${c}_w
-  timeout 600 python bench.py --config $c --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${T}_bench_cfg$c.json
+  timeout 900 python bench.py --config $c --steps 50 --warmup 10 2>/dev/null | grep '^{' > $O/${T}_bench_cfg$c.json
   rm -rf $O/prof_cfg$c
   timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $O/prof_cfg$c -- python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof_cfg$c.log 2>&1
   python tools/rocpd_step.py $(find $O/prof_cfg$c -name "*.db" | head -1) 5 > $O/${T}_cfg${c}_per_step.txt
