@@ -289,7 +289,21 @@ __device__ __forceinline__ void onehot_table_grads_body(const OhtK& k, unsigned 
     const float* s = k.S + T.oh_off + v;
     const float* w = k.W + T.w_col + e;
     float acc = 0.f;
-    for (int n = j0; n < k.N; n += OHT_LANES) acc = fmaf(s[n * k.lds], w[n * k.ldw], acc);
+    // four steps' loads in flight at once, the multiply-adds in the same ascending order (same bits): the plain loop waited for
+    // each step's two loads -- ten dependent round trips for N = 148 at the very end of the weight-gradient branch
+    for (int n0 = j0; n0 < k.N; n0 += 4 * OHT_LANES) {
+        float sv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * OHT_LANES;
+            const bool ok = n < k.N;
+            sv[u] = ok ? s[n * k.lds] : 0.f;
+            wv[u] = ok ? w[n * k.ldw] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (n0 + u * OHT_LANES < k.N) acc = fmaf(sv[u], wv[u], acc);
+    }
 #pragma unroll
     for (int o = 1; o < OHT_LANES; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (live && j0 == 0) {
@@ -413,7 +427,21 @@ __device__ __forceinline__ void fold_bwd_body(const FoldK& k, unsigned block) {
         const swr_onehot_table& T = k.tab[-1 - m];
         const int e = c - T.w_col;
         const float* s = k.dWp + n * k.lddwp + k.Kp + T.oh_off;
-        for (int q = 0; q < T.vocab; ++q) v = fmaf(s[q], T.grad[static_cast<int64_t>(q) * T.dim + e], v);
+        // (eight rows' loads in flight, multiply-adds in row order: same bits as the one-row-at-a-time loop, an eighth of its round trips)
+        const int vocab = T.vocab, dim = T.dim;
+        const float* __restrict__ g = T.grad + e;
+        for (int q0 = 0; q0 < vocab; q0 += 8) {
+            float sv[8], gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = q0 + u < vocab;
+                sv[u] = ok ? s[q0 + u] : 0.f;
+                gv[u] = ok ? g[static_cast<int64_t>(q0 + u) * dim] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + u < vocab) v = fmaf(sv[u], gv[u], v);
+        }
     }
     float* dst = k.dW + n * k.lddw + c;
     *dst = k.accumulate ? *dst + v : v;

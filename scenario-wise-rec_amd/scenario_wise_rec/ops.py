@@ -127,6 +127,8 @@ def _grad_alias(params, kind=1):
     for p in params:
         if not p.is_leaf or not p.requires_grad:       # (derived tensors, e.g. STAR's effective weights: autograd carries those)
             return None
+        if not hasattr(p, "_swr_hooked"):              # only parameters of a gradient arena (basic/module.py build_arena): a foreign
+            return None                                # leaf keeps autograd's semantics (torch.autograd.grad, tensor hooks, its own .grad)
         g = getattr(p, "grad", None)
         if g is None or g.dtype != torch.float32:
             return None

@@ -36,8 +36,15 @@ def _run(case, n_steps, use_graph, limit=None):
         SwrModule.dense_table_limit_bytes = old
 
 
+@pytest.mark.parametrize("side", ["forced", "auto"])
 @pytest.mark.parametrize("name,limit", [("mmoe", None), ("mmoe", 2048), ("ple", None), ("ppnet", None), ("star", None)])
-def test_graph_replay_matches_eager(name, limit):
+def test_graph_replay_matches_eager(name, limit, side, monkeypatch):
+    """`side`: the suite forces the side-stream forks on (tests/conftest.py); "auto" is the product default -- the lookup that
+    opens a step decides by batch size (these batches: ONE stream, the fused BatchNorm-backward + dX in front of the weight
+    gradient, the optimizer's step bookkeeping riding the loss launch)."""
+    from scenario_wise_rec import ops
+    if side == "auto":
+        monkeypatch.setattr(ops, "_SIDE_MODE", "auto")
     c = Case(name)
     a = _run(c, 6, use_graph=False, limit=limit)
     b = _run(c, 6, use_graph=True, limit=limit)

@@ -154,6 +154,8 @@ def test_one_graph_step_over_rccl_matches_eager(limit, one_stream):
     FORCES the one-graph capture: a capture that fails raises (it used to fall back to three graphs and pass)."""
     extra = () if limit is None else (str(limit),)
     env = {"DP_WORKER_BACKEND": "nccl", "SWR_DP_ONE_GRAPH": "1", "SWR_DP_ONE_STREAM": one_stream}
+    if one_stream == "1":
+        env["SWR_SIDE_STREAM"] = "auto"          # the product default (the suite forces the forks on): a short-batch step on one stream
     a = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 1, extra=extra, env_extra=env), "state1.npz"))
     b = np.load(os.path.join(run_workers("graph-gpu", "mmoe_dp2", 1, extra=extra, env_extra=dict(env, DP_EAGER_REFERENCE="1")), "state1.npz"))
     for k in a.files:
