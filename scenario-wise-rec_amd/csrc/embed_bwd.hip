@@ -617,14 +617,13 @@ __device__ __forceinline__ float from_fixed(long long hi, long long lo) {
 // and integer addition commutes, so the result is bit-identical to the sorted path whatever the order of the
 // LDS / memory-side atomics.
 template <int V>
-__global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta dm, const uint32_t* __restrict__ keys,
-                                                                const float* __restrict__ dE, int64_t ld,
-                                                                longlong2* __restrict__ slab, uint32_t* err) {
+__device__ __forceinline__ void direct_body(const DirectMeta& dm, const uint32_t* __restrict__ keys, const float* __restrict__ dE, int64_t ld,
+                                            longlong2* __restrict__ slab, uint32_t* err, const int block) {
     extern __shared__ unsigned long long lacc[];              // [elems] hi limbs, then [elems] lo limbs
     int gi = 0;
-    while (gi + 1 < dm.n_groups && dm.grp[gi + 1].block0 <= static_cast<int>(blockIdx.x)) ++gi;
+    while (gi + 1 < dm.n_groups && dm.grp[gi + 1].block0 <= block) ++gi;
     const DirectGroup& G = dm.grp[gi];
-    const int chunk_id = static_cast<int>(blockIdx.x) - G.block0;
+    const int chunk_id = block - G.block0;
     const int64_t b0 = static_cast<int64_t>(chunk_id) * G.chunk;
     const int64_t b1 = min(b0 + G.chunk, dm.B);
     const int elems = G.elems;
@@ -745,6 +744,25 @@ __global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta
             dst[j] = make_longlong2(h, l);
         }
     }
+}
+template <int V>
+__global__ __launch_bounds__(DIRECT_THREADS) void direct_kernel(const DirectMeta dm, const uint32_t* __restrict__ keys,
+                                                                const float* __restrict__ dE, int64_t ld,
+                                                                longlong2* __restrict__ slab, uint32_t* err) {
+    direct_body<V>(dm, keys, dE, ld, slab, err, static_cast<int>(blockIdx.x));
+}
+
+// Short batches: the counting sort of the large tables' keys (radix_sort.h) and the direct sums of the small tables are independent
+// and each leaves most of the chip idle (a few hundred workgroups of one latency chain each): ONE launch runs both -- workgroups
+// [0, n_direct) the direct sums, the rest the sort with 512-entry rows -- so the two chains overlap instead of following each other
+// on the step's single stream (a second stream would make the replayed graph host-bound, ops.SIDE_MIN_BATCH).  Same bodies: same bits.
+template <int ROWS>
+__global__ __launch_bounds__(DIRECT_THREADS) void rank_direct_kernel(const DirectMeta dm, const uint32_t* __restrict__ keys,
+                                                                     const float* __restrict__ dE, int64_t ld, longlong2* __restrict__ slab,
+                                                                     uint32_t* err, int n_direct, const SortMeta sm, const RankSrc src,
+                                                                     uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
+    if (static_cast<int>(blockIdx.x) < n_direct) direct_body<4>(dm, keys, dE, ld, slab, err, static_cast<int>(blockIdx.x));
+    else rank_sort_body<ROWS, DIRECT_THREADS>(sm, src, kout, vout, static_cast<int>(blockIdx.x) - n_direct, static_cast<int>(gridDim.x) - n_direct);
 }
 
 // ------------------------------------------------------------------------------------------ segsum (MFMA)
@@ -1301,6 +1319,32 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         rc = swr_zero_async(acc_hi, zero_bytes, st);
         if (rc != SWR_OK) return rc;
     }
+    // the direct sums' launch shape (needed up here: at short batches the sort shares their launch)
+    bool direct_vec4 = (ld % 4 == 0) && dE && swr_aligned16(dE);
+    size_t direct_lds = 0;
+    if ((phases & 4) && p.dm.n_blocks > 0) {
+        int max_elems = 0;
+        for (int g = 0; g < p.dm.n_groups; ++g) max_elems = std::max(max_elems, p.dm.grp[g].elems);
+        for (int q = 0; q < p.dm.n_members; ++q) direct_vec4 = direct_vec4 && p.dm.mem[q].dim % 4 == 0 && p.dm.mem[q].col % 4 == 0;
+        bool lists = false;
+        for (int g = 0; g < p.dm.n_groups; ++g)
+            lists = lists || (p.dm.grp[g].n_members == 1 && p.dm.grp[g].chunk <= DIRECT_LIST_MAX);
+        direct_lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long) + 8 +
+                     ((direct_vec4 && lists) ? sizeof(uint32_t) * (DIRECT_LIST_MAX + 2) : 0);
+        SWR_REQUIRE(direct_lds <= 160 * 1024, SWR_ERR_UNSUPPORTED);
+    }
+    bool fused_rank_direct = false;
+    {
+        const char* e = getenv("SWR_K3_FUSE");
+        bool segs = false;
+        for (int c = 0; c < 3; ++c) segs = segs || p.sg[c].n_jobs > 0;
+        // OPT-IN (SWR_K3_FUSE=1): measured at the 8 192-row shards -- config 2 0.2046-0.2059 -> 0.2025-0.2027 ms, config 4 0.3168 ->
+        // 0.3203 -- the launch's LDS size is the direct sums' (64 KB of accumulators + 12 KB list + the sort's 35 KB static): one
+        // workgroup per CU for BOTH kinds, so the ~700 workgroups run in rounds instead of side by side
+        fused_rank_direct = (e && e[0] == '1') && phases == 7 && n > 0 && p.rank_sort && p.dm.n_blocks > 0 && direct_vec4 && !segs &&
+                            direct_lds + sizeof(uint32_t) * DIRECT_THREADS * (RANK_EPB + 1) <= 150 * 1024 &&
+                            p.max_keys <= 32 * DIRECT_THREADS;
+    }
     if ((phases & 1) && n > 0 && p.rank_sort) {
         // short segments: the counting sort reads the lookup's keys itself (no build_keys launch) and carries the zero-fill
         RankSrc src;
@@ -1320,7 +1364,26 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
         }
         src.zero = reinterpret_cast<uint4*>(acc_hi);
         src.zero16 = zero_in_keys ? static_cast<int64_t>(zero_bytes / 16) : 0;
-        rank_sort_launch(p.sm, src, p.max_keys, kbuf, vbuf, st);
+        if (fused_rank_direct) {
+            // one launch with the direct sums; the sort's blocks are RANK_EPB entries of 512-entry rows: its plan counts the same blocks
+            const int rows = static_cast<int>((p.max_keys + DIRECT_THREADS - 1) / DIRECT_THREADS);
+            const void* fn = rows <= 4 ? reinterpret_cast<const void*>(rank_direct_kernel<4>)
+                           : rows <= 8 ? reinterpret_cast<const void*>(rank_direct_kernel<8>)
+                           : rows <= 16 ? reinterpret_cast<const void*>(rank_direct_kernel<16>)
+                                        : reinterpret_cast<const void*>(rank_direct_kernel<32>);
+            // (static LDS of the sort's counters + the direct sums' dynamic accumulators: past 64 KB in all the attribute is needed, and
+            // the dynamic part it allows must leave room for the static one)
+            constexpr int rank_static = static_cast<int>(sizeof(uint32_t)) * DIRECT_THREADS * (RANK_EPB + 1);
+            if (direct_lds + rank_static > 64 * 1024 && !swr_raise_lds(fn, 160 * 1024 - rank_static)) return SWR_ERR_LAUNCH;
+            const dim3 grid(static_cast<unsigned>(p.dm.n_blocks + p.sm.n_tiles));
+            longlong2* slab = reinterpret_cast<longlong2*>(ws + p.off_slab);
+            if (rows <= 4) hipLaunchKernelGGL(rank_direct_kernel<4>, grid, dim3(DIRECT_THREADS), direct_lds, st, p.dm, keys, dE, ld, slab, err_flag, p.dm.n_blocks, p.sm, src, kbuf[1], vbuf[1]);
+            else if (rows <= 8) hipLaunchKernelGGL(rank_direct_kernel<8>, grid, dim3(DIRECT_THREADS), direct_lds, st, p.dm, keys, dE, ld, slab, err_flag, p.dm.n_blocks, p.sm, src, kbuf[1], vbuf[1]);
+            else if (rows <= 16) hipLaunchKernelGGL(rank_direct_kernel<16>, grid, dim3(DIRECT_THREADS), direct_lds, st, p.dm, keys, dE, ld, slab, err_flag, p.dm.n_blocks, p.sm, src, kbuf[1], vbuf[1]);
+            else hipLaunchKernelGGL(rank_direct_kernel<32>, grid, dim3(DIRECT_THREADS), direct_lds, st, p.dm, keys, dE, ld, slab, err_flag, p.dm.n_blocks, p.sm, src, kbuf[1], vbuf[1]);
+        } else {
+            rank_sort_launch(p.sm, src, p.max_keys, kbuf, vbuf, st);
+        }
     } else if ((phases & 1) && n > 0) {
         hipLaunchKernelGGL(build_keys_kernel, dim3(static_cast<unsigned>(swr_ceil_div(n, RB_THREADS))), dim3(RB_THREADS), 0,
                            st, m, keys, kbuf[0], vbuf[0], reinterpret_cast<uint4*>(acc_hi),
@@ -1345,21 +1408,12 @@ static int run_embed_bwd(int phases, const swr_embed_grad_slot* slots, int n_slo
             else hipLaunchKernelGGL((segsum_mfma_kernel<4, 2, 2>), grid, dim3(SEG_WAVES * 64), lds, st, sg, keys, dE, ld, part, err_flag);
         }
     }
-    if ((phases & 4) && p.dm.n_blocks > 0) {
+    if ((phases & 4) && p.dm.n_blocks > 0 && !fused_rank_direct) {
         // LDS sized by the largest group (small groups -> more workgroups per CU); 16-byte loads when every lookup
-        // column span is 4-float aligned
-        int max_elems = 0;
-        bool vec4 = (ld % 4 == 0) && swr_aligned16(dE);
-        for (int g = 0; g < p.dm.n_groups; ++g) max_elems = std::max(max_elems, p.dm.grp[g].elems);
-        for (int q = 0; q < p.dm.n_members; ++q) vec4 = vec4 && p.dm.mem[q].dim % 4 == 0 && p.dm.mem[q].col % 4 == 0;
-        // the sample list (12 KB) is spent only when some workgroup takes the list branch (direct_kernel: V == 4, one lookup
-        // per workgroup, chunk <= DIRECT_LIST_MAX)
-        bool lists = false;
-        for (int g = 0; g < p.dm.n_groups; ++g)
-            lists = lists || (p.dm.grp[g].n_members == 1 && p.dm.grp[g].chunk <= DIRECT_LIST_MAX);
-        const size_t lds = 2 * static_cast<size_t>(max_elems) * sizeof(unsigned long long) + 8 +
-                           ((vec4 && lists) ? sizeof(uint32_t) * (DIRECT_LIST_MAX + 2) : 0);
-        SWR_REQUIRE(lds <= 160 * 1024, SWR_ERR_UNSUPPORTED);
+        // column span is 4-float aligned; the sample list (12 KB) is spent only when some workgroup takes the list branch
+        // (direct_kernel: V == 4, one lookup per workgroup, chunk <= DIRECT_LIST_MAX) -- computed above
+        const bool vec4 = direct_vec4;
+        const size_t lds = direct_lds;
         if (lds > 64 * 1024) {
             // above 64 KB of dynamic LDS the attribute is needed (idempotent, not a stream operation; the first call of a
             // shape happens in a warm-up step, never inside a hipGraph capture -- as bnmix.hip, gemm.hip)

@@ -253,11 +253,12 @@ struct RankSrc {
     int64_t zero16;
 };
 
-template <int ROWS>
-static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const SortMeta sm, const RankSrc src, uint32_t* __restrict__ kout,
-                                                                         uint32_t* __restrict__ vout) {
-    __shared__ uint32_t cnt[RANK_THREADS][RANK_EPB + 1];
-    const int tile = blockIdx.x;
+// THREADS: threads of the workgroup = entries per row (256 in the launch of its own; 512 where the sort shares a launch with the direct
+// sums of the embedding backward, embed_bwd.hip); `tile` / `n_tiles`: this workgroup among the sort's workgroups
+template <int ROWS, int THREADS>
+static __device__ __forceinline__ void rank_sort_body(const SortMeta& sm, const RankSrc& src, uint32_t* __restrict__ kout,
+                                                      uint32_t* __restrict__ vout, const int tile, const int n_tiles) {
+        __shared__ uint32_t cnt[THREADS][RANK_EPB + 1];
     const int tid = threadIdx.x;
     const int t = sort_table_of_tile(sm, tile);
     const int64_t seg = sm.seg_off[t];
@@ -281,7 +282,7 @@ static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const So
         locate(j, slot, b);
         return src.keys[static_cast<int64_t>(slot) * src.B + b];
     };
-    const int row_of_block = i0 / RANK_THREADS;                        // (RANK_EPB divides RANK_THREADS: the block lies in one row)
+    const int row_of_block = i0 / THREADS;                        // (RANK_EPB divides THREADS: the block lies in one row)
     // x = the entry's key as the loop below compares it: every comparison is `x < key_i + 1` with the right-hand sides loop-invariant
     // scalars.  Rows in front of the block count when key_j <= key_i: x = key_j; the block's row and the rows behind it when
     // key_j < key_i: x = key_j + 1 (real keys are < 0xFFFFFFFF, the launcher checks: no wrap); padding never counts: x = 0xFFFFFFFF
@@ -289,7 +290,7 @@ static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const So
     uint32_t kb = 0xFFFFFFFFu;                                         // the thread's key in the block's own row
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int j = r * RANK_THREADS + tid;
+        const int j = r * THREADS + tid;
         const uint32_t kj = j < len ? key_at(j) : 0xFFFFFFFFu;
         if (r == row_of_block) kb = kj;
         x[r] = (j < len && r >= row_of_block) ? kj + 1u : kj;
@@ -301,7 +302,7 @@ static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const So
     uint32_t c[RANK_EPB];
     // the block's own row: entries with an EQUAL key come first when they stand in front
     {
-        const int j = row_of_block * RANK_THREADS + tid;
+        const int j = row_of_block * THREADS + tid;
 #pragma unroll
         for (int e = 0; e < RANK_EPB; ++e) c[e] = (j < len && kb + 1u == thr[e] && j < i0 + e) ? 1u : 0u;
     }
@@ -314,11 +315,11 @@ static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const So
     for (int e = 0; e < RANK_EPB; ++e) cnt[tid][e] = c[e];
     __syncthreads();
     // column sums: thread (e, part) adds 16 of the 256 partial counts of entry e; then the 16 parts
-    constexpr int PARTS = RANK_THREADS / RANK_EPB;
+    constexpr int PARTS = THREADS / RANK_EPB;
     const int e = tid & (RANK_EPB - 1), part = tid / RANK_EPB;
     uint32_t sum = 0;
 #pragma unroll
-    for (int q = 0; q < RANK_THREADS / PARTS; ++q) sum += cnt[part * (RANK_THREADS / PARTS) + q][e];
+    for (int q = 0; q < THREADS / PARTS; ++q) sum += cnt[part * (THREADS / PARTS) + q][e];
     __syncthreads();
     cnt[part][e] = sum;
     __syncthreads();
@@ -332,8 +333,14 @@ static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const So
         vout[seg + pos] = (static_cast<uint32_t>(slot) << 24) | static_cast<uint32_t>(b);
     }
     // (behind the sort's own loads: in front of them the fill's stores delayed the first round trip of every workgroup)
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * RANK_THREADS;
-    for (int64_t z = static_cast<int64_t>(tile) * RANK_THREADS + tid; z < src.zero16; z += stride) src.zero[z] = make_uint4(0u, 0u, 0u, 0u);
+    const int64_t stride = static_cast<int64_t>(n_tiles) * THREADS;
+    for (int64_t z = static_cast<int64_t>(tile) * THREADS + tid; z < src.zero16; z += stride) src.zero[z] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <int ROWS>
+static __global__ __launch_bounds__(RANK_THREADS) void rank_sort_kernel(const SortMeta sm, const RankSrc src, uint32_t* __restrict__ kout,
+                                                                         uint32_t* __restrict__ vout) {
+    rank_sort_body<ROWS, RANK_THREADS>(sm, src, kout, vout, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 
 // the counting sort of every segment, one launch: sm.tile == RANK_EPB (sm.tile_off counts blocks); result in buffer 1
