@@ -874,6 +874,211 @@ __global__ __launch_bounds__(RM_WAVES * 64) void rowmat_fwd2_kernel(const float*
     }
 }
 
+// ---- matrix-pipe forms (round 6).  The kernels above issue ONE multiply-add per lane and instruction on 35 of 64 lanes (88 / 71 us
+// forward, 150 us backward for HAMUR's [32 768, 8, 35] x [35, 35]: vector-instruction-bound, 3-6 x the HBM time of their 160 MB of H_b).
+// v_mfma_f32_4x4x1_16B_f32 multiplies sixteen independent 4 x 1 by 1 x 4 blocks per instruction -- 256 multiply-adds, each output a
+// k-ordered fp32 fmaf chain, i.e. the SAME sums in the same order as the loops above (bit-identical results) -- and the blocks map
+// onto this product without padding waste:
+//   out / dT: a wave takes 8 samples; block (sample s, row block rb) x column block cb, k steps: lane (blk, q) feeds
+//             A = X[s][4 rb + q][kk] (its own row of T / dOut, held in registers) and B = H_s[kk][4 cb + q] (out) or
+//             H_s[4 cb + q][kk] (dT); ceil(k / 4) accumulators of 4 registers; 16 / 16 blocks busy.
+//   dH:       a wave takes one sample; its ceil(k / 4)^2 output blocks in groups of 16, D <= 8 steps each:
+//             A = T[s][d][4 rb + q], B = dOut[s][d][4 cb + q].
+// Loads are plain dword loads (rows of 35 floats are 4-byte aligned at best); the B operand of the next k step is requested
+// before the current step's products.  D <= 8 and k <= 4 RMM_NCB (36); other shapes keep the kernels above.
+typedef float rm_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* rm_lds_ptr;
+typedef __attribute__((address_space(1))) const void* rm_glb_ptr;
+#define RMM_NCB 9                       // column blocks of 4: k <= 36
+#define RMM_WAVES 4
+
+// out / dT.  A workgroup = ONE wave = 8 samples: their H_b (8 k k contiguous floats) are copied into LDS with coalesced loads first --
+// straight from global memory a B-operand load touched eight cache lines for 128 useful bytes (16 bytes per sample) and the kernel
+// ran at a fifth of the vector kernels' speed -- and the operands are read back with conflict-free 4-byte LDS reads (a sample's
+// matrices are k k = 1 225 floats = 9 banks apart).
+template <bool TRANS>
+__global__ __launch_bounds__(RMM_WAVES * 64) void rowmat_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Hm,
+                                                                     float* __restrict__ Y, int64_t B, int D, int k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];            // [8][k k]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = lane >> 2, q = lane & 3;
+    const int rb = blk & 1;
+    const int64_t s0 = static_cast<int64_t>(blockIdx.x) * 8;
+    const int64_t s = s0 + (blk >> 1);
+    const bool s_ok = s < B;
+    const int r = 4 * rb + q;                                   // the lane's row of X
+    const int kk2 = k * k;
+    // the four waves of the workgroup share the 8 samples' H and split the column blocks: wave 0 takes blocks 0-2, wave w blocks
+    // 2 w + 1, 2 w + 2 (four workgroups per CU in different phases: one's copy runs under another's products)
+    const int cb0 = wave == 0 ? 0 : 2 * wave + 1;
+    const int ncb_w = wave == 0 ? 3 : 2;
+    // ---- H of the workgroup's samples -> LDS (16-byte LDS-DMA copies when the block is aligned, as it is for a 16-byte aligned
+    // tensor: 8 k k floats per workgroup; 1 KB per instruction, all in flight at once, no registers)
+    {
+        const int ns = static_cast<int>(min<int64_t>(8, B - s0));
+        const int n = ns * kk2;
+        const float* __restrict__ src = Hm + s0 * kk2;
+        if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+            const int n4 = n >> 2;
+            int e = 64 * wave;
+            for (; e + 64 <= n4; e += 64 * RMM_WAVES)
+                __builtin_amdgcn_global_load_lds((rm_glb_ptr)(reinterpret_cast<const float4*>(src) + e + lane),
+                                                 (rm_lds_ptr)(reinterpret_cast<float4*>(lds) + e), 16, 0, 0);
+            for (int t = 4 * (n4 / 64 * 64) + tid; t < n; t += 64 * RMM_WAVES) lds[t] = src[t];          // (< 1 KB of tail)
+        } else {
+            for (int e0 = 0; e0 < n; e0 += 16 * 64 * RMM_WAVES) {                  // 16 loads in flight per thread
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int e = e0 + u * 64 * RMM_WAVES + tid; v[u] = e < n ? src[e] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int e = e0 + u * 64 * RMM_WAVES + tid; if (e < n) lds[e] = v[u]; }
+            }
+        }
+    }
+    // A operand: the lane's row, all k elements (zero past k, for rows past D and samples past B)
+    float a[4 * RMM_NCB];
+    {
+        const float* __restrict__ xr = X + (s_ok ? s : 0) * (static_cast<int64_t>(D) * k) + (r < D ? r : 0) * k;
+        const bool ok = s_ok && r < D;
+#pragma unroll
+        for (int e = 0; e < 4 * RMM_NCB; ++e) a[e] = (ok && e < k) ? xr[e] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float* hs = lds + (blk >> 1) * kk2;
+    // B operand of step kk, the wave's column block u: H[kk][4 cb + q] (out) / H[4 cb + q][kk] (dT); zero where 4 cb + q >= k
+    auto load_b = [&](int kk, float (&b)[3]) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = 4 * (cb0 + u) + q;
+            const bool ok = s_ok && u < ncb_w && c < k && kk < k;
+            const int idx = TRANS ? c * k + kk : kk * k + c;
+            b[u] = ok ? hs[ok ? idx : 0] : 0.f;
+        }
+    };
+    rm_f32x4 acc[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) acc[u] = rm_f32x4{0.f, 0.f, 0.f, 0.f};
+    float b0[3], b1[3], b2[3], b3[3];
+    load_b(0, b0);
+    load_b(1, b1);
+    load_b(2, b2);
+    // (fully unrolled: every register-array index is a constant; steps past k are skipped by wave-uniform tests, not by `break` --
+    // with early exits hipcc kept the loop rolled and indexed `a` through scratch).  Four steps' operands in flight.
+#define RMM_STEP(KK, BC, BN)                                                                                      \
+    if ((KK) < k) {                                                                                               \
+        load_b((KK) + 3, BN);                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < 3; ++u)                                                              \
+            if (u < ncb_w) acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[KK], BC[u], acc[u], 0, 0, 0);            \
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4 * RMM_NCB; kk += 4) {
+        RMM_STEP(kk, b0, b3)
+        RMM_STEP(kk + 1, b1, b0)
+        RMM_STEP(kk + 2, b2, b1)
+        RMM_STEP(kk + 3, b3, b2)
+    }
+#undef RMM_STEP
+    // D[i][j] of block blk: register i, lane 4 blk + j  ->  Y[s][4 rb + i][4 cb + q]
+    if (s_ok) {
+        float* __restrict__ yr = Y + s * (static_cast<int64_t>(D) * k);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = 4 * (cb0 + u) + q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (u < ncb_w && c < k && 4 * rb + i < D) yr[(4 * rb + i) * k + c] = acc[u][i];
+        }
+    }
+}
+
+// dHm[s][i][j] (+)= sum_d T[s][d][i] dOut[s][d][j].  A wave takes one sample at a time: the sample's rows of T and dOut come in with
+// coalesced loads (LDS), the k k products leave through an LDS tile and coalesced stores (written straight from the accumulators
+// the 160 MB of dHm went out in 16-byte pieces).
+__global__ __launch_bounds__(RMM_WAVES * 64) void rowmat_mfma_dh_kernel(const float* __restrict__ T, const float* __restrict__ dOut,
+                                                                        float* __restrict__ dHm, int accumulate, int64_t B, int D, int k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];            // per wave: [2][D k] operands | [k k] products
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bq = lane >> 2, q = lane & 3;
+    const int ncb = (k + 3) >> 2, nblk = ncb * ncb;
+    const int kk2 = k * k, dk = D * k;
+    float* tsh = lds + wave * (2 * dk + kk2);
+    float* gsh = tsh + dk;
+    float* osh = gsh + dk;
+    constexpr int NG = (RMM_NCB * RMM_NCB + 15) / 16;           // groups of 16 blocks
+    for (int64_t s = static_cast<int64_t>(blockIdx.x) * RMM_WAVES + wave; s < B; s += static_cast<int64_t>(gridDim.x) * RMM_WAVES) {
+        const float* __restrict__ ts = T + s * dk;
+        const float* __restrict__ gs = dOut + s * dk;
+        float* __restrict__ ds = dHm + s * kk2;
+        {
+            float tv[5], gv[5];                                  // D k <= 8 x 36 = 288 floats: five per lane, all loads in flight
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const int e = u * 64 + lane; tv[u] = e < dk ? ts[e] : 0.f; gv[u] = e < dk ? gs[e] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const int e = u * 64 + lane; if (e < dk) { tsh[e] = tv[u]; gsh[e] = gv[u]; } }
+        }
+        __builtin_amdgcn_wave_barrier();
+        rm_f32x4 acc[NG];
+        int rbv[NG], cbv[NG];
+        bool okv[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int blk = 16 * g + bq;
+            okv[g] = blk < nblk;
+            rbv[g] = okv[g] ? blk / ncb : 0;
+            cbv[g] = okv[g] ? blk - rbv[g] * ncb : 0;
+            acc[g] = rm_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            if (d < D) {                                         // (wave-uniform)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int ra = 4 * rbv[g] + q, ca = 4 * cbv[g] + q;
+                    const float av = (okv[g] && ra < k) ? tsh[d * k + ra] : 0.f;
+                    const float bv = (okv[g] && ca < k) ? gsh[d * k + ca] : 0.f;
+                    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[g], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int c = 4 * cbv[g] + q;
+            if (okv[g] && c < k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = 4 * rbv[g] + i;
+                    if (rr < k) osh[rr * k + c] = acc[g][i];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (accumulate) {
+            float dv[21];                                        // k k <= 1 296 floats: 21 per lane, all loads in flight
+#pragma unroll
+            for (int u = 0; u < 21; ++u) { const int e = u * 64 + lane; dv[u] = e < kk2 ? ds[e] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 21; ++u) { const int e = u * 64 + lane; if (e < kk2) ds[e] = dv[u] + osh[e]; }
+        } else {
+            for (int e = lane; e < kk2; e += 64) ds[e] = osh[e];
+        }
+        __builtin_amdgcn_wave_barrier();                         // (the tile and the operands are reused by the next sample)
+    }
+}
+
+// OPT-IN (SWR_ROWMAT_MFMA=1; read per call: the tests compare both forms in one process).  Measured at HAMUR's config-5 shape
+// (tools/micro/rowmat_probe.py, rowmat_parts.py): forward 83 us against 109 for the pipelined vector kernel, dT 79 vs 81, dHm 99 vs 80
+// (the vector backward computes dT and dHm in ONE pass over its operands: 147 us against 182 for the two launches here), and the
+// config-5 step does not move (4.80-4.86 vs 4.84-4.85 ms): every one of these passes, vector or matrix, read-only or write-only,
+// moves its 160 MB of per-sample matrices at ~2 TB/s -- the instruction mix is not what bounds them.
+static int rowmat_mfma_mode() {
+    const char* e = getenv("SWR_ROWMAT_MFMA");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+static bool rowmat_mfma_ok(int64_t B, int D, int k) { return rowmat_mfma_mode() && D <= 8 && k <= 4 * RMM_NCB && k >= 4 && B >= 64; }
+
 static bool rowmat_pipelined() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SWR_ROWMAT_PIPE"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -884,6 +1089,11 @@ extern "C" int swr_rowmat_fwd(const float* T, const float* Hm, float* out, int64
     SWR_REQUIRE(T && Hm && out && B >= 0 && D > 0 && k > 0, SWR_ERR_ARG);
     SWR_REQUIRE(k <= RM_KMAX, SWR_ERR_UNSUPPORTED);
     if (B == 0) return SWR_OK;
+    if (rowmat_mfma_ok(B, D, k)) {
+        hipLaunchKernelGGL(rowmat_mfma_kernel<false>, dim3(static_cast<unsigned>(swr_ceil_div(B, 8))), dim3(RMM_WAVES * 64),
+                           static_cast<size_t>(8) * k * k * sizeof(float), static_cast<hipStream_t>(stream), T, Hm, out, B, D, k);
+        return swr_launch_status();
+    }
     if (rowmat_pipelined() && B >= 4096 && k * k <= 64 * 20) {
         // a wave walks ~8 samples: long enough for the prefetch to pay, short enough to fill the chip
         const unsigned grid2 = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 1024));
@@ -904,6 +1114,17 @@ extern "C" int swr_rowmat_bwd(const float* dOut, const float* T, const float* Hm
     SWR_REQUIRE(k <= RM_KMAX, SWR_ERR_UNSUPPORTED);
     const size_t lds = dT ? static_cast<size_t>(RM_WAVES) * k * k * sizeof(float) : 0;
     if (B == 0) return SWR_OK;
+    if (rowmat_mfma_ok(B, D, k)) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (dT)
+            hipLaunchKernelGGL(rowmat_mfma_kernel<true>, dim3(static_cast<unsigned>(swr_ceil_div(B, 8))), dim3(RMM_WAVES * 64),
+                               static_cast<size_t>(8) * k * k * sizeof(float), st, dOut, Hm, dT, B, D, k);
+        if (dHm)
+            hipLaunchKernelGGL(rowmat_mfma_dh_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RMM_WAVES), 2048))),
+                               dim3(RMM_WAVES * 64), static_cast<size_t>(RMM_WAVES) * (2 * D * k + k * k) * sizeof(float), st, T, dOut,
+                               dHm, accumulate_dhm, B, D, k);
+        return swr_launch_status();
+    }
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(swr_ceil_div(B, RM_WAVES), 16384));
     hipLaunchKernelGGL(rowmat_bwd_kernel, dim3(grid), dim3(RM_WAVES * 64), lds, static_cast<hipStream_t>(stream), dOut, T, Hm, dT,
                        dHm, accumulate_dhm, B, D, k);

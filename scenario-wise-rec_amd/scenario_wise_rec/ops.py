@@ -302,7 +302,8 @@ def _fork_extras():
         else:
             src = ent["src"]
             if src.is_contiguous() and src.dtype == torch.float32 and src.dim() == 2:
-                H.check(lib.swr_transpose_groups(H.ptr(src), 1, src.shape[0], src.shape[1], H.ptr(ent["buf"]), H.stream()),
+                Gq = ent.get("G", 1)
+                H.check(lib.swr_transpose_groups(H.ptr(src), Gq, src.shape[0] // Gq, src.shape[1], H.ptr(ent["buf"]), H.stream()),
                         "swr_transpose_groups")              # (was an ATen strided copy per layer and step)
             else:
                 ent["buf"].copy_(src.t())
@@ -341,6 +342,27 @@ def _transposed_weight(W):
     Wt = transpose_groups(W, 1)
     if SIDE_STREAM and len(_side["wt"]) < 64:
         _side["wt"][key] = {"src": W.detach(), "buf": torch.empty_like(Wt), "epoch": -1}
+    return Wt
+
+
+WT_GROUPS_FORK = os.environ.get("SWR_WT_GROUPS_FORK", "1") != "0"
+
+
+def _transposed_groups(W, G, stable):
+    """transpose_groups(W, G) for a grouped dX product, made by this step's forward-time fork when the step has one and the
+    weights are `stable` (a zero-copy view of arena parameters: same address and live values every step -- NOT a tensor derived
+    per step, e.g. STAR's effective weights): the copy leaves the backward pass's critical path (config 6: seven of them, ~15 us
+    each at 8 x [128, 452] .. [32, 64])."""
+    if not (stable and SIDE_STREAM and WT_GROUPS_FORK):
+        return transpose_groups(W, G)
+    key = (W.data_ptr(), W.shape[0], W.shape[1], "g", G)
+    ent = _side["wt"].get(key)
+    if ent is not None and ent["epoch"] == _side["epoch"]:
+        join_side_streams(dw=False)
+        return ent["buf"]
+    Wt = transpose_groups(W, G)
+    if len(_side["wt"]) < 64 and W.is_contiguous() and W.dtype == torch.float32:
+        _side["wt"][key] = {"src": W.detach(), "buf": torch.empty_like(Wt), "epoch": -1, "G": G}
     return Wt
 
 
@@ -1374,7 +1396,7 @@ class LinearBNAct(Function):
                 if M >= 4096 and N % 4 == 0 and K >= 32 and K % 4 == 0 and lib.swr_gemm_precision_mode() == 1:
                     # the groups' transposed weights (one small launch) make dX an "nt" product: the [N, K] layout the bf16-split
                     # kernel stages, 2.7 x the matrix rate of the f32-MFMA kernel the "nn" form falls to
-                    gemm("nt", dZ, transpose_groups(W, G), dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
+                    gemm("nt", dZ, _transposed_groups(W, G, direct_w), dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
                 else:
                     gemm("nn", dZ, W, dx, M, K, N, groups=G, gsA=N, gsB=N * K, gsC=K)
             else:

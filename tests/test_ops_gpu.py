@@ -1259,6 +1259,42 @@ def test_rowmat_pipelined_forward_is_bitwise_the_plain_one(B, D, k, offset):
     torch.testing.assert_close(out[:64].double(), want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,D,k,offset", [(32768, 8, 35, 0), (4099, 8, 35, 1), (515, 5, 35, 3), (777, 1, 36, 0), (1000, 3, 8, 2), (64, 8, 4, 0),
+                                          (4100, 4, 17, 1)])
+def test_rowmat_matrix_pipe_forms_are_bitwise_the_vector_ones(B, D, k, offset, monkeypatch):
+    """swr_rowmat_fwd / _bwd on v_mfma_f32_4x4x1_16B_f32 (csrc/moe.hip rowmat_mfma_kernel / _dh_kernel; D <= 8, k <= 36): every
+    output is the same k-ordered fp32 fmaf chain as in the vector kernels (SWR_ROWMAT_MFMA=0), so out, dT and dHm -- written and
+    accumulated -- agree BIT FOR BIT; ragged tails (B not a multiple of 8, k not a multiple of 4, D < 8), unaligned operands, guard
+    words around every output."""
+    from scenario_wise_rec import _hip as H
+    g = torch.Generator(device="cuda").manual_seed(B * 13 + D * 5 + k)
+
+    def view(n):
+        return torch.randn(n + offset, device="cuda", generator=g)[offset:]
+    T, Hm, dO = view(B * D * k), view(B * k * k), view(B * D * k)
+    base_dH = view(B * k * k).clone()
+    guard = 32
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SWR_ROWMAT_MFMA", mode)
+        bufs = [torch.full((n + 2 * guard,), 3.5, device="cuda") for n in (B * D * k, B * D * k, B * k * k, B * k * k)]
+        out, dT, dH, dHa = (b[guard:guard + n] for b, n in zip(bufs, (B * D * k, B * D * k, B * k * k, B * k * k)))
+        dHa.copy_(base_dH)
+        H.check(H.lib.swr_rowmat_fwd(H.ptr(T), H.ptr(Hm), H.ptr(out), B, D, k, H.stream()), "fwd")
+        H.check(H.lib.swr_rowmat_bwd(H.ptr(dO), H.ptr(T), H.ptr(Hm), H.ptr(dT), H.ptr(dH), 0, B, D, k, H.stream()), "bwd")
+        H.check(H.lib.swr_rowmat_bwd(H.ptr(dO), H.ptr(T), H.ptr(Hm), None, H.ptr(dHa), 1, B, D, k, H.stream()), "bwd acc")
+        torch.cuda.synchronize()
+        for b, n in zip(bufs, (B * D * k, B * D * k, B * k * k, B * k * k)):
+            assert bool((b[:guard] == 3.5).all()) and bool((b[guard + n:] == 3.5).all())
+        res.append([t.clone() for t in (out, dT, dH, dHa)])
+    for name, a, b in zip(("out", "dT", "dHm", "dHm accumulated"), *res):
+        assert torch.equal(a, b), name
+    T3, H3, G3 = T.view(B, D, k)[:128].double(), Hm.view(B, k, k)[:128].double(), dO.view(B, D, k)[:128].double()
+    torch.testing.assert_close(res[1][0].view(B, D, k)[:128].double(), torch.einsum("bdi,bij->bdj", T3, H3), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[1][1].view(B, D, k)[:128].double(), torch.einsum("bdj,bij->bdi", G3, H3), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[1][2].view(B, k, k)[:128].double(), torch.einsum("bdi,bdj->bij", T3, G3), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("uses", [2, 3])
 def test_rowmat_shared_factor_collects_its_gradient_in_one_buffer(uses, monkeypatch):
     """One H_b feeding several RowMat products (HAMUR's adapter cell): the backward passes add into one buffer and the last
