@@ -362,6 +362,10 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
     // direct groups (needs the accumulator offsets assigned above)
     {
         int open = -1;                               // group still accepting adjacent small lookups
+        // SWR_DIRECT_MERGE=0: every lookup a group of its own (the single-lookup workgroups list their samples first and walk the
+        // list with one memory latency per round; a merged group walks its whole chunk with two -- key, then row)
+        bool direct_merge = true;
+        { const char* e = getenv("SWR_DIRECT_MERGE"); direct_merge = !(e && e[0] == '0'); }
         auto new_group = [&](int col0) {
             DirectGroup& g = dm.grp[dm.n_groups];
             g.col0 = col0; g.width = 0; g.member0 = static_cast<int16_t>(dm.n_members); g.n_members = 0; g.elems = 0;
@@ -394,7 +398,7 @@ static int make_plan(const swr_embed_grad_slot* slots, int n_slots, int64_t B, H
             if (open >= 0) {
                 const DirectGroup& g = dm.grp[open];
                 if (g.col0 + g.width != slots[s].in_col || g.elems + elems > DIRECT_CAP_ELEMS ||
-                    g.width + tm.dim > DIRECT_THREADS)
+                    g.width + tm.dim > DIRECT_THREADS || !direct_merge)
                     open = -1;
             }
             if (open < 0) open = new_group(slots[s].in_col);
@@ -620,6 +624,9 @@ template <int V>
 __device__ __forceinline__ void direct_body(const DirectMeta& dm, const uint32_t* __restrict__ keys, const float* __restrict__ dE, int64_t ld,
                                             longlong2* __restrict__ slab, uint32_t* err, const int block) {
     extern __shared__ unsigned long long lacc[];              // [elems] hi limbs, then [elems] lo limbs
+#ifdef DIRECT_EMPTY            // (ablation builds of tools/build_variant.py only)
+    if (dm.B > 0) return;
+#endif
     int gi = 0;
     while (gi + 1 < dm.n_groups && dm.grp[gi + 1].block0 <= block) ++gi;
     const DirectGroup& G = dm.grp[gi];
@@ -630,6 +637,9 @@ __device__ __forceinline__ void direct_body(const DirectMeta& dm, const uint32_t
     const int tid = threadIdx.x;
     for (int j = tid; j < 2 * elems + 1; j += DIRECT_THREADS) lacc[j] = 0ull;    // (+ the sample list's counter word)
     __syncthreads();
+#ifdef DIRECT_ZERO_ONLY
+    if (dm.B > 0) return;
+#endif
 
     const int W = G.width / V;                                // threads per sample row
     const int spl = DIRECT_THREADS / W;                       // sample lanes
@@ -670,12 +680,46 @@ __device__ __forceinline__ void direct_body(const DirectMeta& dm, const uint32_t
         uint32_t* list = reinterpret_cast<uint32_t*>(lacc + 2 * elems);      // [0] = count (zeroed above), entries from [1]
         const uint32_t* __restrict__ kp = keys + static_cast<int64_t>(M.slot) * dm.B + b0;
         const int ns = static_cast<int>(b1 - b0);
-        for (int s = tid; s < ns; s += DIRECT_THREADS) {
-            const uint32_t r = kp[s] - static_cast<uint32_t>(M.row_lo);
-            if (r < static_cast<uint32_t>(M.rows)) list[1 + atomicAdd(&list[0], 1u)] = (static_cast<uint32_t>(s) << 16) | r;
+        // (one counter increment per WAVE: the lanes whose sample belongs here take consecutive places behind the wave's base.  With
+        // one returning LDS atomic per lane on the single counter word, the 3 072 increments of a workgroup ran one after the other --
+        // ~15 of the launch's 25 us, found by building the kernel without its walk and without its flush: 27.5 of 35 us remained)
+        // (ALL of the chunk's keys requested before the first is looked at: the rolled loop made one memory round trip per 512 keys,
+        // six in a row for a 3 072-sample chunk -- 14 of the launch's 21 us)
+        constexpr int KR = (DIRECT_LIST_MAX + DIRECT_THREADS - 1) / DIRECT_THREADS;
+        uint32_t kr[KR];
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+            const int s = u * DIRECT_THREADS + tid;
+            kr[u] = s < ns ? kp[s] : 0xFFFFFFFFu;
+        }
+#ifdef DIRECT_KEYS_ONLY        // (ablation builds only)
+        if (kr[0] + kr[KR - 1] != 0x12345u) return;
+#endif
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+            const int s0 = u * DIRECT_THREADS;
+            if (s0 >= ns) break;                                  // (workgroup-uniform)
+            const int s = s0 + tid;
+            const uint32_t r = s < ns ? kr[u] - static_cast<uint32_t>(M.row_lo) : 0xFFFFFFFFu;
+            const bool mine = r < static_cast<uint32_t>(M.rows);
+            const unsigned long long mask = __ballot(mine);
+            uint32_t base = 0u;
+            if (mask != 0ull) {
+                const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(&list[0], static_cast<uint32_t>(__popcll(mask)));
+                base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+            }
+            if (mine) list[1 + base + __popcll(mask & ((1ull << (tid & 63)) - 1ull))] = (static_cast<uint32_t>(s) << 16) | r;
         }
         __syncthreads();
+#ifdef DIRECT_LIST_ONLY
+        if (list[0] != 0x7FFFFFFFu) return;
+#endif
+#ifdef DIRECT_NO_WALK          // (ablation builds of tools/build_variant.py only)
+        const int n_mine = 0;
+#else
         const int n_mine = static_cast<int>(list[0]);
+#endif
         if (tid < spl * W) {
             const int c = (tid % W) * V, sl = tid / W;
             const int rot = sl & 3;
@@ -733,6 +777,9 @@ __device__ __forceinline__ void direct_body(const DirectMeta& dm, const uint32_t
     __syncthreads();
     // every accumulator (touched or not) goes to this workgroup's part of the slab of (lookup, sample chunk): one coalesced
     // 16-byte store per element, no zero-fill needed in front, nothing shared with another workgroup
+#ifdef DIRECT_NO_FLUSH
+    if (lacc[0] == 0x123456789ull)
+#endif
     for (int q = 0; q < G.n_members; ++q) {
         const DirectMember& M = dm.mem[G.member0 + q];
         const int n = M.rows * M.dim;
