@@ -651,7 +651,8 @@ static bool fl_split_columns(int64_t n_tiles, int nt) {
     if (nt < 2) return false;
     const char* e = getenv("SWR_FL_SPLIT");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    return n_tiles * nt <= 2048;          // rows x tiles up to two waves per SIMD: 8 192 rows x 5 tiles = 1 280 waves
+    return n_tiles * nt <= 2560;          // measured at N = 148 (5 tiles): 8 192 rows 0.2259 -> 0.2110 ms per step, 16 384 rows 0.2678 ->
+                                          // 0.2637, 32 768 rows 0.2634 -> 0.279, 65 536 rows 0.377 -> 0.417: up to 16 384 rows x 5 tiles
 }
 
 typedef __attribute__((address_space(3))) void* fl_lds_ptr;
