@@ -172,11 +172,12 @@ def _mark_touched(params):
 # same, configs 5 / 6 (32 768) and config 2 (65 536) 1-5 % faster WITH the branches.  Decided by the lookup that opens a step.
 _SIDE_MODE = os.environ.get("SWR_SIDE_STREAM", "auto")
 SIDE_MIN_BATCH = int(os.environ.get("SWR_SIDE_MIN_BATCH", 32768))
+SIDE_MIN_BATCH_FUSED = int(os.environ.get("SWR_SIDE_MIN_BATCH_FUSED", 4096))
 SIDE_STREAM = _SIDE_MODE != "0"
 # weight-gradient products of 2e9 .. 2e10 flop run on a stream of their own (_fork_dw) next to the dX -> K3 chain: 0.535 ->
 # 0.506 ms at config 2; a fork / join pair costs ~10-20 us of edges, so smaller products stay on the main stream (forking
 # every product LOSES 0.02 ms at configs 1, 3, 4) and chip-filling ones only slow what they overlap
-SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = 2e9, 2e10
+SIDE_DW_MIN_FLOP, SIDE_DW_MAX_FLOP = float(os.environ.get("SWR_SIDE_DW_MIN_FLOP", 5e8)), 2e10      # (5e8: the first layer of config 2 from 4 096 rows on)
 PAD_ROWS = os.environ.get("SWR_PAD_ROWS", "1") != "0"          # 128-byte aligned rows for the tensors of a fused gate-mix level
 FUSE_BN_DX = os.environ.get("SWR_FUSE_BN_DX", "1") != "0"      # BatchNorm backward applied inside the first layer's dX product
 FUSE_BN_DX_SINGLE = os.environ.get("SWR_FUSE_BN_DX_SINGLE", "1") != "0"   # ... also where the step runs on ONE stream (short batches)
@@ -823,7 +824,15 @@ class EmbedGather(Function):
         plan.ctx = ctx
         if _SIDE_MODE == "auto" and not _in_backward():
             global SIDE_STREAM
-            SIDE_STREAM = B >= SIDE_MIN_BATCH          # (the lookup opens the step: every fork decision of the step follows it)
+            # (the lookup opens the step: every fork decision of the step follows it.)  A replayed multi-stream graph costs the host
+            # ~7 us per node, so the forks pay where they hide more than that: from SIDE_MIN_BATCH rows on for every model, and from
+            # SIDE_MIN_BATCH_FUSED rows on for a step that has BOTH a fused first layer (few launches: ~28 nodes) and large tables
+            # (their sort, the direct sums and the first layer's weight gradient are three independent chains behind dX) -- config 2
+            # at 4 096 / 8 192 / 16 384 rows: 0.189 / 0.207 / 0.260 ms on one stream, 0.165 / 0.185 / 0.210 with the forks; SharedBottom
+            # (no large table), PLE and STAR (generic layers, 38 - 113 nodes) are faster on one stream up to 16 384 rows
+            big = any(weights[wp].numel() * 4 > plan.dense_limit_bytes for wp, *_r in plan.sparse) if plan.sparse else False
+            fused = getattr(plan, "fl", None) is not None
+            SIDE_STREAM = B >= SIDE_MIN_BATCH or (fused and big and B >= SIDE_MIN_BATCH_FUSED)
         if need_keys and ns and B > 0 and SIDE_STREAM and getattr(plan, "want_grad", False):   # a backward may follow
             # the grouping of the large tables' entries by row needs only the keys: run it NOW on the side stream,
             # hidden behind the rest of the forward and backward pass; the backward joins before it reduces
