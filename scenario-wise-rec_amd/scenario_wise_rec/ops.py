@@ -822,7 +822,9 @@ class EmbedGather(Function):
         ctx.fused_dx = None              # (compact dX, {position in plan.sparse: first compact column}) from the consuming layer
         ctx.n_k3_slots = ctx.n_grad_slots - (len(plan.oh) if plan.oh else 0)      # without the one-hot tables
         plan.ctx = ctx
-        if _SIDE_MODE == "auto" and not _in_backward():
+        if _SIDE_MODE == "auto" and not _in_backward() and getattr(plan, "want_grad", False):
+            # (only a lookup that a backward pass may follow decides: an evaluation forward between a training step's forward and its
+            # backward must not flip the choice the backward-time forks read)
             global SIDE_STREAM
             # (the lookup opens the step: every fork decision of the step follows it.)  A replayed multi-stream graph costs the host
             # ~7 us per node, so the forks pay where they hide more than that: from SIDE_MIN_BATCH rows on for every model, and from
