@@ -178,6 +178,40 @@ class FusedAdam(torch.optim.Optimizer):
         _EARLY_ADVANCED.add(hyper.data_ptr())
 
     @torch.no_grad()
+    def early_rows(self, params):
+        """Data-parallel step, on the exchange's side branch right behind the row merge: what `step()` does in FRONT of its update
+        launches -- the catch-up of the merged row lists' rows that only other ranks looked up, then the step bookkeeping -- so that
+        the main stream's tail behind the last gradient is collective -> mean -> update.  `params`: the row-sparse tables whose merged
+        lists (`_swr_sparse_grad`, `_swr_sparse_local = False`) are in place.  Same launches, same order between them; `step()`
+        notices (`_advanced`, `_behind_done`).  No-op where advance_early() would not advance either."""
+        if len(self.param_groups) != 1 or 0 not in self._hyper or getattr(self, "_advanced", False):
+            return False
+        ent = self._hyper[0]
+        if self.lazy_rows and self._since_flush + 3 >= self.hist_cap:
+            return False
+        group = self.param_groups[0]
+        hyper = self._hyper_dev(0, group, ent[0].device)
+        hist = ent[2]
+        if self.lazy_rows:
+            behind = []
+            for p in params:
+                sg = getattr(p, "_swr_sparse_grad", None)
+                if sg is None:
+                    continue
+                st = self._lazy_state(p, hist, hyper)
+                if not getattr(p, "_swr_sparse_local", False):
+                    behind.append((st, sg[0], 0))
+            if behind:
+                catchup_many(behind)
+        H.check(lib.swr_adam_advance(H.ptr(hyper), H.ptr(hist), self.hist_cap if hist is not None else 0, H.stream()),
+                "swr_adam_advance")
+        ent[3] += 1
+        self._since_flush += 1
+        self._advanced = True
+        self._behind_done = True
+        return True
+
+    @torch.no_grad()
     def advance_rider(self):
         """`advance_early` without its launch: the same bookkeeping on the host, and the device arguments for the launch that will
         carry the advance as a rider (the step's fused loss launch, ops.take_loss_rider) -- or None where advance_early would
@@ -217,13 +251,15 @@ class FusedAdam(torch.optim.Optimizer):
 
     def host_counts(self):
         """Host-side step bookkeeping (a capture runs step() on the host without executing it: snapshot / restore)."""
-        return (self._since_flush, {gi: ent[3] for gi, ent in self._hyper.items()}, getattr(self, "_advanced", False))
+        return (self._since_flush, {gi: ent[3] for gi, ent in self._hyper.items()}, getattr(self, "_advanced", False),
+                getattr(self, "_behind_done", False))
 
     def restore_host_counts(self, snap):
         self._since_flush = snap[0]
         for gi, n in snap[1].items():
             self._hyper[gi][3] = n
         self._advanced = snap[2]
+        self._behind_done = snap[3] if len(snap) > 3 else False
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -249,16 +285,19 @@ class FusedAdam(torch.optim.Optimizer):
             hist = ent[2]
             if self.lazy_rows:
                 behind = []
+                done = gi == 0 and getattr(self, "_behind_done", False)      # early_rows() caught them up already
                 for p, (urow, ugrad) in sparse:
                     # rows that take a gradient must be current BEFORE the step advances: those looked up by this
                     # rank were caught up by the forward lookup, those that only other ranks touched are caught up here
                     st = self._lazy_state(p, hist, hyper)        # (state must exist before the row kernel)
-                    if not getattr(p, "_swr_sparse_local", False):
+                    if not getattr(p, "_swr_sparse_local", False) and not done:
                         behind.append((st, urow, 0))
                 if behind:
                     catchup_many(behind)
+            if gi == 0:
+                self._behind_done = False
             if gi == 0 and getattr(self, "_advanced", False):
-                self._advanced = False                         # advance_early() already did it for this step
+                self._advanced = False                         # advance_early() / early_rows() already did it for this step
                 _EARLY_ADVANCED.discard(hyper.data_ptr())
             else:
                 if self.lazy_rows and gi == 0 and self._since_flush + 3 >= self.hist_cap:

@@ -31,6 +31,7 @@ from . import ops
 # (world 1 over RCCL, same box: 0.470 -> 0.428 ms per step at config 2, i.e. 1.27 x -> 1.16 x the single-GPU step); gloo collectives
 # are host-synchronous and cannot be captured: three graphs with eager collectives between them (the multi-process tests on one GPU)
 ONE_STREAM = os.environ.get("SWR_DP_ONE_STREAM", "auto")      # "1" / "0" / auto = with the step (ops.SIDE_STREAM): the exchange on the step's one stream
+EARLY_ROWS = os.environ.get("SWR_DP_EARLY_ROWS", "1") != "0"   # one-graph step: catch-up + step bookkeeping on the exchange's branch
 ROWS_EVENT = os.environ.get("SWR_DP_ROWS_EVENT", "1") != "0"   # one-graph step: the rows all-gather waits for the row lists alone
 ONE_GRAPH = os.environ.get("SWR_DP_ONE_GRAPH", "auto")      # "auto": one graph over RCCL (nccl backend), three with gloo; "0" / "1" force
 
@@ -432,6 +433,10 @@ class DataParallelStep(object):
                 with torch.cuda.stream(side):
                     dist.all_gather_into_tensor(xb["recv_r"], xb["send_r"], group=self.group)
                     self._merge_rows(xb, big)
+                    # the optimizer's work on the merged lists that needs no dense gradient (catch-up of rows other ranks looked
+                    # up, step bookkeeping) stays on this branch: the main stream's tail is collective -> mean -> update
+                    if EARLY_ROWS and hasattr(opt, "early_rows"):
+                        opt.early_rows(big)
             ops.run_late_jobs()
             ops.join_side_streams()
             self._send_dense(xb, arena["g"], pack=True)
