@@ -110,3 +110,43 @@ def test_side_streams_by_batch_size(name, monkeypatch):
     for k in multi:
         assert np.array_equal(multi[k], single[k]), f"{k}: one stream differs from the forked step"
         assert np.array_equal(multi[k], auto_on[k]), k
+
+
+def test_fork_policy_looks_at_what_the_step_can_overlap(monkeypatch):
+    """Automatic side-stream mode (ops.SIDE_MIN_BATCH_FUSED): a training step with a fused first layer AND a row-sparse table forks
+    from 4 096 rows on (three independent chains behind dX); the same model below that, or without a large table, stays on one
+    stream; an evaluation forward never changes the decision a training step's backward will read."""
+    from scenario_wise_rec import ops
+    from scenario_wise_rec.basic.features import DenseFeature, SparseFeature
+    from scenario_wise_rec.basic.module import SwrModule
+    from scenario_wise_rec.models.multi_domain import MMOE
+    from scenario_wise_rec.trainers import CTRTrainer
+    monkeypatch.setattr(ops, "_SIDE_MODE", "auto")
+    monkeypatch.setattr(SwrModule, "dense_table_limit_bytes", 64 * 1024)
+    rng = np.random.default_rng(1)
+
+    def step(vocab_big, B, train=True):
+        torch.manual_seed(0)
+        feats = [SparseFeature("a", vocab_big, 16), SparseFeature("b", 40, 16), SparseFeature("c", 3, 16), DenseFeature("d0")]
+        model = MMOE(feats, domain_num=3, n_expert=2, expert_params={"dims": [16]}, tower_params={"dims": [8]})
+        tr = CTRTrainer(model, "policy", optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device="cuda")
+        tr.use_graph = False
+        x = {"a": rng.integers(0, vocab_big, size=B), "b": rng.integers(0, 40, size=B), "c": rng.integers(0, 3, size=B),
+             "d0": rng.random(B).astype(np.float32), "domain_indicator": rng.integers(0, 3, size=B)}
+        xd = {k: torch.from_numpy(v).cuda() for k, v in x.items()}
+        y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).cuda()
+        if train:
+            model.train()
+            tr.train_step(xd, y)
+        else:
+            model.eval()
+            with torch.no_grad():
+                model(xd)
+        torch.cuda.synchronize()
+        return ops.SIDE_STREAM
+
+    assert step(50000, 4096) is True            # fused first layer + a 3.2 MB (row-sparse) table
+    assert step(50000, 2048) is False           # below SIDE_MIN_BATCH_FUSED
+    assert step(500, 4096) is False             # no large table: nothing to overlap but the host cost
+    assert step(50000, 4096) is True
+    assert step(500, 4096, train=False) is True  # an evaluation forward leaves the training step's decision alone
